@@ -1,0 +1,141 @@
+"""ctypes binding of libadp_hip.so (C-ABI in include/adp.h).
+
+The product path has exactly one backend: the hand-written gfx950 kernels.  If the shared
+library is missing or a tensor is not on a HIP device, calls fail loudly -- there is no CPU
+or PyTorch fallback.  (`_testing_use_library` exists so the GPU-less unit tests can point the
+same host code at the SIMT-emulated build of the *same kernel sources*; see tests/emul/.)
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libadp_hip.so")
+
+_lib = None
+_allow_cpu = False
+
+ERRORS = {-1: "bad shape", -2: "unsupported configuration", -3: "misaligned pointer", -4: "kernel launch failed",
+          -5: "null pointer"}
+
+P = c_void_p
+I = c_int64
+F = c_float
+
+
+class ConvDesc(Structure):
+    _fields_ = [(n, c_void_p) for n in ("x", "x2", "w", "bias", "pro_stats", "pro_gamma", "pro_beta", "e_scale",
+                                        "res", "out")] + \
+               [(n, c_int64) for n in ("B", "R", "R1", "Lin", "M", "N", "KT", "stride", "dil", "pad", "up",
+                                       "transposed", "prologue", "groups", "store", "sp", "e_bstride")]
+
+
+class WgradDesc(Structure):
+    _fields_ = [(n, c_void_p) for n in ("x", "x2", "dy", "pro_stats", "pro_gamma", "pro_beta", "dw", "dbias", "ws")] + \
+               [(n, c_int64) for n in ("B", "R", "R1", "Lin", "M", "N", "KT", "stride", "dil", "pad", "up",
+                                       "prologue", "groups", "accumulate")]
+
+
+# name -> (restype, argtypes); mirrors include/adp.h one to one
+SIGNATURES = {
+    "adp_version": (c_int, []),
+    "adp_conv1d": (c_int, [POINTER(ConvDesc), P]),
+    "adp_conv1d_wgrad_ws_bytes": (I, [POINTER(WgradDesc)]),
+    "adp_conv1d_wgrad": (c_int, [POINTER(WgradDesc), P]),
+    "adp_gn_stats_ws_bytes": (I, [I, I, I, I]),
+    "adp_gn_stats": (c_int, [P, I, I, I, I, F, P, P, P]),
+    "adp_row_nsplit": (I, [I, I]),
+    "adp_gn_silu_bwd_reduce": (c_int, [P, P, P, P, P, I, I, I, I, I, P, P]),
+    "adp_gn_silu_bwd_apply": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P, P]),
+    "adp_gn_param_grad": (c_int, [P, I, I, I, P, P, I, P]),
+    "adp_modulation_fwd": (c_int, [P, P, I, I, I, I, F, P, P, P]),
+    "adp_chan_ln_bwd_ws_bytes": (I, [I, I, I]),
+    "adp_modulation_bwd": (c_int, [P, P, P, I, P, I, I, I, P, P, I, P, P]),
+    "adp_ln_stats": (c_int, [P, I, I, I, F, P, P]),
+    "adp_ln_bwd": (c_int, [P, P, P, P, P, I, I, I, I, P, P, P, P]),
+    "adp_linear_fwd": (c_int, [P, P, P, I, I, I, I, I, P, I, P]),
+    "adp_linear_bwd_data_ws_bytes": (I, [I, I, I]),
+    "adp_linear_bwd_data": (c_int, [P, I, P, I, I, I, I, P, P, P]),
+    "adp_linear_bwd_weight": (c_int, [P, I, P, I, I, I, I, I, P, P, P]),
+    "adp_time_fourier_fwd": (c_int, [P, P, I, I, P, P]),
+    "adp_time_fourier_bwd": (c_int, [P, P, P, I, I, I, P, P]),
+    "adp_act_fwd": (c_int, [P, I, I, P, P]),
+    "adp_act_bwd": (c_int, [P, P, I, I, I, P, P]),
+    "adp_skipmod_bwd_ws_bytes": (I, [I, I, I]),
+    "adp_skipmod_bwd": (c_int, [P, P, P, I, I, I, I, P, P, I, P, P]),
+    "adp_v_noise": (c_int, [P, P, P, I, I, P, P, P]),
+    "adp_mse_ws_bytes": (I, [I]),
+    "adp_mse_fwd": (c_int, [P, P, I, P, P, P]),
+    "adp_mse_bwd": (c_int, [P, P, P, I, P, P]),
+    "adp_v_step": (c_int, [P, P, P, I, P, P]),
+    "adp_add": (c_int, [P, P, I, P, P]),
+    "adp_attn_fwd": (c_int, [P, P, P, I, I, I, I, I, I, I, P, P, P]),
+    "adp_attn_bwd_ws_bytes": (I, [I, I, I, I, I]),
+    "adp_attn_bwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P, P]),
+}
+
+
+def _bind(path: str):
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export what adp.h declares
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def lib():
+    """The loaded kernel library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the gfx950 kernels first "
+                "(python -m audio_diffusion_pytorch_amd.build or __graft_entry__.build()); "
+                "audio_diffusion_pytorch_amd has no CPU/PyTorch fallback path")
+        _lib = _bind(LIB_PATH)
+    return _lib
+
+
+def _testing_use_library(path, allow_cpu: bool):
+    """TESTS ONLY: route the host code to another build of the same C-ABI (the SIMT emulator)."""
+    global _lib, _allow_cpu
+    _lib = _bind(path) if path is not None else None
+    _allow_cpu = allow_cpu
+
+
+def stream() -> int:
+    if _allow_cpu and not torch.cuda.is_available():
+        return 0
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise TypeError(f"adp kernels are fp32; got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("adp kernels need contiguous tensors")
+    if not t.is_cuda and not _allow_cpu:
+        raise RuntimeError("adp kernels run on MI355X (HIP) tensors only; got a CPU tensor and there is no CPU path")
+    return t.data_ptr()
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(code, code)} ({code})")
+
+
+def call(name: str, *args):
+    check(getattr(lib(), name)(*args), name)
+
+
+def query(name: str, *args) -> int:
+    v = getattr(lib(), name)(*args)
+    if v < 0:
+        raise RuntimeError(f"{name} failed: {ERRORS.get(v, v)} ({v})")
+    return int(v)

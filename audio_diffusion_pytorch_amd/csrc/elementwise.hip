@@ -1,0 +1,204 @@
+// v-objective elementwise math and small helpers (HBM-bound streaming kernels, gfx950).
+//   adp_v_noise  : diffusion.py:88-92   x_noisy = a x + b n ; v_target = a n - b x      (2 reads, 2 writes)
+//   adp_mse_*    : diffusion.py:95      F.mse_loss(v_pred, v_target) and its gradient
+//   adp_v_step   : diffusion.py:185-187 one VSampler update, 2 reads 1 write
+//   adp_time_fourier_* : a_unet NumberEmbedder under TimeConditioningPlugin (components.py:74-76)
+#include "adp_rt.h"
+#include "adp.h"
+
+namespace {
+
+constexpr float PI_F = 3.14159265358979323846f;
+
+__global__ __launch_bounds__(256) void v_noise_kernel(const float* x, const float* noise, const float* sigma,
+                                                      int64_t per, float* x_noisy, float* v_target) {
+  const int64_t b = blockIdx.y;
+  // angle = sigma * pi / 2 evaluated left to right in fp32, as the reference does (diffusion.py:78)
+  const float angle = (sigma[b] * PI_F) / 2.0f;
+  const float a = cosf(angle), bt = sinf(angle);
+  const int64_t base = b * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+    const float xv = x[base + i], nv = noise[base + i];
+    x_noisy[base + i] = a * xv + bt * nv;
+    v_target[base + i] = a * nv - bt * xv;
+  }
+}
+
+constexpr int MSE_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* p, const float* t, int64_t n, float* ws) {
+  __shared__ float sh[4];
+  float s = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float d = p[i] - t[i];
+    s = fmaf(d, d, s);
+  }
+  s = adp_block_sum<4>(s, sh);
+  if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(64) void mse_final_kernel(const float* ws, int nb, int64_t n, float* loss) {
+  if (threadIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < nb; ++i) s += (double)ws[i];
+  loss[0] = (float)(s / (double)n);
+}
+
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* p, const float* t, const float* gloss, int64_t n,
+                                                      float* dv) {
+  const float sc = (gloss ? gloss[0] : 1.0f) * 2.0f / (float)n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    dv[i] = (p[i] - t[i]) * sc;
+}
+
+__global__ __launch_bounds__(256) void v_step_kernel(const float* x, const float* v, const float* ab4, int64_t n,
+                                                     float* xo) {
+  const float a0 = ab4[0], b0 = ab4[1], a1 = ab4[2], b1 = ab4[3];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float xv = x[i], vv = v[i];
+    const float x_pred = a0 * xv - b0 * vv;
+    const float n_pred = b0 * xv + a0 * vv;
+    xo[i] = a1 * x_pred + b1 * n_pred;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, int64_t n, float* y) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = a[i] + b[i];
+}
+
+__device__ __forceinline__ float act_f(float x, int act) {
+  return act == 1 ? adp_silu(x) : (act == 2 ? adp_gelu(x) : x);
+}
+__device__ __forceinline__ float dact_f(float x, int act) {
+  return act == 1 ? adp_dsilu(x) : (act == 2 ? adp_dgelu(x) : 1.0f);
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* x, int64_t n, int act, float* y) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = act_f(x[i], act);
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* x, const float* dy, int64_t n, int act,
+                                                      int accumulate, float* dx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const float v = dy[i] * dact_f(x[i], act);
+    dx[i] = accumulate ? dx[i] + v : v;
+  }
+}
+
+// four[b, :] = [t, sin(f_0..f_{H-1}), cos(f_0..f_{H-1})],  f_h = ((t * w_h) * 2) * pi  (a_unet order of operations)
+__global__ __launch_bounds__(256) void fourier_fwd_kernel(const float* t, const float* w, int64_t B, int64_t H,
+                                                          float* four) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * H) return;
+  const int64_t b = i / H, h = i % H;
+  const float tv = t[b];
+  const float f = ((tv * w[h]) * 2.0f) * PI_F;
+  float* row = four + b * (2 * H + 1);
+  if (h == 0) row[0] = tv;
+  row[1 + h] = sinf(f);
+  row[1 + H + h] = cosf(f);
+}
+__global__ __launch_bounds__(256) void fourier_bwd_kernel(const float* t, const float* w, const float* dfour,
+                                                          int64_t B, int64_t H, int accumulate, float* dw) {
+  const int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (h >= H) return;
+  float s = 0.0f;
+  for (int64_t b = 0; b < B; ++b) {
+    const float tv = t[b];
+    const float f = ((tv * w[h]) * 2.0f) * PI_F;
+    const float* row = dfour + b * (2 * H + 1);
+    s += (row[1 + h] * cosf(f) - row[1 + H + h] * sinf(f)) * (tv * 2.0f * PI_F);
+  }
+  dw[h] = accumulate ? dw[h] + s : s;
+}
+
+unsigned stream_grid(int64_t n) {
+  int64_t g = adp_cdiv(n, 256 * 4);
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int adp_version(void) { return 100; }
+
+extern "C" int adp_v_noise(const float* x, const float* noise, const float* sigma, int64_t B, int64_t per,
+                           float* x_noisy, float* v_target, void* stream) {
+  if (!x || !noise || !sigma || !x_noisy || !v_target) return ADP_ERR_NULL;
+  if (B <= 0 || per <= 0 || B > 65535) return ADP_ERR_SHAPE;
+  unsigned gx = stream_grid(per);
+  ADP_LAUNCH(v_noise_kernel, dim3(gx, (unsigned)B), dim3(256), stream, x, noise, sigma, per, x_noisy, v_target);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int64_t adp_mse_ws_bytes(int64_t n) {
+  (void)n;
+  return MSE_BLOCKS * (int64_t)sizeof(float);
+}
+
+extern "C" int adp_mse_fwd(const float* v_pred, const float* v_target, int64_t n, float* loss, float* ws,
+                           void* stream) {
+  if (!v_pred || !v_target || !loss || !ws) return ADP_ERR_NULL;
+  if (n <= 0) return ADP_ERR_SHAPE;
+  int nb = (int)adp_cdiv(n, 256 * 8);
+  if (nb > MSE_BLOCKS) nb = MSE_BLOCKS;
+  ADP_LAUNCH(mse_partial_kernel, dim3((unsigned)nb), dim3(256), stream, v_pred, v_target, n, ws);
+  ADP_LAUNCH(mse_final_kernel, dim3(1), dim3(64), stream, (const float*)ws, nb, n, loss);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_mse_bwd(const float* v_pred, const float* v_target, const float* gloss, int64_t n, float* dv,
+                           void* stream) {
+  if (!v_pred || !v_target || !dv) return ADP_ERR_NULL;
+  if (n <= 0) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(mse_bwd_kernel, dim3(stream_grid(n)), dim3(256), stream, v_pred, v_target, gloss, n, dv);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_v_step(const float* x, const float* v, const float* ab4, int64_t n, float* x_out, void* stream) {
+  if (!x || !v || !ab4 || !x_out) return ADP_ERR_NULL;
+  if (n <= 0) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(v_step_kernel, dim3(stream_grid(n)), dim3(256), stream, x, v, ab4, n, x_out);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_add(const float* a, const float* b, int64_t n, float* y, void* stream) {
+  if (!a || !b || !y) return ADP_ERR_NULL;
+  if (n <= 0) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(add_kernel, dim3(stream_grid(n)), dim3(256), stream, a, b, n, y);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_act_fwd(const float* x, int64_t n, int64_t act, float* y, void* stream) {
+  if (!x || !y) return ADP_ERR_NULL;
+  if (n <= 0 || act < 0 || act > 2) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(act_fwd_kernel, dim3((unsigned)adp_cdiv(n, 256)), dim3(256), stream, x, n, (int)act, y);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_act_bwd(const float* x, const float* dy, int64_t n, int64_t act, int64_t accumulate, float* dx,
+                           void* stream) {
+  if (!x || !dy || !dx) return ADP_ERR_NULL;
+  if (n <= 0 || act < 0 || act > 2) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(act_bwd_kernel, dim3((unsigned)adp_cdiv(n, 256)), dim3(256), stream, x, dy, n, (int)act,
+             (int)accumulate, dx);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_time_fourier_fwd(const float* t, const float* w, int64_t B, int64_t H, float* four, void* stream) {
+  if (!t || !w || !four) return ADP_ERR_NULL;
+  if (B <= 0 || H <= 0) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(fourier_fwd_kernel, dim3((unsigned)adp_cdiv(B * H, 256)), dim3(256), stream, t, w, B, H, four);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_time_fourier_bwd(const float* t, const float* w, const float* dfour, int64_t B, int64_t H,
+                                    int64_t accumulate, float* dw, void* stream) {
+  if (!t || !w || !dfour || !dw) return ADP_ERR_NULL;
+  if (B <= 0 || H <= 0) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(fourier_bwd_kernel, dim3((unsigned)adp_cdiv(H, 256)), dim3(256), stream, t, w, dfour, B, H,
+             (int)accumulate, dw);
+  return ADP_LAUNCH_OK();
+}

@@ -1,0 +1,223 @@
+// Small-batch Linear layers of the conditioning path (gfx950, HBM-bound weight streaming):
+// TimeConditioningPlugin's MLP (components.py:74-76) and the bank of every
+// `Linear(modulation_features -> 2C | C)(SiLU(features))` that ModulationItem / SkipModulate own
+// (components.py:90, :99, modulation_features :48).  With B <= 16 rows these are GEMV-shaped: the weight
+// matrix is read exactly once with 16-byte lane loads, the few activation rows sit in LDS.
+#include "adp_rt.h"
+#include "adp.h"
+
+namespace {
+
+constexpr int LIN_BMAX = 16;
+constexpr int LIN_KC = 1024;  // K chunk held in LDS: 16 rows x 1024 x 4 B = 64 KiB max
+
+__device__ __forceinline__ float lin_act(float x, int act) {
+  return act == 1 ? adp_silu(x) : (act == 2 ? adp_gelu(x) : x);
+}
+
+// stage act(x[b, k0 : k0+kc]) for all rows into xs[b][LIN_KC]
+__device__ __forceinline__ void lin_stage(const float* x, int64_t B, int64_t K, int64_t k0, int kc, int act,
+                                          float* xs) {
+  for (int e = threadIdx.x; e < (int)B * LIN_KC; e += 256) {
+    const int b = e / LIN_KC, k = e - b * LIN_KC;
+    xs[e] = (k < kc) ? lin_act(x[b * K + k0 + k], act) : 0.0f;
+  }
+}
+
+// y[b, n] = post(bias[n] + sum_k act(x[b,k]) w[n,k]); one wave per output row n, lanes stride K by 4
+template <int BT>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* x, const float* w, const float* bias,
+                                                         int64_t B, int64_t K, int64_t N, int act, int post,
+                                                         int64_t ybstride, float* y) {
+  __shared__ float xs[BT * LIN_KC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+  float acc[BT];
+#pragma unroll
+  for (int b = 0; b < BT; ++b) acc[b] = 0.0f;
+  const bool vec = (K % 4 == 0);
+  for (int64_t k0 = 0; k0 < K; k0 += LIN_KC) {
+    const int kc = (int)((K - k0) < LIN_KC ? (K - k0) : LIN_KC);
+    __syncthreads();
+    lin_stage(x, B, K, k0, kc, act, xs);
+    __syncthreads();
+    if (n < N) {
+      const float* wr = w + n * K + k0;
+      for (int k = lane * 4; k < kc; k += 256) {
+        float w0, w1, w2, w3;
+        if (vec) {
+          const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+          w0 = wv.x; w1 = wv.y; w2 = wv.z; w3 = wv.w;
+        } else {
+          w0 = wr[k];
+          w1 = (k + 1 < kc) ? wr[k + 1] : 0.0f;
+          w2 = (k + 2 < kc) ? wr[k + 2] : 0.0f;
+          w3 = (k + 3 < kc) ? wr[k + 3] : 0.0f;
+        }
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+          if (b < B) {
+            const float* xr = xs + b * LIN_KC + k;
+            acc[b] = fmaf(w0, xr[0], fmaf(w1, xr[1], fmaf(w2, xr[2], fmaf(w3, xr[3], acc[b]))));
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < BT; ++b) {
+    const float s = adp_wave_sum(acc[b]);
+    if (lane == 0 && n < N && b < B) {
+      float v = s + (bias ? bias[n] : 0.0f);
+      if (post == 2) v = adp_gelu(v);
+      y[b * ybstride + n] = v;
+    }
+  }
+}
+
+// partial[p][b][k] = sum_{n in block p's 256-row range} dy[b,n] w[n,k]; thread owns 4 consecutive k
+template <int BT>
+__global__ __launch_bounds__(256) void linear_bwd_data_kernel(const float* dy, int64_t dybstride, const float* w,
+                                                              int64_t B, int64_t K, int64_t N, float* ws) {
+  constexpr int NR = 256;
+  __shared__ float dys[BT * NR];
+  const int64_t n0 = (int64_t)blockIdx.x * NR;
+  const int nr = (int)((N - n0) < NR ? (N - n0) : NR);
+  for (int e = threadIdx.x; e < BT * NR; e += 256) {
+    const int b = e / NR, j = e - b * NR;
+    dys[e] = (b < B && j < nr) ? dy[b * dybstride + n0 + j] : 0.0f;
+  }
+  __syncthreads();
+  const bool vec = (K % 4 == 0);
+  for (int64_t k = (int64_t)threadIdx.x * 4; k < K; k += 1024) {
+    float acc[BT][4];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) acc[b][0] = acc[b][1] = acc[b][2] = acc[b][3] = 0.0f;
+    for (int j = 0; j < nr; ++j) {
+      const float* wr = w + (n0 + j) * K + k;
+      float w0, w1, w2, w3;
+      if (vec) {
+        const float4 wv = *reinterpret_cast<const float4*>(wr);
+        w0 = wv.x; w1 = wv.y; w2 = wv.z; w3 = wv.w;
+      } else {
+        w0 = wr[0];
+        w1 = (k + 1 < K) ? wr[1] : 0.0f;
+        w2 = (k + 2 < K) ? wr[2] : 0.0f;
+        w3 = (k + 3 < K) ? wr[3] : 0.0f;
+      }
+#pragma unroll
+      for (int b = 0; b < BT; ++b) {
+        const float d = dys[b * NR + j];
+        acc[b][0] = fmaf(d, w0, acc[b][0]);
+        acc[b][1] = fmaf(d, w1, acc[b][1]);
+        acc[b][2] = fmaf(d, w2, acc[b][2]);
+        acc[b][3] = fmaf(d, w3, acc[b][3]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      if (b < B) {
+        float* o = ws + ((int64_t)blockIdx.x * B + b) * K + k;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (k + q < K) o[q] = acc[b][q];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void linear_bwd_data_reduce_kernel(const float* ws, int64_t P, int64_t BK,
+                                                                     int accumulate, float* dxa) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= BK) return;
+  float s = 0.0f;
+  for (int64_t p = 0; p < P; ++p) s += ws[p * BK + i];
+  dxa[i] = accumulate ? dxa[i] + s : s;
+}
+
+// dw[n,k] = sum_b dy[b,n] act(x[b,k]) ; dbias[n] = sum_b dy[b,n]; one wave per row n
+template <int BT>
+__global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float* dy, int64_t dybstride, const float* x,
+                                                                int64_t B, int64_t K, int64_t N, int act,
+                                                                int accumulate, float* dw, float* dbias) {
+  __shared__ float xs[BT * LIN_KC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+  float d[BT];
+#pragma unroll
+  for (int b = 0; b < BT; ++b) d[b] = (b < B && n < N) ? dy[b * dybstride + n] : 0.0f;
+  if (dbias && lane == 0 && n < N) {
+    float s = 0.0f;
+#pragma unroll
+    for (int b = 0; b < BT; ++b) s += d[b];
+    dbias[n] = accumulate ? dbias[n] + s : s;
+  }
+  for (int64_t k0 = 0; k0 < K; k0 += LIN_KC) {
+    const int kc = (int)((K - k0) < LIN_KC ? (K - k0) : LIN_KC);
+    __syncthreads();
+    lin_stage(x, B, K, k0, kc, act, xs);
+    __syncthreads();
+    if (n < N) {
+      for (int k = lane; k < kc; k += 64) {
+        float s = 0.0f;
+#pragma unroll
+        for (int b = 0; b < BT; ++b)
+          if (b < B) s = fmaf(d[b], xs[b * LIN_KC + k], s);
+        float* o = dw + n * K + k0 + k;
+        *o = accumulate ? *o + s : s;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+#define LIN_DISPATCH(B, CALL)                   \
+  do {                                          \
+    if ((B) <= 4) { constexpr int BT = 4; CALL; }        \
+    else if ((B) <= 8) { constexpr int BT = 8; CALL; }   \
+    else { constexpr int BT = 16; CALL; }       \
+  } while (0)
+
+extern "C" int adp_linear_fwd(const float* x, const float* w, const float* bias, int64_t B, int64_t K, int64_t N,
+                              int64_t act, int64_t post, float* y, int64_t y_bstride, void* stream) {
+  if (!x || !w || !y) return ADP_ERR_NULL;
+  if (B <= 0 || B > LIN_BMAX || K <= 0 || N <= 0) return ADP_ERR_SHAPE;
+  if (act < 0 || act > 2 || (post != 0 && post != 2)) return ADP_ERR_UNSUPPORTED;
+  if (y_bstride == 0) y_bstride = N;
+  dim3 grid((unsigned)adp_cdiv(N, 4));
+  LIN_DISPATCH(B, ADP_LAUNCH((linear_fwd_kernel<BT>), grid, dim3(256), stream, x, w, bias, B, K, N, (int)act,
+                             (int)post, y_bstride, y));
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int64_t adp_linear_bwd_data_ws_bytes(int64_t B, int64_t K, int64_t N) {
+  if (B <= 0 || K <= 0 || N <= 0) return ADP_ERR_SHAPE;
+  return adp_cdiv(N, 256) * B * K * (int64_t)sizeof(float);
+}
+
+extern "C" int adp_linear_bwd_data(const float* dy, int64_t dy_bstride, const float* w, int64_t B, int64_t K,
+                                   int64_t N, int64_t accumulate, float* dxa, float* ws, void* stream) {
+  if (!dy || !w || !dxa || !ws) return ADP_ERR_NULL;
+  if (B <= 0 || B > LIN_BMAX || K <= 0 || N <= 0) return ADP_ERR_SHAPE;
+  if (dy_bstride == 0) dy_bstride = N;
+  const int64_t P = adp_cdiv(N, 256);
+  LIN_DISPATCH(B, ADP_LAUNCH((linear_bwd_data_kernel<BT>), dim3((unsigned)P), dim3(256), stream, dy, dy_bstride, w,
+                             B, K, N, ws));
+  ADP_LAUNCH(linear_bwd_data_reduce_kernel, dim3((unsigned)adp_cdiv(B * K, 256)), dim3(256), stream,
+             (const float*)ws, P, B * K, (int)accumulate, dxa);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_linear_bwd_weight(const float* dy, int64_t dy_bstride, const float* x, int64_t B, int64_t K,
+                                     int64_t N, int64_t act, int64_t accumulate, float* dw, float* dbias,
+                                     void* stream) {
+  if (!dy || !x || !dw) return ADP_ERR_NULL;
+  if (B <= 0 || B > LIN_BMAX || K <= 0 || N <= 0) return ADP_ERR_SHAPE;
+  if (act < 0 || act > 2) return ADP_ERR_UNSUPPORTED;
+  if (dy_bstride == 0) dy_bstride = N;
+  dim3 grid((unsigned)adp_cdiv(N, 4));
+  LIN_DISPATCH(B, ADP_LAUNCH((linear_bwd_weight_kernel<BT>), grid, dim3(256), stream, dy, dy_bstride, x, B, K, N,
+                             (int)act, (int)accumulate, dw, dbias));
+  return ADP_LAUNCH_OK();
+}

@@ -1,0 +1,392 @@
+// Normalisation family for gfx950 (HBM-bound streaming + wave-shuffle / LDS reductions):
+//   * GroupNorm statistics and the backward of SiLU(GroupNorm(x))        (a_unet ConvBlock; components.py:89)
+//   * Modulation: per-position LayerNorm over channels * (1+scale) + shift  (a_unet ModulationItem; components.py:90)
+//   * LayerNorm-over-channels statistics / backward for the attention projections (components.py:92-93)
+//   * SkipModulate backward                                              (components.py:99)
+// Layout [B, C, L], L fastest: lanes always run along L so every global access is a coalesced 256-B wave load.
+// All cross-workgroup reductions are two-stage through a caller-provided workspace (deterministic, no atomics).
+#include "adp_rt.h"
+#include "adp.h"
+
+namespace {
+
+constexpr int GN_CHUNK = 4096;  // elements per partial-statistics workgroup (16 per thread, register resident)
+
+// ---- GroupNorm statistics: chunk-local (mean, M2) then Chan's exact combination ------------------------
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* x, int64_t NG, int64_t nchunks, float* ws) {
+  __shared__ float sh[4];
+  const int64_t bg = blockIdx.y, c = blockIdx.x;
+  const float* base = x + bg * NG + c * GN_CHUNK;
+  const int64_t cnt = (NG - c * GN_CHUNK) < GN_CHUNK ? (NG - c * GN_CHUNK) : GN_CHUNK;
+  float v[16];
+  float s = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int64_t i = (int64_t)j * 256 + threadIdx.x;
+    v[j] = (i < cnt) ? base[i] : 0.0f;
+    s += v[j];
+  }
+  const float mean = adp_block_sum<4>(s, sh) / (float)cnt;
+  float q = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int64_t i = (int64_t)j * 256 + threadIdx.x;
+    const float dlt = v[j] - mean;
+    q += (i < cnt) ? dlt * dlt : 0.0f;
+  }
+  const float m2 = adp_block_sum<4>(q, sh);
+  if (threadIdx.x == 0) {
+    ws[(bg * nchunks + c) * 2] = mean;
+    ws[(bg * nchunks + c) * 2 + 1] = m2;
+  }
+}
+
+__global__ __launch_bounds__(64) void gn_final_kernel(const float* ws, int64_t NG, int64_t nchunks, float eps,
+                                                      float* stats) {
+  const int64_t bg = blockIdx.x;
+  const int lane = threadIdx.x;
+  float s = 0.0f;
+  for (int64_t c = lane; c < nchunks; c += 64) {
+    const int64_t cnt = (NG - c * GN_CHUNK) < GN_CHUNK ? (NG - c * GN_CHUNK) : GN_CHUNK;
+    s += ws[(bg * nchunks + c) * 2] * (float)cnt;
+  }
+  const float mean = adp_wave_sum(s) / (float)NG;
+  float q = 0.0f;
+  for (int64_t c = lane; c < nchunks; c += 64) {
+    const int64_t cnt = (NG - c * GN_CHUNK) < GN_CHUNK ? (NG - c * GN_CHUNK) : GN_CHUNK;
+    const float dm = ws[(bg * nchunks + c) * 2] - mean;
+    q += ws[(bg * nchunks + c) * 2 + 1] + (float)cnt * dm * dm;
+  }
+  q = adp_wave_sum(q);
+  if (lane == 0) {
+    stats[bg * 2] = mean;
+    stats[bg * 2 + 1] = 1.0f / sqrtf(q / (float)NG + eps);
+  }
+}
+
+// ---- backward of y = SiLU(GN(x)) ------------------------------------------------------------------------
+// ab[b, c, split, {A,B}] : A = sum ds*xhat, B = sum ds over the split's slice of L, ds = dact * silu'(h)
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* x, const float* dact, const float* stats,
+                                                            const float* gamma, const float* beta, int64_t C,
+                                                            int64_t L, int64_t G, int64_t NS, int64_t CL, float* ab) {
+  __shared__ float sh[4];
+  const int64_t row = blockIdx.y, split = blockIdx.x;
+  const int64_t b = row / C, c = row % C, g = c / (C / G);
+  const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+  const float ga = gamma[c], be = beta[c];
+  const int64_t lo = split * CL, hi = (lo + CL < L) ? lo + CL : L;
+  const float* xr = x + row * L;
+  const float* dr = dact + row * L;
+  float a = 0.0f, bs = 0.0f;
+  for (int64_t l = lo + threadIdx.x; l < hi; l += 256) {
+    const float xh = (xr[l] - mean) * rstd;
+    const float h = fmaf(xh, ga, be);
+    const float ds = dr[l] * adp_dsilu(h);
+    a = fmaf(ds, xh, a);
+    bs += ds;
+  }
+  a = adp_block_sum<4>(a, sh);
+  bs = adp_block_sum<4>(bs, sh);
+  if (threadIdx.x == 0) {
+    ab[(row * NS + split) * 2] = a;
+    ab[(row * NS + split) * 2 + 1] = bs;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* x, const float* dact, const float* stats,
+                                                           const float* gamma, const float* beta, const float* ab,
+                                                           const float* dres, int64_t C, int64_t L, int64_t G,
+                                                           int64_t NS, int64_t CL, float* dx) {
+  __shared__ float sh[4];
+  const int64_t row = blockIdx.y, split = blockIdx.x;
+  const int64_t b = row / C, c = row % C, Cg = C / G, g = c / Cg;
+  const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+  float sa = 0.0f, sb = 0.0f;
+  for (int64_t e = threadIdx.x; e < Cg * NS; e += 256) {
+    const int64_t cc = g * Cg + e / NS, spx = e % NS;
+    const float gm = gamma[cc];
+    sa = fmaf(gm, ab[((b * C + cc) * NS + spx) * 2], sa);
+    sb = fmaf(gm, ab[((b * C + cc) * NS + spx) * 2 + 1], sb);
+  }
+  const float inv = 1.0f / ((float)Cg * (float)L);
+  const float m2 = adp_block_sum<4>(sa, sh) * inv;
+  const float m1 = adp_block_sum<4>(sb, sh) * inv;
+  const float ga = gamma[c], be = beta[c];
+  const int64_t lo = split * CL, hi = (lo + CL < L) ? lo + CL : L;
+  const float* xr = x + row * L;
+  const float* dr = dact + row * L;
+  for (int64_t l = lo + threadIdx.x; l < hi; l += 256) {
+    const float xh = (xr[l] - mean) * rstd;
+    const float h = fmaf(xh, ga, be);
+    const float ds = dr[l] * adp_dsilu(h);
+    float v = rstd * (ga * ds - m1 - xh * m2);
+    if (dres) v += dres[row * L + l];
+    dx[row * L + l] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* ab, int64_t B, int64_t C, int64_t NS,
+                                                            float* dgamma, float* dbeta, int accumulate) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.0f, bs = 0.0f;
+  for (int64_t b = 0; b < B; ++b)
+    for (int64_t s = 0; s < NS; ++s) {
+      a += ab[((b * C + c) * NS + s) * 2];
+      bs += ab[((b * C + c) * NS + s) * 2 + 1];
+    }
+  dgamma[c] = accumulate ? dgamma[c] + a : a;
+  dbeta[c] = accumulate ? dbeta[c] + bs : bs;
+}
+
+// ---- LayerNorm over channels (per position): tile = 64 positions x all channels, 4 waves stride channels ---
+// mode 0: y = xhat * (1 + ss[b*bstride + c]) + ss[b*bstride + C + c]      (Modulation)
+// y == NULL: statistics only.
+__global__ __launch_bounds__(256) void chan_ln_fwd_kernel(const float* x, const float* ss, int64_t bstride, int64_t C,
+                                                          int64_t L, float eps, float* y, float* stats) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t l = (int64_t)blockIdx.x * 64 + lane, b = blockIdx.y;
+  const bool valid = l < L;
+  const float* xb = x + b * C * L;
+  float s = 0.0f;
+  for (int64_t c = wave; c < C; c += 4) s += valid ? xb[c * L + l] : 0.0f;
+  red[wave][lane] = s;
+  __syncthreads();
+  const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+  __syncthreads();
+  float q = 0.0f;
+  for (int64_t c = wave; c < C; c += 4) {
+    const float dlt = valid ? xb[c * L + l] - mean : 0.0f;
+    q = fmaf(dlt, dlt, q);
+  }
+  red[wave][lane] = q;
+  __syncthreads();
+  const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (wave == 0 && valid) {
+    stats[(b * L + l) * 2] = mean;
+    stats[(b * L + l) * 2 + 1] = rstd;
+  }
+  if (y == nullptr) return;
+  float* yb = y + b * C * L;
+  const float* sb = ss + b * bstride;
+  for (int64_t c = wave; c < C; c += 4) {
+    const float sc = 1.0f + sb[c], sft = sb[C + c];
+    if (valid) yb[c * L + l] = fmaf((xb[c * L + l] - mean) * rstd, sc, sft);
+  }
+}
+
+// Backward of y = xhat * mul_c + add_c with mul_c = 1 + ss[b*bstride + c] (gamma == NULL) or gamma[c].
+// dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)), g = dy * mul_c   (+ dres)
+// partial per-channel sums over the tile: ws[b][0][c][tile] = sum dy*xhat, ws[b][1][c][tile] = sum dy
+__global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const float* x, const float* dy, const float* ss,
+                                                          int64_t bstride, const float* gamma, const float* stats,
+                                                          const float* dres, int64_t C, int64_t L, int64_t NT,
+                                                          float* dx, float* ws) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tile = blockIdx.x, l = tile * 64 + lane, b = blockIdx.y;
+  const bool valid = l < L;
+  const float* xb = x + b * C * L;
+  const float* db = dy + b * C * L;
+  const float mean = valid ? stats[(b * L + l) * 2] : 0.0f;
+  const float rstd = valid ? stats[(b * L + l) * 2 + 1] : 0.0f;
+  float s1 = 0.0f, s2 = 0.0f;
+  for (int64_t c = wave; c < C; c += 4) {
+    const float mul = gamma ? gamma[c] : 1.0f + ss[b * bstride + c];
+    const float d = valid ? db[c * L + l] : 0.0f;
+    const float xh = valid ? (xb[c * L + l] - mean) * rstd : 0.0f;
+    const float g = d * mul;
+    s1 += g;
+    s2 = fmaf(g, xh, s2);
+    const float pa = adp_wave_sum(d * xh), pb = adp_wave_sum(d);
+    if (lane == 0) {
+      ws[((b * 2 + 0) * C + c) * NT + tile] = pa;
+      ws[((b * 2 + 1) * C + c) * NT + tile] = pb;
+    }
+  }
+  red[0][wave][lane] = s1;
+  red[1][wave][lane] = s2;
+  __syncthreads();
+  const float m1 = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / (float)C;
+  const float m2 = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / (float)C;
+  float* ob = dx + b * C * L;
+  for (int64_t c = wave; c < C; c += 4) {
+    if (!valid) continue;
+    const float mul = gamma ? gamma[c] : 1.0f + ss[b * bstride + c];
+    const float xh = (xb[c * L + l] - mean) * rstd;
+    float v = rstd * (db[c * L + l] * mul - m1 - xh * m2);
+    if (dres) v += dres[(b * C + c) * L + l];
+    ob[c * L + l] = v;
+  }
+}
+
+// out[b*bstride + j] (or out[j] summed over b) = sum_t ws[(b*W + j)*NT + t]; one wave per row
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* ws, int64_t B, int64_t W, int64_t NT,
+                                                          int64_t bstride, int sum_over_b, int accumulate,
+                                                          float* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t rows = sum_over_b ? W : B * W;
+  if (row >= rows) return;
+  float s = 0.0f;
+  if (sum_over_b) {
+    for (int64_t b = 0; b < B; ++b)
+      for (int64_t t = lane; t < NT; t += 64) s += ws[(b * W + row) * NT + t];
+  } else {
+    for (int64_t t = lane; t < NT; t += 64) s += ws[row * NT + t];
+  }
+  s = adp_wave_sum(s);
+  if (lane == 0) {
+    const int64_t o = sum_over_b ? row : (row / W) * bstride + (row % W);
+    out[o] = accumulate ? out[o] + s : s;
+  }
+}
+
+// ---- SkipModulate backward: dx = scale[b,c] * g ; partial dot(g, x) per (row, split) -------------------------
+__global__ __launch_bounds__(256) void skipmod_bwd_kernel(const float* g, const float* x, const float* scale,
+                                                          int64_t sbstride, int64_t C, int64_t L, int64_t NS,
+                                                          int64_t CL, float* dx, float* ws) {
+  __shared__ float sh[4];
+  const int64_t row = blockIdx.y, split = blockIdx.x;
+  const int64_t b = row / C, c = row % C;
+  const float sc = scale[b * sbstride + c];
+  const int64_t lo = split * CL, hi = (lo + CL < L) ? lo + CL : L;
+  float dot = 0.0f;
+  for (int64_t l = lo + threadIdx.x; l < hi; l += 256) {
+    const float gv = g[row * L + l];
+    dot = fmaf(gv, x[row * L + l], dot);
+    dx[row * L + l] = sc * gv;
+  }
+  dot = adp_block_sum<4>(dot, sh);
+  if (threadIdx.x == 0) ws[row * NS + split] = dot;
+}
+
+int64_t row_nsplit(int64_t rows, int64_t L) {
+  int64_t ns = adp_cdiv(1024, rows);
+  const int64_t mx = L / 1024 > 1 ? L / 1024 : 1;
+  if (ns > mx) ns = mx;
+  if (ns < 1) ns = 1;
+  if (ns > 65535) ns = 65535;
+  return ns;
+}
+
+}  // namespace
+
+extern "C" int64_t adp_gn_stats_ws_bytes(int64_t B, int64_t C, int64_t L, int64_t G) {
+  if (B <= 0 || C <= 0 || L <= 0 || G <= 0 || C % G) return ADP_ERR_SHAPE;
+  const int64_t NG = (C / G) * L;
+  return B * G * adp_cdiv(NG, GN_CHUNK) * 2 * (int64_t)sizeof(float);
+}
+
+extern "C" int adp_gn_stats(const float* x, int64_t B, int64_t C, int64_t L, int64_t G, float eps, float* stats,
+                            float* ws, void* stream) {
+  if (!x || !stats || !ws) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || L <= 0 || G <= 0 || C % G) return ADP_ERR_SHAPE;
+  const int64_t NG = (C / G) * L, nchunks = adp_cdiv(NG, GN_CHUNK);
+  if (B * G > 65535) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(gn_partial_kernel, dim3((unsigned)nchunks, (unsigned)(B * G)), dim3(256), stream, x, NG, nchunks, ws);
+  ADP_LAUNCH(gn_final_kernel, dim3((unsigned)(B * G)), dim3(64), stream, (const float*)ws, NG, nchunks, eps, stats);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int64_t adp_row_nsplit(int64_t rows, int64_t L) { return row_nsplit(rows, L); }
+
+extern "C" int adp_gn_silu_bwd_reduce(const float* x, const float* dact, const float* stats, const float* gamma,
+                                      const float* beta, int64_t B, int64_t C, int64_t L, int64_t G, int64_t NS,
+                                      float* ab, void* stream) {
+  if (!x || !dact || !stats || !gamma || !beta || !ab) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || L <= 0 || G <= 0 || C % G || NS < 1 || NS > 65535 || B * C > 65535) return ADP_ERR_SHAPE;
+  const int64_t CL = adp_cdiv(L, NS);
+  ADP_LAUNCH(gn_bwd_reduce_kernel, dim3((unsigned)NS, (unsigned)(B * C)), dim3(256), stream, x, dact, stats, gamma,
+             beta, C, L, G, NS, CL, ab);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_gn_silu_bwd_apply(const float* x, const float* dact, const float* stats, const float* gamma,
+                                     const float* beta, const float* ab, const float* dres, int64_t B, int64_t C,
+                                     int64_t L, int64_t G, int64_t NS, float* dx, void* stream) {
+  if (!x || !dact || !stats || !gamma || !beta || !ab || !dx) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || L <= 0 || G <= 0 || C % G || NS < 1 || NS > 65535 || B * C > 65535) return ADP_ERR_SHAPE;
+  const int64_t CL = adp_cdiv(L, NS);
+  ADP_LAUNCH(gn_bwd_apply_kernel, dim3((unsigned)NS, (unsigned)(B * C)), dim3(256), stream, x, dact, stats, gamma,
+             beta, ab, dres, C, L, G, NS, CL, dx);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_gn_param_grad(const float* ab, int64_t B, int64_t C, int64_t NS, float* dgamma, float* dbeta,
+                                 int64_t accumulate, void* stream) {
+  if (!ab || !dgamma || !dbeta) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || NS < 1) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(gn_param_grad_kernel, dim3((unsigned)adp_cdiv(C, 256)), dim3(256), stream, ab, B, C, NS, dgamma, dbeta,
+             (int)accumulate);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_modulation_fwd(const float* x, const float* ss, int64_t ss_bstride, int64_t B, int64_t C,
+                                  int64_t L, float eps, float* y, float* stats, void* stream) {
+  if (!x || !ss || !y || !stats) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || L <= 0 || B > 65535) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(chan_ln_fwd_kernel, dim3((unsigned)adp_cdiv(L, 64), (unsigned)B), dim3(256), stream, x, ss, ss_bstride,
+             C, L, eps, y, stats);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_ln_stats(const float* x, int64_t B, int64_t C, int64_t L, float eps, float* stats, void* stream) {
+  if (!x || !stats) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || L <= 0 || B > 65535) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(chan_ln_fwd_kernel, dim3((unsigned)adp_cdiv(L, 64), (unsigned)B), dim3(256), stream, x,
+             (const float*)nullptr, (int64_t)0, C, L, eps, (float*)nullptr, stats);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int64_t adp_chan_ln_bwd_ws_bytes(int64_t B, int64_t C, int64_t L) {
+  if (B <= 0 || C <= 0 || L <= 0) return ADP_ERR_SHAPE;
+  return B * 2 * C * adp_cdiv(L, 64) * (int64_t)sizeof(float);
+}
+
+extern "C" int adp_modulation_bwd(const float* x, const float* dy, const float* ss, int64_t ss_bstride,
+                                  const float* stats, int64_t B, int64_t C, int64_t L, float* dx, float* dss,
+                                  int64_t dss_bstride, float* ws, void* stream) {
+  if (!x || !dy || !ss || !stats || !dx || !dss || !ws) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || L <= 0 || B > 65535) return ADP_ERR_SHAPE;
+  const int64_t NT = adp_cdiv(L, 64);
+  ADP_LAUNCH(chan_ln_bwd_kernel, dim3((unsigned)NT, (unsigned)B), dim3(256), stream, x, dy, ss, ss_bstride,
+             (const float*)nullptr, stats, (const float*)nullptr, C, L, NT, dx, ws);
+  ADP_LAUNCH(reduce_rows_kernel, dim3((unsigned)adp_cdiv(B * 2 * C, 4)), dim3(256), stream, (const float*)ws, B,
+             2 * C, NT, dss_bstride, 0, 0, dss);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_ln_bwd(const float* x, const float* dxn, const float* stats, const float* gamma, const float* dres,
+                          int64_t B, int64_t C, int64_t L, int64_t accumulate, float* dx, float* dgamma_dbeta,
+                          float* ws, void* stream) {
+  if (!x || !dxn || !stats || !gamma || !dx || !dgamma_dbeta || !ws) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || L <= 0 || B > 65535) return ADP_ERR_SHAPE;
+  const int64_t NT = adp_cdiv(L, 64);
+  ADP_LAUNCH(chan_ln_bwd_kernel, dim3((unsigned)NT, (unsigned)B), dim3(256), stream, x, dxn, (const float*)nullptr,
+             (int64_t)0, gamma, stats, dres, C, L, NT, dx, ws);
+  // dgamma_dbeta = [dgamma (C) | dbeta (C)]
+  ADP_LAUNCH(reduce_rows_kernel, dim3((unsigned)adp_cdiv(2 * C, 4)), dim3(256), stream, (const float*)ws, B, 2 * C,
+             NT, (int64_t)0, 1, (int)accumulate, dgamma_dbeta);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int64_t adp_skipmod_bwd_ws_bytes(int64_t B, int64_t C, int64_t L) {
+  if (B <= 0 || C <= 0 || L <= 0) return ADP_ERR_SHAPE;
+  return B * C * row_nsplit(B * C, L) * (int64_t)sizeof(float);
+}
+
+extern "C" int adp_skipmod_bwd(const float* g, const float* x, const float* scale, int64_t scale_bstride, int64_t B,
+                               int64_t C, int64_t L, float* dx, float* dscale, int64_t dscale_bstride, float* ws,
+                               void* stream) {
+  if (!g || !x || !scale || !dx || !dscale || !ws) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || L <= 0 || B * C > 65535) return ADP_ERR_SHAPE;
+  const int64_t NS = row_nsplit(B * C, L), CL = adp_cdiv(L, NS);
+  ADP_LAUNCH(skipmod_bwd_kernel, dim3((unsigned)NS, (unsigned)(B * C)), dim3(256), stream, g, x, scale,
+             scale_bstride, C, L, NS, CL, dx, ws);
+  ADP_LAUNCH(reduce_rows_kernel, dim3((unsigned)adp_cdiv(B * C, 4)), dim3(256), stream, (const float*)ws, B, C, NS,
+             dscale_bstride, 0, 0, dscale);
+  return ADP_LAUNCH_OK();
+}

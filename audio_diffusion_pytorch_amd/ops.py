@@ -1,0 +1,259 @@
+"""Host-side operator layer: one Python function per C-ABI entry point of include/adp.h.
+
+These only marshal tensors (device pointers, shapes, the current HIP stream) into the hand-written
+gfx950 kernels; they hold no arithmetic of their own and have no fallback.  Outputs are allocated by
+the caller or with torch.empty on the input's device (PyTorch = device memory + streams only).
+"""
+from ctypes import byref
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _C
+from ._C import ConvDesc, WgradDesc, ptr
+
+GN_EPS = 1e-5
+LN_EPS = 1e-5
+
+
+def _ws(nbytes: int, like: Tensor) -> Tensor:
+    return torch.empty(max(1, (nbytes + 3) // 4), dtype=torch.float32, device=like.device)
+
+
+def conv_out_len(Lin: int, KT: int, stride: int, dil: int, pad: int, up: int) -> int:
+    return (Lin * up + 2 * pad - dil * (KT - 1) - 1) // stride + 1
+
+
+def conv1d(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int = 1, dil: int = 1, pad: int = 0,
+           up: int = 1, transposed: bool = False, x2: Optional[Tensor] = None, prologue: int = 0,
+           pro_stats: Optional[Tensor] = None, pro_gamma: Optional[Tensor] = None, pro_beta: Optional[Tensor] = None,
+           groups: int = 1, e_scale: Optional[Tensor] = None, e_bstride: int = 0, res: Optional[Tensor] = None,
+           store: int = 0, sp: int = 1, N: Optional[int] = None, out: Optional[Tensor] = None) -> Tensor:
+    """Fused implicit-GEMM conv (adp_conv1d).  w: [M, R, KT] (or [R, M, KT] when transposed)."""
+    B, R1, Lin = x.shape
+    R = R1 + (x2.shape[1] if x2 is not None else 0)
+    if transposed:
+        Rw, M, KT = w.shape
+    else:
+        M, Rw, KT = w.shape
+    assert Rw == R, f"weight expects {Rw} input channels, got {R}"
+    if N is None:
+        N = conv_out_len(Lin, KT, stride, dil, pad, up)
+    if store == 0:
+        oshape = (B, M, N)
+    elif store == 1:
+        oshape = (B, M // sp, N * sp)
+    else:
+        oshape = (B, M, N // sp)
+    if out is None:
+        out = torch.empty(oshape, dtype=torch.float32, device=x.device)
+    else:
+        assert tuple(out.shape) == oshape, (out.shape, oshape)
+    d = ConvDesc(ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(pro_stats), ptr(pro_gamma), ptr(pro_beta), ptr(e_scale),
+                 ptr(res), ptr(out), B, R, R1, Lin, M, N, KT, stride, dil, pad, up, int(transposed), prologue, groups,
+                 store, sp, e_bstride)
+    _C.call("adp_conv1d", byref(d), _C.stream())
+    return out
+
+
+def conv1d_wgrad(x: Tensor, dy: Tensor, KT: int, *, stride: int = 1, dil: int = 1, pad: int = 0, up: int = 1,
+                 x2: Optional[Tensor] = None, prologue: int = 0, pro_stats: Optional[Tensor] = None,
+                 pro_gamma: Optional[Tensor] = None, pro_beta: Optional[Tensor] = None, groups: int = 1,
+                 dw: Optional[Tensor] = None, dbias: Optional[Tensor] = None, want_bias: bool = True,
+                 accumulate: bool = False):
+    B, R1, Lin = x.shape
+    R = R1 + (x2.shape[1] if x2 is not None else 0)
+    _, M, N = dy.shape
+    if dw is None:
+        dw = torch.empty((M, R, KT), dtype=torch.float32, device=x.device)
+    if dbias is None and want_bias:
+        dbias = torch.empty((M,), dtype=torch.float32, device=x.device)
+    d = WgradDesc(ptr(x), ptr(x2), ptr(dy), ptr(pro_stats), ptr(pro_gamma), ptr(pro_beta), ptr(dw), ptr(dbias), None,
+                  B, R, R1, Lin, M, N, KT, stride, dil, pad, up, prologue, groups, int(accumulate))
+    ws = _ws(_C.query("adp_conv1d_wgrad_ws_bytes", byref(d)), x)
+    d.ws = ptr(ws)
+    _C.call("adp_conv1d_wgrad", byref(d), _C.stream())
+    return dw, dbias
+
+
+def gn_stats(x: Tensor, groups: int, eps: float = GN_EPS, out: Optional[Tensor] = None) -> Tensor:
+    B, C, L = x.shape
+    stats = out if out is not None else torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+    ws = _ws(_C.query("adp_gn_stats_ws_bytes", B, C, L, groups), x)
+    _C.call("adp_gn_stats", ptr(x), B, C, L, groups, eps, ptr(stats), ptr(ws), _C.stream())
+    return stats
+
+
+def gn_silu_bwd(x: Tensor, dact: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor, groups: int,
+                dres: Optional[Tensor] = None, dx: Optional[Tensor] = None, dgamma: Optional[Tensor] = None,
+                dbeta: Optional[Tensor] = None, accumulate: bool = False):
+    """Backward of SiLU(GroupNorm(x)): returns (dx [+ dres], dgamma, dbeta)."""
+    B, C, L = x.shape
+    NS = _C.query("adp_row_nsplit", B * C, L)
+    ab = torch.empty((B, C, NS, 2), dtype=torch.float32, device=x.device)
+    s = _C.stream()
+    _C.call("adp_gn_silu_bwd_reduce", ptr(x), ptr(dact), ptr(stats), ptr(gamma), ptr(beta), B, C, L, groups, NS,
+            ptr(ab), s)
+    if dx is None:
+        dx = torch.empty_like(x)
+    _C.call("adp_gn_silu_bwd_apply", ptr(x), ptr(dact), ptr(stats), ptr(gamma), ptr(beta), ptr(ab), ptr(dres), B, C,
+            L, groups, NS, ptr(dx), s)
+    if dgamma is None:
+        dgamma = torch.empty_like(gamma)
+    if dbeta is None:
+        dbeta = torch.empty_like(beta)
+    _C.call("adp_gn_param_grad", ptr(ab), B, C, NS, ptr(dgamma), ptr(dbeta), int(accumulate), s)
+    return dx, dgamma, dbeta
+
+
+def modulation_fwd(x: Tensor, ss: Tensor, ss_bstride: int, eps: float = LN_EPS, y: Optional[Tensor] = None,
+                   stats: Optional[Tensor] = None):
+    """ss: 1-D view whose element [b*ss_bstride + c] is scale and [b*ss_bstride + C + c] is shift."""
+    B, C, L = x.shape
+    if y is None:
+        y = torch.empty_like(x)
+    if stats is None:
+        stats = torch.empty((B, L, 2), dtype=torch.float32, device=x.device)
+    _C.call("adp_modulation_fwd", ptr(x), ptr(ss), ss_bstride, B, C, L, eps, ptr(y), ptr(stats), _C.stream())
+    return y, stats
+
+
+def modulation_bwd(x: Tensor, dy: Tensor, ss: Tensor, ss_bstride: int, stats: Tensor, dss: Tensor, dss_bstride: int,
+                   dx: Optional[Tensor] = None) -> Tensor:
+    B, C, L = x.shape
+    if dx is None:
+        dx = torch.empty_like(x)
+    ws = _ws(_C.query("adp_chan_ln_bwd_ws_bytes", B, C, L), x)
+    _C.call("adp_modulation_bwd", ptr(x), ptr(dy), ptr(ss), ss_bstride, ptr(stats), B, C, L, ptr(dx), ptr(dss),
+            dss_bstride, ptr(ws), _C.stream())
+    return dx
+
+
+def ln_stats(x: Tensor, eps: float = LN_EPS) -> Tensor:
+    B, C, L = x.shape
+    stats = torch.empty((B, L, 2), dtype=torch.float32, device=x.device)
+    _C.call("adp_ln_stats", ptr(x), B, C, L, eps, ptr(stats), _C.stream())
+    return stats
+
+
+def ln_bwd(x: Tensor, dxn: Tensor, stats: Tensor, gamma: Tensor, dres: Optional[Tensor] = None,
+           dgb: Optional[Tensor] = None, accumulate: bool = False):
+    """Backward of LayerNorm-over-channels with affine: returns (dx [+ dres], [dgamma | dbeta])."""
+    B, C, L = x.shape
+    dx = torch.empty_like(x)
+    if dgb is None:
+        dgb = torch.empty((2 * C,), dtype=torch.float32, device=x.device)
+    ws = _ws(_C.query("adp_chan_ln_bwd_ws_bytes", B, C, L), x)
+    _C.call("adp_ln_bwd", ptr(x), ptr(dxn), ptr(stats), ptr(gamma), ptr(dres), B, C, L, int(accumulate), ptr(dx),
+            ptr(dgb), ptr(ws), _C.stream())
+    return dx, dgb
+
+
+def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], act: int = 0, post: int = 0,
+               y: Optional[Tensor] = None) -> Tensor:
+    B, K = x.shape
+    N = w.shape[0]
+    if y is None:
+        y = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    _C.call("adp_linear_fwd", ptr(x), ptr(w), ptr(bias), B, K, N, act, post, ptr(y), N, _C.stream())
+    return y
+
+
+def linear_bwd_data(dy: Tensor, w: Tensor, dxa: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    B, N = dy.shape
+    K = w.shape[1]
+    if dxa is None:
+        dxa = torch.empty((B, K), dtype=torch.float32, device=dy.device)
+    ws = _ws(_C.query("adp_linear_bwd_data_ws_bytes", B, K, N), dy)
+    _C.call("adp_linear_bwd_data", ptr(dy), N, ptr(w), B, K, N, int(accumulate), ptr(dxa), ptr(ws), _C.stream())
+    return dxa
+
+
+def linear_bwd_weight(dy: Tensor, x: Tensor, act: int = 0, dw: Optional[Tensor] = None,
+                      dbias: Optional[Tensor] = None, want_bias: bool = True, accumulate: bool = False):
+    B, N = dy.shape
+    K = x.shape[1]
+    if dw is None:
+        dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    if dbias is None and want_bias:
+        dbias = torch.empty((N,), dtype=torch.float32, device=dy.device)
+    _C.call("adp_linear_bwd_weight", ptr(dy), N, ptr(x), B, K, N, act, int(accumulate), ptr(dw), ptr(dbias),
+            _C.stream())
+    return dw, dbias
+
+
+def time_fourier_fwd(t: Tensor, w: Tensor) -> Tensor:
+    B, H = t.shape[0], w.shape[0]
+    four = torch.empty((B, 2 * H + 1), dtype=torch.float32, device=t.device)
+    _C.call("adp_time_fourier_fwd", ptr(t), ptr(w), B, H, ptr(four), _C.stream())
+    return four
+
+
+def time_fourier_bwd(t: Tensor, w: Tensor, dfour: Tensor, dw: Optional[Tensor] = None,
+                     accumulate: bool = False) -> Tensor:
+    B, H = t.shape[0], w.shape[0]
+    if dw is None:
+        dw = torch.empty_like(w)
+    _C.call("adp_time_fourier_bwd", ptr(t), ptr(w), ptr(dfour), B, H, int(accumulate), ptr(dw), _C.stream())
+    return dw
+
+
+def act_fwd(x: Tensor, act: int) -> Tensor:
+    y = torch.empty_like(x)
+    _C.call("adp_act_fwd", ptr(x), x.numel(), act, ptr(y), _C.stream())
+    return y
+
+
+def act_bwd(x: Tensor, dy: Tensor, act: int, dx: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    if dx is None:
+        dx = torch.empty_like(x)
+    _C.call("adp_act_bwd", ptr(x), ptr(dy), x.numel(), act, int(accumulate), ptr(dx), _C.stream())
+    return dx
+
+
+def skipmod_bwd(g: Tensor, x: Tensor, scale: Tensor, scale_bstride: int, dscale: Tensor, dscale_bstride: int,
+                dx: Optional[Tensor] = None) -> Tensor:
+    B, C, L = x.shape
+    if dx is None:
+        dx = torch.empty_like(x)
+    ws = _ws(_C.query("adp_skipmod_bwd_ws_bytes", B, C, L), x)
+    _C.call("adp_skipmod_bwd", ptr(g), ptr(x), ptr(scale), scale_bstride, B, C, L, ptr(dx), ptr(dscale),
+            dscale_bstride, ptr(ws), _C.stream())
+    return dx
+
+
+def v_noise(x: Tensor, noise: Tensor, sigma: Tensor):
+    B = x.shape[0]
+    per = x.numel() // B
+    x_noisy, v_target = torch.empty_like(x), torch.empty_like(x)
+    _C.call("adp_v_noise", ptr(x), ptr(noise), ptr(sigma), B, per, ptr(x_noisy), ptr(v_target), _C.stream())
+    return x_noisy, v_target
+
+
+def mse_fwd(v_pred: Tensor, v_target: Tensor) -> Tensor:
+    n = v_pred.numel()
+    loss = torch.empty((), dtype=torch.float32, device=v_pred.device)
+    ws = _ws(_C.query("adp_mse_ws_bytes", n), v_pred)
+    _C.call("adp_mse_fwd", ptr(v_pred), ptr(v_target), n, ptr(loss), ptr(ws), _C.stream())
+    return loss
+
+
+def mse_bwd(v_pred: Tensor, v_target: Tensor, gloss: Optional[Tensor]) -> Tensor:
+    dv = torch.empty_like(v_pred)
+    _C.call("adp_mse_bwd", ptr(v_pred), ptr(v_target), ptr(gloss), v_pred.numel(), ptr(dv), _C.stream())
+    return dv
+
+
+def v_step(x: Tensor, v: Tensor, ab4: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    if out is None:
+        out = torch.empty_like(x)
+    _C.call("adp_v_step", ptr(x), ptr(v), ptr(ab4), x.numel(), ptr(out), _C.stream())
+    return out
+
+
+def add(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    if out is None:
+        out = torch.empty_like(a)
+    _C.call("adp_add", ptr(a), ptr(b), a.numel(), ptr(out), _C.stream())
+    return out

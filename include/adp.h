@@ -1,0 +1,211 @@
+/*
+ * adp.h -- C-ABI of libadp_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * 1-D U-Net denoising hot path of archinetai/audio-diffusion-pytorch.
+ *
+ * The reference has NO native / FFI boundary for this path (it is pure Python):
+ * every entry point below replaces a chain of ATen ops reached through the third-party
+ * `a_unet` blocks that /root/reference/audio_diffusion_pytorch/components.py:79-105 composes,
+ * or the tensor math of /root/reference/audio_diffusion_pytorch/diffusion.py:77-95, :172-190.
+ * The citation on each function names the reference call site it stands in for.
+ *
+ * Conventions (all functions):
+ *   - plain device pointers (fp32 unless noted), int64 sizes, a hipStream_t passed as void*;
+ *   - returns 0 (ADP_OK) or a negative ADP_ERR_* code; never throws, never allocates,
+ *     never synchronises: stream-ordered, re-entrant, hipGraph-capturable;
+ *   - tensors are contiguous, activations laid out [B, C, L] with L fastest.
+ */
+#ifndef ADP_H
+#define ADP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADP_OK 0
+#define ADP_ERR_SHAPE (-1)
+#define ADP_ERR_UNSUPPORTED (-2)
+#define ADP_ERR_ALIGN (-3)
+#define ADP_ERR_LAUNCH (-4)
+#define ADP_ERR_NULL (-5)
+
+int adp_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused implicit-GEMM Conv1d on the f32 matrix cores (v_mfma_f32_32x32x2_f32).
+ *
+ *   out[b, m, n] = e_scale[b,m] * ( bias[m] + sum_{r,t} A(m,r,t) * Xv[b, r, n*stride + t*dil - pad] ) + res[...]
+ *
+ *   Xv = prologue(x) nearest-upsampled by `up` and zero padded (padding applies AFTER the
+ *        prologue, exactly like nn.Conv1d padding after GroupNorm+SiLU).
+ *   A(m,r,t) = w[m][r][t]              (transposed = 0: forward conv, w is [M, R, KT])
+ *            = w[r][m][KT-1-t]         (transposed = 1: data gradient, w is [R, M, KT])
+ *   prologue: 0 none | 1 GroupNorm(groups)+SiLU using pro_stats[b,g,{mean,rstd}], pro_gamma/beta[r]
+ *             | 2 LayerNorm over channels using pro_stats[b,l,{mean,rstd}], pro_gamma/beta[r]
+ *   store:    0 out[b][m][n]
+ *             | 1 pixel-shuffle out[b][m / sp][n*sp + m % sp]   (gradient of a kernel=stride=sp conv)
+ *             | 2 pooled       out[b][m][n / sp] = sum of sp adjacent n (gradient of nearest upsample)
+ *   x2 / R1: optional channel concat -- channels r >= R1 are read from x2[b][r-R1][.] (R1 = R: unused).
+ *
+ * Replaces (reference call sites): ResnetItem ConvBlocks (components.py:89), DownsampleItem /
+ * UpsampleItem (implicit XBlock defaults, components.py:84), the Linear projections of
+ * AttentionItem / CrossAttentionItem (components.py:92-93) run as 1x1 convs, InjectChannelsItem
+ * and AppendChannelsPlugin's torch.cat (components.py:91, :174-176), SkipModulate's merge
+ * (components.py:99), and their autograd data gradients.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct adp_conv_desc {
+  const float* x;          /* [B, R1, Lin] */
+  const float* x2;         /* [B, R-R1, Lin] or NULL */
+  const float* w;          /* see A(m,r,t) */
+  const float* bias;       /* [M] or NULL */
+  const float* pro_stats;  /* prologue statistics or NULL */
+  const float* pro_gamma;  /* [R] or NULL (=1) */
+  const float* pro_beta;   /* [R] or NULL (=0) */
+  const float* e_scale;    /* e_scale[b*e_bstride + m] or NULL (=1) */
+  const float* res;        /* same layout as out, or NULL */
+  float* out;
+  int64_t B, R, R1, Lin, M, N; /* N = output positions per batch element BEFORE the store transform */
+  int64_t KT, stride, dil, pad, up;
+  int64_t transposed, prologue, groups, store, sp;
+  int64_t e_bstride;       /* batch stride of e_scale in floats (0 -> M) */
+} adp_conv_desc;
+
+int adp_conv1d(const adp_conv_desc* d, void* stream);
+
+/* Weight (+bias) gradient of the same convolution, deterministic two-stage reduction:
+ *   dw[m][r][t] = sum_{b,n} dy[b,m,n] * Xv[b, r, n*stride + t*dil - pad]     dbias[m] = sum_{b,n} dy[b,m,n]
+ * `x`/prologue fields describe Xv exactly as in adp_conv1d (the activated conv input is
+ * recomputed on load, never materialised).  ws must hold adp_conv1d_wgrad_ws_bytes().
+ * Replaces autograd's conv weight gradient for every Conv1d above. */
+typedef struct adp_wgrad_desc {
+  const float* x;
+  const float* x2;
+  const float* dy;         /* [B, M, N] */
+  const float* pro_stats;
+  const float* pro_gamma;
+  const float* pro_beta;
+  float* dw;               /* [M, R, KT] (overwritten, or accumulated when accumulate != 0) */
+  float* dbias;            /* [M] or NULL */
+  float* ws;
+  int64_t B, R, R1, Lin, M, N;
+  int64_t KT, stride, dil, pad, up;
+  int64_t prologue, groups, accumulate;
+} adp_wgrad_desc;
+
+int64_t adp_conv1d_wgrad_ws_bytes(const adp_wgrad_desc* d);
+int adp_conv1d_wgrad(const adp_wgrad_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm statistics (nn.GroupNorm inside a_unet ConvBlock; components.py:89, resnet_groups :46)
+ * stats[b, g, 0] = mean, stats[b, g, 1] = rstd = 1/sqrt(var + eps)  (biased variance).
+ * ws: adp_gn_stats_ws_bytes(B, C, L, G) bytes of scratch.
+ * ------------------------------------------------------------------------------------------ */
+int64_t adp_gn_stats_ws_bytes(int64_t B, int64_t C, int64_t L, int64_t G);
+int adp_gn_stats(const float* x, int64_t B, int64_t C, int64_t L, int64_t G, float eps, float* stats, float* ws,
+                 void* stream);
+
+/* Split count used by the row-wise two-stage reductions below (rows = B*C rows of length L). */
+int64_t adp_row_nsplit(int64_t rows, int64_t L);
+
+/* Backward of y = SiLU(GroupNorm(x)) given dact = dL/dy (the conv data gradient), NS = adp_row_nsplit(B*C, L):
+ *   adp_gn_silu_bwd_reduce: ab[b,c,s,0] = sum_l ds*xhat, ab[b,c,s,1] = sum_l ds over slice s of L, ds = dact*silu'(h)
+ *   adp_gn_silu_bwd_apply : dx = rstd*(gamma*ds - m1 - xhat*m2) (+ dres)
+ *   adp_gn_param_grad     : dgamma[c] = sum_{b,s} ab[..0], dbeta[c] = sum_{b,s} ab[..1]
+ * ab holds B*C*NS*2 floats. */
+int adp_gn_silu_bwd_reduce(const float* x, const float* dact, const float* stats, const float* gamma,
+                           const float* beta, int64_t B, int64_t C, int64_t L, int64_t G, int64_t NS, float* ab,
+                           void* stream);
+int adp_gn_silu_bwd_apply(const float* x, const float* dact, const float* stats, const float* gamma,
+                          const float* beta, const float* ab, const float* dres, int64_t B, int64_t C, int64_t L,
+                          int64_t G, int64_t NS, float* dx, void* stream);
+int adp_gn_param_grad(const float* ab, int64_t B, int64_t C, int64_t NS, float* dgamma, float* dbeta,
+                      int64_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Modulation (a_unet ModulationItem, components.py:90): per position LayerNorm over channels
+ * without affine, then * (1 + scale[b,c]) + shift[b,c]; scale = ss[b*ss_bstride + c],
+ * shift = ss[b*ss_bstride + C + c] (a slice of the conditioning bank, see adp_linear_fwd).
+ * stats[b, l, {mean, rstd}] is written for the backward pass.
+ * ------------------------------------------------------------------------------------------ */
+int adp_modulation_fwd(const float* x, const float* ss, int64_t ss_bstride, int64_t B, int64_t C, int64_t L,
+                       float eps, float* y, float* stats, void* stream);
+/* dx, and dss[b*dss_bstride + {c | C + c}] = {sum_l dy*xhat | sum_l dy} (overwritten).
+ * ws: adp_chan_ln_bwd_ws_bytes(B, C, L). */
+int64_t adp_chan_ln_bwd_ws_bytes(int64_t B, int64_t C, int64_t L);
+int adp_modulation_bwd(const float* x, const float* dy, const float* ss, int64_t ss_bstride, const float* stats,
+                       int64_t B, int64_t C, int64_t L, float* dx, float* dss, int64_t dss_bstride, float* ws,
+                       void* stream);
+
+/* LayerNorm-over-channels statistics only (LayerNorm prologue of the attention projections, components.py:92-93) */
+int adp_ln_stats(const float* x, int64_t B, int64_t C, int64_t L, float eps, float* stats, void* stream);
+/* Backward of xn = LayerNorm_C(x) * gamma + beta given dxn: dx = ... (+ dres); dgamma_dbeta = [dgamma | dbeta] (2C).
+ * ws: adp_chan_ln_bwd_ws_bytes(B, C, L). */
+int adp_ln_bwd(const float* x, const float* dxn, const float* stats, const float* gamma, const float* dres,
+               int64_t B, int64_t C, int64_t L, int64_t accumulate, float* dx, float* dgamma_dbeta, float* ws,
+               void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small-batch Linear layers of the conditioning path (TimeConditioningPlugin components.py:74-76,
+ * Modulation / MergeModulate `Linear(SiLU(features))`): y[b*y_bstride + n] = post(bias[n] + sum_k act(x[b,k]) w[n,k])
+ * act: 0 identity | 1 SiLU | 2 GELU(erf).  post: 0 none | 2 GELU(erf).  B <= 16 rows; the weight matrix is
+ * streamed once.  Every Modulation/SkipModulate Linear of a model lives in ONE contiguous weight bank so a
+ * single call serves all of them (y = the conditioning bank ss_all [B, NTOT]).
+ * ------------------------------------------------------------------------------------------ */
+int adp_linear_fwd(const float* x, const float* w, const float* bias, int64_t B, int64_t K, int64_t N, int64_t act,
+                   int64_t post, float* y, int64_t y_bstride, void* stream);
+/* dxa[b,k] (+)= sum_n dy[b*dy_bstride + n] w[n,k]  (gradient w.r.t. act(x)); ws: adp_linear_bwd_data_ws_bytes */
+int64_t adp_linear_bwd_data_ws_bytes(int64_t B, int64_t K, int64_t N);
+int adp_linear_bwd_data(const float* dy, int64_t dy_bstride, const float* w, int64_t B, int64_t K, int64_t N,
+                        int64_t accumulate, float* dxa, float* ws, void* stream);
+/* dw[n,k] (+)= sum_b dy[b,n] act(x[b,k]) ; dbias[n] (+)= sum_b dy[b,n] */
+int adp_linear_bwd_weight(const float* dy, int64_t dy_bstride, const float* x, int64_t B, int64_t K, int64_t N,
+                          int64_t act, int64_t accumulate, float* dw, float* dbias, void* stream);
+
+/* NumberEmbedder of TimeConditioningPlugin: four[b, :] = [t, sin(2 pi t w), cos(2 pi t w)], w in R^H */
+int adp_time_fourier_fwd(const float* t, const float* w, int64_t B, int64_t H, float* four, void* stream);
+int adp_time_fourier_bwd(const float* t, const float* w, const float* dfour, int64_t B, int64_t H, int64_t accumulate,
+                         float* dw, void* stream);
+/* elementwise activation helpers on small [n] vectors: y = act(x); dx (+)= dy * act'(x) */
+int adp_act_fwd(const float* x, int64_t n, int64_t act, float* y, void* stream);
+int adp_act_bwd(const float* x, const float* dy, int64_t n, int64_t act, int64_t accumulate, float* dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SkipModulate backward (components.py:99): out = skip + scale[b,c] * x
+ *   dx = scale * g ; dscale[b*dscale_bstride + c] = sum_l g * x ; ws: adp_skipmod_bwd_ws_bytes
+ * ------------------------------------------------------------------------------------------ */
+int64_t adp_skipmod_bwd_ws_bytes(int64_t B, int64_t C, int64_t L);
+int adp_skipmod_bwd(const float* g, const float* x, const float* scale, int64_t scale_bstride, int64_t B, int64_t C,
+                    int64_t L, float* dx, float* dscale, int64_t dscale_bstride, float* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * v-objective math (diffusion.py:77-95 and :183-187).  sigma -> alpha = cos(sigma*pi/2), beta = sin(.)
+ * ------------------------------------------------------------------------------------------ */
+/* x_noisy = a x + b n ; v_target = a n - b x   (sigma per batch element; per = C*L elements each) */
+int adp_v_noise(const float* x, const float* noise, const float* sigma, int64_t B, int64_t per, float* x_noisy,
+                float* v_target, void* stream);
+/* loss = mean((v_pred - v_target)^2) (deterministic two-stage) and dv = 2 (v_pred - v_target) / n * gscale */
+int64_t adp_mse_ws_bytes(int64_t n);
+int adp_mse_fwd(const float* v_pred, const float* v_target, int64_t n, float* loss, float* ws, void* stream);
+int adp_mse_bwd(const float* v_pred, const float* v_target, const float* gloss, int64_t n, float* dv, void* stream);
+/* one VSampler step: x <- a1*(a0 x - b0 v) + b1*(b0 x + a0 v); ab4 = device [a0, b0, a1, b1] */
+int adp_v_step(const float* x, const float* v, const float* ab4, int64_t n, float* x_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-head attention core (a_unet AttentionBase; components.py:92-93): channel-major operands
+ *   q [B, H*D, n], k,v [B, H*D, m]  ->  o [B, H*D, n] = softmax(q^T k * D^-0.5) v   per head
+ * lse [B, H, n] (log-sum-exp) is written for the backward pass.
+ * ------------------------------------------------------------------------------------------ */
+int adp_attn_fwd(const float* q, const float* k, const float* v, int64_t B, int64_t H, int64_t D, int64_t n,
+                 int64_t m, int64_t q_bstride, int64_t kv_bstride, float* o, float* lse, void* stream);
+int adp_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                 const float* lse, int64_t B, int64_t H, int64_t D, int64_t n, int64_t m, int64_t q_bstride,
+                 int64_t kv_bstride, float* dq, float* dk, float* dv, float* ws, void* stream);
+int64_t adp_attn_bwd_ws_bytes(int64_t B, int64_t H, int64_t D, int64_t n, int64_t m);
+
+/* y = a + b (n elements); used where two gradient streams meet */
+int adp_add(const float* a, const float* b, int64_t n, float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADP_H */

@@ -1,0 +1,288 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into the product library.
+//
+// A tiny host-side SIMT emulator so the *same* kernel sources under
+// audio_diffusion_pytorch_amd/csrc/ can be compiled with g++ (-DADP_EMULATE) and their
+// index / tiling / reduction logic exercised in the GPU-less build container.
+// Every HIP thread of a workgroup is a ucontext fiber; __syncthreads() and the wave64
+// collectives (__shfl*, MFMA) are rendezvous points.  Workgroups run one after another.
+// The MFMA emulation follows the gfx950 fragment layouts documented in
+// /opt/skills/guides/cdna_hip_programming.md section 3 (f32-input 32x32x2 and 16x16x4 forms)
+// and accumulates with a k-ordered fmaf chain, which is what the hardware does.
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct adp_uint3 {
+  unsigned x, y, z;
+};
+struct float4 {
+  float x, y, z, w;
+};
+struct float2 {
+  float x, y;
+};
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+
+typedef void* hipStream_t;
+struct f32x16 {
+  float v[16];
+  float& operator[](int i) { return v[i]; }
+  const float& operator[](int i) const { return v[i]; }
+};
+struct f32x4 {
+  float v[4];
+  float& operator[](int i) { return v[i]; }
+  const float& operator[](int i) const { return v[i]; }
+};
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+
+namespace adp_emul {
+
+enum { READY = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  int state = READY;
+  unsigned coll = 0;  // per-lane count of wave collectives (double-buffer parity)
+};
+
+struct State {
+  adp_uint3 tid{0, 0, 0}, bid{0, 0, 0};
+  dim3 bdim, gdim;
+  int cur = 0;  // linear thread index inside the block
+  ucontext_t sched;
+  std::vector<Fiber> fibers;
+  std::vector<uint32_t> slotA, slotB;  // [wave][2][64]
+  std::function<void()> body;
+  size_t stack_size = 256 * 1024;
+};
+
+inline State& S() {
+  static State s;
+  return s;
+}
+
+inline void trampoline() {
+  State& s = S();
+  s.body();
+  s.fibers[s.cur].state = DONE;
+  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+}
+
+inline void yield_as(int st) {
+  State& s = S();
+  int me = s.cur;
+  s.fibers[me].state = st;
+  swapcontext(&s.fibers[me].ctx, &s.sched);
+}
+
+inline void sync_block() { yield_as(WAIT_BLOCK); }
+inline void sync_wave() { yield_as(WAIT_WAVE); }
+
+inline void set_tid(State& s, int t) {
+  s.cur = t;
+  s.tid.x = t % s.bdim.x;
+  s.tid.y = (t / s.bdim.x) % s.bdim.y;
+  s.tid.z = t / (s.bdim.x * s.bdim.y);
+}
+
+inline void run_block(State& s) {
+  const int n = s.bdim.x * s.bdim.y * s.bdim.z;
+  const int nwaves = (n + 63) / 64;
+  if ((int)s.fibers.size() < n) s.fibers.resize(n);
+  s.slotA.assign((size_t)nwaves * 2 * 64, 0);
+  s.slotB.assign((size_t)nwaves * 2 * 64, 0);
+  for (int t = 0; t < n; ++t) {
+    Fiber& f = s.fibers[t];
+    if (!f.stack) f.stack = (char*)malloc(s.stack_size);
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = s.stack_size;
+    f.ctx.uc_link = nullptr;
+    f.state = READY;
+    f.coll = 0;
+    makecontext(&f.ctx, (void (*)())trampoline, 0);
+  }
+  int ndone = 0;
+  while (ndone < n) {
+    bool progressed = false;
+    for (int t = 0; t < n; ++t) {
+      if (s.fibers[t].state != READY) continue;
+      set_tid(s, t);
+      swapcontext(&s.sched, &s.fibers[t].ctx);
+      progressed = true;
+      if (s.fibers[t].state == DONE) ++ndone;
+    }
+    // release wave rendezvous
+    for (int w = 0; w < nwaves; ++w) {
+      int lo = w * 64, hi = lo + 64 < n ? lo + 64 : n;
+      bool all = true, any = false;
+      for (int t = lo; t < hi; ++t) {
+        int st = s.fibers[t].state;
+        if (st == WAIT_WAVE) any = true;
+        else if (st != DONE) all = false;
+      }
+      if (all && any) {
+        for (int t = lo; t < hi; ++t)
+          if (s.fibers[t].state == WAIT_WAVE) s.fibers[t].state = READY;
+        progressed = true;
+      }
+    }
+    // release block barrier
+    {
+      bool all = true, any = false;
+      for (int t = 0; t < n; ++t) {
+        int st = s.fibers[t].state;
+        if (st == WAIT_BLOCK) any = true;
+        else if (st != DONE) all = false;
+      }
+      if (all && any) {
+        for (int t = 0; t < n; ++t)
+          if (s.fibers[t].state == WAIT_BLOCK) s.fibers[t].state = READY;
+        progressed = true;
+      }
+    }
+    if (!progressed) {
+      fprintf(stderr, "adp_emul: deadlock (divergent barrier / collective) in block (%u,%u,%u)\n", s.bid.x, s.bid.y,
+              s.bid.z);
+      abort();
+    }
+  }
+}
+
+inline void launch(dim3 grid, dim3 block, std::function<void()> body) {
+  State& s = S();
+  s.gdim = grid;
+  s.bdim = block;
+  s.body = std::move(body);
+  for (unsigned z = 0; z < grid.z; ++z)
+    for (unsigned y = 0; y < grid.y; ++y)
+      for (unsigned x = 0; x < grid.x; ++x) {
+        s.bid = adp_uint3{x, y, z};
+        run_block(s);
+      }
+}
+
+inline int lane_id() { return S().cur & 63; }
+inline int wave_id() { return S().cur >> 6; }
+
+template <typename T>
+inline T shfl_idx(T v, int src) {
+  static_assert(sizeof(T) == 4, "4-byte shuffles only");
+  State& s = S();
+  Fiber& f = s.fibers[s.cur];
+  uint32_t* slot = &s.slotA[((size_t)wave_id() * 2 + (f.coll & 1)) * 64];
+  uint32_t bits;
+  memcpy(&bits, &v, 4);
+  slot[lane_id()] = bits;
+  ++f.coll;
+  sync_wave();
+  uint32_t r = slot[src & 63];
+  T out;
+  memcpy(&out, &r, 4);
+  return out;
+}
+
+inline void mfma_exchange(float a, float b, const float*& A, const float*& B) {
+  State& s = S();
+  Fiber& f = s.fibers[s.cur];
+  size_t base = ((size_t)wave_id() * 2 + (f.coll & 1)) * 64;
+  memcpy(&s.slotA[base + lane_id()], &a, 4);
+  memcpy(&s.slotB[base + lane_id()], &b, 4);
+  ++f.coll;
+  sync_wave();
+  A = reinterpret_cast<const float*>(&s.slotA[base]);
+  B = reinterpret_cast<const float*>(&s.slotB[base]);
+}
+
+}  // namespace adp_emul
+
+#define threadIdx (adp_emul::S().tid)
+#define blockIdx (adp_emul::S().bid)
+#define blockDim (adp_emul::S().bdim)
+#define gridDim (adp_emul::S().gdim)
+
+static inline void __syncthreads() { adp_emul::sync_block(); }
+
+template <typename T>
+static inline T __shfl_xor(T v, int mask, int width = 64) {
+  (void)width;
+  return adp_emul::shfl_idx(v, adp_emul::lane_id() ^ mask);
+}
+template <typename T>
+static inline T __shfl_down(T v, unsigned delta, int width = 64) {
+  int l = adp_emul::lane_id();
+  int src = ((l % width) + (int)delta < width) ? l + (int)delta : l;
+  return adp_emul::shfl_idx(v, src);
+}
+template <typename T>
+static inline T __shfl(T v, int src, int width = 64) {
+  int l = adp_emul::lane_id();
+  return adp_emul::shfl_idx(v, (l / width) * width + (src % width));
+}
+
+// v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)
+static inline f32x16 adp_mfma32(float a, float b, f32x16 c) {
+  const float *A, *B;
+  adp_emul::mfma_exchange(a, b, A, B);
+  int l = adp_emul::lane_id();
+  int col = l & 31;
+  f32x16 d = c;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 2; ++k) acc = fmaf(A[row + 32 * k], B[col + 32 * k], acc);
+    d[r] = acc;
+  }
+  return d;
+}
+// v_mfma_f32_16x16x4_f32: A[l&15][k=l>>4], B[k=l>>4][l&15]; D: col=l&15, row=(l>>4)*4+r
+static inline f32x4 adp_mfma16(float a, float b, f32x4 c) {
+  const float *A, *B;
+  adp_emul::mfma_exchange(a, b, A, B);
+  int l = adp_emul::lane_id();
+  int col = l & 15;
+  f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    int row = (l >> 4) * 4 + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) acc = fmaf(A[row + 16 * k], B[col + 16 * k], acc);
+    d[r] = acc;
+  }
+  return d;
+}
+
+static inline float atomicAdd(float* p, float v) {
+  float o = *p;
+  *p = o + v;
+  return o;
+}
+#define __expf(x) expf(x)
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __fdividef(float a, float b) { return a / b; }
+
+#define ADP_LAUNCH(kern, grid, block, stream, ...) \
+  do {                                             \
+    (void)(stream);                                \
+    adp_emul::launch(grid, block, [=]() { kern(__VA_ARGS__); }); \
+  } while (0)
+#define ADP_LAUNCH_OK() 0

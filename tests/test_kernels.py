@@ -1,0 +1,301 @@
+"""Per-kernel parity: every C-ABI entry point against the stock torch.nn.functional CPU op it replaces.
+Each test runs twice (fixture `dev`): on the SIMT-emulated build of the kernel sources (CPU suite) and,
+with -m gpu, on the real gfx950 library.  Tolerance: 1e-3 rel (north_star), fp32; in practice ~1e-6.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from audio_diffusion_pytorch_amd import ops
+from conftest import rel_err
+
+TOL = 1e-4  # tighter than the 1e-3 contract on purpose: these are single ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def ref_gn_silu(x, G, gamma, beta):
+    return F.silu(F.group_norm(x, G, gamma, beta, eps=1e-5))
+
+
+# ------------------------------------------------------------------ conv forward family
+CONV_CASES = [
+    # B, R, M, L, KT, stride, pad, up  -- shapes cover: narrow (M<=32), 64-tile, 128-tile, ragged edges
+    (2, 8, 8, 300, 3, 1, 1, 1),
+    (1, 2, 8, 256, 1, 1, 0, 1),
+    (2, 32, 32, 260, 3, 1, 1, 1),
+    (1, 48, 80, 200, 3, 1, 1, 1),
+    (1, 8, 32, 256, 4, 4, 0, 1),
+    (2, 32, 64, 128, 4, 4, 0, 1),
+    (1, 16, 32, 128, 2, 2, 0, 1),
+    (1, 40, 24, 66, 3, 1, 1, 2),
+    (1, 32, 8, 50, 3, 1, 1, 4),
+    (3, 136, 130, 140, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("B,R,M,L,KT,stride,pad,up", CONV_CASES)
+def test_conv1d_plain(dev, B, R, M, L, KT, stride, pad, up):
+    x, w, b = rnd(B, R, L, seed=1), rnd(M, R, KT, seed=2, scale=0.2), rnd(M, seed=3)
+    xr = F.interpolate(x, scale_factor=up, mode="nearest") if up > 1 else x
+    ref = F.conv1d(xr, w, b, stride=stride, padding=pad)
+    out = ops.conv1d(x.to(dev), w.to(dev), b.to(dev), stride=stride, pad=pad, up=up)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < TOL
+
+
+def test_conv1d_big_tile(dev):
+    # enough workgroups to select the 128x128 tile on the dispatcher
+    B, R, M, L = 6, 32, 128, 1024 if dev.type == "cuda" else 1024
+    x, w, b = rnd(B, R, L, seed=1), rnd(M, R, 3, seed=2, scale=0.2), rnd(M, seed=3)
+    if dev.type != "cuda":
+        B = 6
+    ref = F.conv1d(x, w, b, padding=1)
+    out = ops.conv1d(x.to(dev), w.to(dev), b.to(dev), pad=1)
+    assert rel_err(out, ref) < TOL
+
+
+@pytest.mark.parametrize("C,G,L,dil", [(8, 8, 300, 1), (32, 8, 130, 1), (64, 8, 96, 2)])
+def test_convblock_gn_silu_conv_residual(dev, C, G, L, dil):
+    """ConvBlock: GroupNorm -> SiLU -> Conv1d(k3) with the GN+SiLU applied in the loader, + residual epilogue."""
+    B = 2
+    x, w, b = rnd(B, C, L, seed=1) * 1.7 + 0.3, rnd(C, C, 3, seed=2, scale=0.2), rnd(C, seed=3)
+    gamma, beta, res = rnd(C, seed=4) * 0.5 + 1, rnd(C, seed=5) * 0.1, rnd(B, C, L, seed=6)
+    ref = F.conv1d(ref_gn_silu(x, G, gamma, beta), w, b, padding=dil, dilation=dil) + res
+    xd = x.to(dev)
+    stats = ops.gn_stats(xd, G)
+    sref = torch.stack([x.view(B, G, -1).mean(-1), (x.view(B, G, -1).var(-1, unbiased=False) + 1e-5).rsqrt()], -1)
+    assert rel_err(stats, sref) < 1e-5
+    out = ops.conv1d(xd, w.to(dev), b.to(dev), pad=dil, dil=dil, prologue=1, pro_stats=stats, pro_gamma=gamma.to(dev),
+                     pro_beta=beta.to(dev), groups=G, res=res.to(dev))
+    assert rel_err(out, ref) < TOL
+
+
+def test_gn_stats_large_group(dev):
+    B, C, L, G = 1, 8, 9000, 4
+    x = rnd(B, C, L, seed=7) * 3 + 5
+    stats = ops.gn_stats(x.to(dev), G)
+    xv = x.view(B, G, -1).double()
+    sref = torch.stack([xv.mean(-1), (xv.var(-1, unbiased=False) + 1e-5).rsqrt()], -1).float()
+    assert rel_err(stats, sref) < 1e-5
+
+
+def test_conv1d_ln_prologue(dev):
+    """1x1 projection with the LayerNorm-over-channels prologue (attention to_q / to_kv)."""
+    B, C, L, M = 2, 40, 70, 48
+    x, w = rnd(B, C, L, seed=1) * 2 + 1, rnd(M, C, 1, seed=2, scale=0.2)
+    gamma, beta = rnd(C, seed=3) * 0.3 + 1, rnd(C, seed=4) * 0.1
+    xn = F.layer_norm(x.transpose(1, 2), (C,), gamma, beta, eps=1e-5).transpose(1, 2)
+    ref = F.conv1d(xn, w)
+    xd = x.to(dev)
+    stats = ops.ln_stats(xd)
+    out = ops.conv1d(xd, w.to(dev), None, prologue=2, pro_stats=stats, pro_gamma=gamma.to(dev), pro_beta=beta.to(dev))
+    assert rel_err(out, ref) < TOL
+
+
+def test_conv1d_concat_and_skipmod(dev):
+    """x2 channel concat (AppendChannels / InjectChannels) and the SkipModulate epilogue out = skip + scale*conv."""
+    B, R1, R2, M, L = 2, 5, 3, 6, 90
+    x, x2, w, b = rnd(B, R1, L, seed=1), rnd(B, R2, L, seed=2), rnd(M, R1 + R2, 3, seed=3, scale=0.3), rnd(M, seed=4)
+    skip, bank = rnd(B, M, L, seed=5), rnd(B, 17, seed=6)
+    scale = bank[:, 4:4 + M]
+    ref = skip + scale[:, :, None] * F.conv1d(torch.cat([x, x2], 1), w, b, padding=1)
+    bank_d = bank.to(dev)
+    out = ops.conv1d(x.to(dev), w.to(dev), b.to(dev), pad=1, x2=x2.to(dev), e_scale=bank_d.view(-1)[4:], e_bstride=17,
+                     res=skip.to(dev))
+    assert rel_err(out, ref) < TOL
+
+
+# ------------------------------------------------------------------ conv data gradients
+@pytest.mark.parametrize("B,R,M,L,KT,stride,pad,up", CONV_CASES)
+def test_conv1d_dgrad(dev, B, R, M, L, KT, stride, pad, up):
+    x = rnd(B, R, L, seed=1).requires_grad_()
+    w = rnd(M, R, KT, seed=2, scale=0.2)
+    xr = F.interpolate(x, scale_factor=up, mode="nearest") if up > 1 else x
+    y = F.conv1d(xr, w, None, stride=stride, padding=pad)
+    dy = rnd(*y.shape, seed=9)
+    (dx_ref,) = torch.autograd.grad(y, x, dy)
+    dyd, wd = dy.to(dev), w.to(dev)
+    if stride == 1:
+        # transposed-weight conv over dy; the nearest-upsample gradient is the pooled store
+        dx = ops.conv1d(dyd, wd, None, pad=(KT - 1) - pad, transposed=True, store=2 if up > 1 else 0, sp=up)
+    else:
+        # kernel == stride: a [C_in*f, C_out] GEMM whose rows are scattered back (pixel-shuffle store)
+        assert KT == stride and pad == 0
+        w2 = wd.permute(0, 1, 2).reshape(M, R * KT, 1)  # view [M][R*KT][1] == transposed layout [r=M][m=R*KT][1]
+        dx = ops.conv1d(dyd, w2, None, transposed=True, store=1, sp=stride)
+        if dx.shape[-1] < L:  # input tail not covered by any window
+            dx = F.pad(dx, (0, L - dx.shape[-1]))
+    assert dx.shape == dx_ref.shape
+    assert rel_err(dx, dx_ref) < TOL
+
+
+# ------------------------------------------------------------------ conv weight gradients
+@pytest.mark.parametrize("B,R,M,L,KT,stride,pad,up", CONV_CASES)
+def test_conv1d_wgrad(dev, B, R, M, L, KT, stride, pad, up):
+    x = rnd(B, R, L, seed=1)
+    w = rnd(M, R, KT, seed=2, scale=0.2).requires_grad_()
+    b = rnd(M, seed=3).requires_grad_()
+    xr = F.interpolate(x, scale_factor=up, mode="nearest") if up > 1 else x
+    y = F.conv1d(xr, w, b, stride=stride, padding=pad)
+    dy = rnd(*y.shape, seed=9)
+    dw_ref, db_ref = torch.autograd.grad(y, (w, b), dy)
+    dw, db = ops.conv1d_wgrad(x.to(dev), dy.to(dev), KT, stride=stride, pad=pad, up=up)
+    assert rel_err(dw, dw_ref) < TOL
+    assert rel_err(db, db_ref) < TOL
+
+
+def test_conv1d_wgrad_prologue_accumulate(dev):
+    B, C, L, G = 2, 16, 700, 8
+    x = rnd(B, C, L, seed=1) * 1.3 + 0.2
+    gamma, beta = rnd(C, seed=4) * 0.5 + 1, rnd(C, seed=5) * 0.1
+    w = rnd(C, C, 3, seed=2, scale=0.2).requires_grad_()
+    y = F.conv1d(ref_gn_silu(x, G, gamma, beta), w, None, padding=1)
+    dy = rnd(*y.shape, seed=9)
+    (dw_ref,) = torch.autograd.grad(y, w, dy)
+    xd = x.to(dev)
+    stats = ops.gn_stats(xd, G)
+    dw0 = rnd(C, C, 3, seed=11)
+    dw, _ = ops.conv1d_wgrad(xd, dy.to(dev), 3, pad=1, prologue=1, pro_stats=stats, pro_gamma=gamma.to(dev),
+                             pro_beta=beta.to(dev), groups=G, dw=dw0.clone().to(dev), want_bias=False,
+                             accumulate=True)
+    assert rel_err(dw, dw_ref + dw0) < TOL
+
+
+# ------------------------------------------------------------------ GroupNorm+SiLU backward
+@pytest.mark.parametrize("B,C,L,G", [(2, 8, 3000, 8), (2, 32, 130, 8), (1, 64, 40, 8)])
+def test_gn_silu_bwd(dev, B, C, L, G):
+    x = (rnd(B, C, L, seed=1) * 1.5 + 0.4).requires_grad_()
+    gamma = (rnd(C, seed=2) * 0.5 + 1).requires_grad_()
+    beta = (rnd(C, seed=3) * 0.2).requires_grad_()
+    y = ref_gn_silu(x, G, gamma, beta)
+    dact, dres = rnd(B, C, L, seed=4), rnd(B, C, L, seed=5)
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(y, (x, gamma, beta), dact)
+    xd = x.detach().to(dev)
+    stats = ops.gn_stats(xd, G)
+    dx, dg, db = ops.gn_silu_bwd(xd, dact.to(dev), stats, gamma.detach().to(dev), beta.detach().to(dev), G,
+                                 dres=dres.to(dev))
+    assert rel_err(dx, dx_ref + dres) < TOL
+    assert rel_err(dg, dg_ref) < TOL
+    assert rel_err(db, db_ref) < TOL
+
+
+# ------------------------------------------------------------------ Modulation / LayerNorm over channels
+@pytest.mark.parametrize("B,C,L", [(2, 8, 300), (2, 32, 70), (1, 130, 64)])
+def test_modulation_fwd_bwd(dev, B, C, L):
+    x = (rnd(B, C, L, seed=1) * 1.5 + 0.4).requires_grad_()
+    NT = 2 * C + 7
+    bank = (rnd(B, NT, seed=2) * 0.5).requires_grad_()
+    off = 3
+    scale, shift = bank[:, off:off + C], bank[:, off + C:off + 2 * C]
+    xn = F.layer_norm(x.transpose(1, 2), (C,), eps=1e-5)
+    y = (xn * (1 + scale[:, None, :]) + shift[:, None, :]).transpose(1, 2)
+    dy = rnd(B, C, L, seed=3)
+    dx_ref, dbank_ref = torch.autograd.grad(y, (x, bank), dy)
+    xd, bank_d = x.detach().to(dev), bank.detach().to(dev)
+    yd, stats = ops.modulation_fwd(xd, bank_d.view(-1)[off:], NT)
+    assert rel_err(yd, y) < TOL
+    dbank = torch.zeros(B, NT, device=dev)
+    dx = ops.modulation_bwd(xd, dy.to(dev), bank_d.view(-1)[off:], NT, stats, dbank.view(-1)[off:], NT)
+    assert rel_err(dx, dx_ref) < TOL
+    assert rel_err(dbank, dbank_ref) < TOL
+
+
+def test_ln_bwd(dev):
+    B, C, L = 2, 40, 70
+    x = (rnd(B, C, L, seed=1) * 2 + 1).requires_grad_()
+    gamma = (rnd(C, seed=3) * 0.3 + 1).requires_grad_()
+    beta = (rnd(C, seed=4) * 0.1).requires_grad_()
+    xn = F.layer_norm(x.transpose(1, 2), (C,), gamma, beta, eps=1e-5).transpose(1, 2)
+    dxn, dres = rnd(B, C, L, seed=5), rnd(B, C, L, seed=6)
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(xn, (x, gamma, beta), dxn)
+    xd = x.detach().to(dev)
+    stats = ops.ln_stats(xd)
+    dx, dgb = ops.ln_bwd(xd, dxn.to(dev), stats, gamma.detach().to(dev), dres=dres.to(dev))
+    assert rel_err(dx, dx_ref + dres) < TOL
+    assert rel_err(dgb[:C], dg_ref) < TOL
+    assert rel_err(dgb[C:], db_ref) < TOL
+
+
+def test_skipmod_bwd(dev):
+    B, C, L, NT = 2, 6, 2500, 11
+    g, x, bank = rnd(B, C, L, seed=1), rnd(B, C, L, seed=2), rnd(B, NT, seed=3)
+    scale = bank[:, 2:2 + C]
+    dx_ref = scale[:, :, None] * g
+    ds_ref = (g * x).sum(-1)
+    bank_d = bank.to(dev)
+    dbank = torch.zeros(B, NT, device=dev)
+    dx = ops.skipmod_bwd(g.to(dev), x.to(dev), bank_d.view(-1)[2:], NT, dbank.view(-1)[2:], NT)
+    assert rel_err(dx, dx_ref) < TOL
+    assert rel_err(dbank[:, 2:2 + C], ds_ref) < TOL
+    assert dbank[:, :2].abs().max().item() == 0 and dbank[:, 2 + C:].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------ conditioning path (small-batch Linear)
+@pytest.mark.parametrize("B,K,N,act,post", [(1, 257, 64, 0, 2), (4, 1024, 37, 1, 0), (8, 1500, 20, 2, 0),
+                                            (16, 64, 9, 1, 2)])
+def test_linear_fwd_bwd(dev, B, K, N, act, post):
+    x = rnd(B, K, seed=1).requires_grad_()
+    w = rnd(N, K, seed=2, scale=K ** -0.5).requires_grad_()
+    b = rnd(N, seed=3).requires_grad_()
+    a = {0: lambda t: t, 1: F.silu, 2: F.gelu}[act]
+    xa = a(x)
+    y = F.linear(xa, w, b)
+    yp = F.gelu(y) if post == 2 else y
+    out = ops.linear_fwd(x.detach().to(dev), w.detach().to(dev), b.detach().to(dev), act, post)
+    assert rel_err(out, yp) < TOL
+    dy = rnd(B, N, seed=4)
+    dxa_ref, dw_ref, db_ref = torch.autograd.grad(y, (xa, w, b), dy)
+    dxa = ops.linear_bwd_data(dy.to(dev), w.detach().to(dev))
+    assert rel_err(dxa, dxa_ref) < TOL
+    dw, db = ops.linear_bwd_weight(dy.to(dev), x.detach().to(dev), act)
+    assert rel_err(dw, dw_ref) < TOL
+    assert rel_err(db, db_ref) < TOL
+    # activation backward helper
+    if act:
+        (dx_ref,) = torch.autograd.grad(xa, x, dxa_ref)
+        dx = ops.act_bwd(x.detach().to(dev), dxa, act)
+        assert rel_err(dx, dx_ref) < TOL
+
+
+def test_time_fourier(dev):
+    B, H = 3, 128
+    t = torch.tensor([0.0, 0.31, 1.0])
+    w = rnd(H, seed=1).requires_grad_()
+    f = t[:, None] * w[None, :] * 2 * math.pi
+    four = torch.cat([t[:, None], f.sin(), f.cos()], -1)
+    out = ops.time_fourier_fwd(t.to(dev), w.detach().to(dev))
+    assert rel_err(out, four) < 1e-5
+    dfour = rnd(B, 2 * H + 1, seed=2)
+    (dw_ref,) = torch.autograd.grad(four, w, dfour)
+    dw = ops.time_fourier_bwd(t.to(dev), w.detach().to(dev), dfour.to(dev))
+    assert rel_err(dw, dw_ref) < TOL
+
+
+# ------------------------------------------------------------------ v-objective math
+def test_v_noise_mse_step(dev):
+    B, C, L = 3, 2, 1000
+    x, n = rnd(B, C, L, seed=1), rnd(B, C, L, seed=2)
+    sig = torch.tensor([0.0, 0.37, 1.0])
+    ang = sig.view(-1, 1, 1) * math.pi / 2
+    a, b = torch.cos(ang), torch.sin(ang)
+    xn, vt = ops.v_noise(x.to(dev), n.to(dev), sig.to(dev))
+    assert rel_err(xn, a * x + b * n) < 1e-6
+    assert rel_err(vt, a * n - b * x) < 1e-6
+    vp = rnd(B, C, L, seed=3).requires_grad_()
+    loss_ref = F.mse_loss(vp, vt.cpu())
+    loss = ops.mse_fwd(vp.detach().to(dev), vt)
+    assert abs(loss.item() - loss_ref.item()) < 1e-6 * abs(loss_ref.item())
+    (dv_ref,) = torch.autograd.grad(loss_ref, vp)
+    gl = torch.tensor(0.7)
+    dv = ops.mse_bwd(vp.detach().to(dev), vt, gl.to(dev))
+    assert rel_err(dv, dv_ref * 0.7) < 1e-6
+    ab4 = torch.tensor([0.3, 0.9, 0.5, 0.8])
+    xo = ops.v_step(x.to(dev), n.to(dev), ab4.to(dev))
+    ref = 0.5 * (0.3 * x - 0.9 * n) + 0.8 * (0.9 * x + 0.3 * n)
+    assert rel_err(xo, ref) < 1e-6
