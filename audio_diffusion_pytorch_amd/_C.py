@@ -27,7 +27,7 @@ F = c_float
 
 class ConvDesc(Structure):
     _fields_ = [(n, c_void_p) for n in ("x", "x2", "w", "bias", "pro_stats", "pro_gamma", "pro_beta", "e_scale",
-                                        "res", "out")] + \
+                                        "res", "out", "out_pre")] + \
                [(n, c_int64) for n in ("B", "R", "R1", "Lin", "M", "N", "KT", "stride", "dil", "pad", "up",
                                        "transposed", "prologue", "groups", "store", "sp", "e_bstride")]
 

@@ -162,6 +162,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_kernel(adp_co
         float v = acc[i][j][r];
         if (ok) {
           if (d.bias) v += d.bias[m];
+          if (d.out_pre) d.out_pre[(b * M + m) * N + n] = v;
           if (d.e_scale) v *= d.e_scale[b * ebs + m];
         } else {
           v = 0.0f;
@@ -378,7 +379,7 @@ extern "C" int adp_conv1d(const adp_conv_desc* dp, void* stream) {
   if (!ks_supported(d.KT, d.stride)) return ADP_ERR_UNSUPPORTED;
   if (d.prologue < 0 || d.prologue > 2 || (d.prologue != 0 && !d.pro_stats)) return ADP_ERR_NULL;
   if (d.prologue == 1 && (d.groups < 1 || d.R % d.groups != 0)) return ADP_ERR_SHAPE;
-  if (d.store < 0 || d.store > 2) return ADP_ERR_UNSUPPORTED;
+  if (d.store < 0 || d.store > 2 || (d.out_pre && d.store != 0)) return ADP_ERR_UNSUPPORTED;
   if (d.store == 1 && (d.sp < 1 || d.M % d.sp != 0)) return ADP_ERR_SHAPE;
   if (d.store == 2 && ((d.sp != 2 && d.sp != 4) || d.N % d.sp != 0 || d.bias)) return ADP_ERR_UNSUPPORTED;
   if (d.B > 65535 || adp_cdiv(d.M, 32) > 65535) return ADP_ERR_SHAPE;

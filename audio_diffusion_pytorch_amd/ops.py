@@ -29,7 +29,8 @@ def conv1d(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int =
            up: int = 1, transposed: bool = False, x2: Optional[Tensor] = None, prologue: int = 0,
            pro_stats: Optional[Tensor] = None, pro_gamma: Optional[Tensor] = None, pro_beta: Optional[Tensor] = None,
            groups: int = 1, e_scale: Optional[Tensor] = None, e_bstride: int = 0, res: Optional[Tensor] = None,
-           store: int = 0, sp: int = 1, N: Optional[int] = None, out: Optional[Tensor] = None) -> Tensor:
+           store: int = 0, sp: int = 1, N: Optional[int] = None, out: Optional[Tensor] = None,
+           out_pre: Optional[Tensor] = None) -> Tensor:
     """Fused implicit-GEMM conv (adp_conv1d).  w: [M, R, KT] (or [R, M, KT] when transposed)."""
     B, R1, Lin = x.shape
     R = R1 + (x2.shape[1] if x2 is not None else 0)
@@ -51,7 +52,7 @@ def conv1d(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int =
     else:
         assert tuple(out.shape) == oshape, (out.shape, oshape)
     d = ConvDesc(ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(pro_stats), ptr(pro_gamma), ptr(pro_beta), ptr(e_scale),
-                 ptr(res), ptr(out), B, R, R1, Lin, M, N, KT, stride, dil, pad, up, int(transposed), prologue, groups,
+                 ptr(res), ptr(out), ptr(out_pre), B, R, R1, Lin, M, N, KT, stride, dil, pad, up, int(transposed), prologue, groups,
                  store, sp, e_bstride)
     _C.call("adp_conv1d", byref(d), _C.stream())
     return out

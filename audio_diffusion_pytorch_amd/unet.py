@@ -1,0 +1,457 @@
+"""XUNet + TimeConditioningPlugin on the hand-written gfx950 kernels (host orchestration only).
+
+Replaces the a_unet module tree that /root/reference/audio_diffusion_pytorch/components.py:64-105
+builds (XUNet / Block / ResnetItem / ModulationItem / AttentionItem / CrossAttentionItem /
+InjectChannelsItem / SkipModulate, wrapped by TimeConditioningPlugin at :74-76).  Semantics of
+each block: SURVEY.md section 8a rows a10-a17 and oracle/a_unet_restatement.py.
+
+MI355X-first structure (not a module-per-op translation):
+  * the whole U-Net is ONE autograd node: forward walks the block recursion issuing fused
+    kernels and records a tape; backward replays the tape in reverse with hand-written
+    gradient kernels.  No ATen arithmetic on the path, nothing returns to the host, so a
+    step is capturable in a hipGraph (static shapes).
+  * GroupNorm+SiLU is never materialised: it is applied inside the conv loaders (forward,
+    weight-gradient) from per-(b,group) statistics.
+  * nearest-upsample, channel concat (AppendChannels / InjectChannels), residual adds and the
+    SkipModulate merge are loader / epilogue modes of the same MFMA conv kernel.
+  * every `Linear(SiLU(features))` of the 42+9 Modulation / SkipModulate items lives in one
+    contiguous weight bank: one HBM-bound GEMV-family launch produces all scale/shift vectors,
+    one launch back-propagates them.
+  * parameter gradients are written straight into one flat HBM buffer (contiguous, in
+    parameter order) so data-parallel training all-reduces it in place over RCCL/xGMI.
+"""
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import ops
+
+ITEM_RESNET = "resnet"
+ITEM_MODULATION = "modulation"
+ITEM_INJECT = "inject"
+ITEM_ATTENTION = "attention"
+ITEM_CROSS_ATTENTION = "cross_attention"
+
+TIME_EMBED_DIM = 256
+TIME_NUM_LAYERS = 2
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+
+
+def item_list(items: int, use_modulation: bool, ctx_channels: int, att: int, cross: int) -> List[str]:
+    """Item types of one depth, composed exactly as components.py:88-95 does."""
+    return (
+        [ITEM_RESNET]
+        + [ITEM_MODULATION] * int(use_modulation)
+        + [ITEM_INJECT] * int(ctx_channels > 0)
+        + [ITEM_ATTENTION] * att
+        + [ITEM_CROSS_ATTENTION] * cross
+    ) * items
+
+
+class _P(nn.Module):
+    """Parameter holder (no forward): keeps state_dict names hierarchical."""
+
+
+def _conv_params(cin: int, cout: int, k: int) -> _P:
+    ref = nn.Conv1d(cin, cout, k)  # PyTorch default init == what a_unet's Conv gets
+    p = _P()
+    p.weight = nn.Parameter(ref.weight.detach().clone())
+    p.bias = nn.Parameter(ref.bias.detach().clone())
+    return p
+
+
+def _linear_params(cin: int, cout: int, bias: bool = True) -> _P:
+    ref = nn.Linear(cin, cout, bias=bias)
+    p = _P()
+    p.weight = nn.Parameter(ref.weight.detach().clone())
+    if bias:
+        p.bias = nn.Parameter(ref.bias.detach().clone())
+    return p
+
+
+def _norm_params(c: int) -> _P:
+    p = _P()
+    p.weight = nn.Parameter(torch.ones(c))
+    p.bias = nn.Parameter(torch.zeros(c))
+    return p
+
+
+class UNetV0Net(nn.Module):
+    """`UNetV0(...)` instance: forward(x [B,C,L], time [B], *, features=None, embedding=None, channels=None)."""
+
+    def __init__(self, dim: int, in_channels: int, channels: Sequence[int], factors: Sequence[int],
+                 items: Sequence[int], attentions: Sequence[int], cross_attentions: Sequence[int],
+                 context_channels: Sequence[int], attention_features: Optional[int], attention_heads: Optional[int],
+                 embedding_features: Optional[int], resnet_groups: int, modulation_features: int,
+                 out_channels: Optional[int]):
+        super().__init__()
+        assert dim == 1, "audio U-Net is 1-D"
+        n = len(channels)
+        self.in_channels = in_channels
+        self.out_channels = out_channels if out_channels is not None else in_channels
+        self.channels, self.factors = list(channels), list(factors)
+        self.context_channels = list(context_channels)
+        self.groups = resnet_groups
+        self.mf = modulation_features
+        self.heads, self.head_features = attention_heads, attention_features
+        self.embedding_features = embedding_features
+        for c in channels:
+            assert c % resnet_groups == 0, "channels must be divisible by resnet_groups"
+        for f in factors:
+            assert f in (1, 2, 4), "down/upsample factors 1, 2, 4 are supported by the gfx950 conv kernels"
+
+        # ---- TimeConditioningPlugin: NumberEmbedder(features=MF, dim=256) + 2 x (Linear + GELU)
+        self.time_weights = nn.Parameter(torch.randn(TIME_EMBED_DIM // 2))
+        self.time_linear = _linear_params(TIME_EMBED_DIM + 1, self.mf)
+        self.time_mlp = nn.ModuleList([_linear_params(self.mf, self.mf) for _ in range(TIME_NUM_LAYERS)])
+
+        # ---- blocks; every Modulation / SkipModulate Linear goes into the bank
+        bank_w, bank_b = [], []
+        self.bank_slices: Dict[tuple, tuple] = {}
+        off = 0
+
+        def bank_add(key, nout):
+            nonlocal off
+            ref = nn.Linear(self.mf, nout)
+            bank_w.append(ref.weight.detach())
+            bank_b.append(ref.bias.detach())
+            self.bank_slices[key] = (off, nout)
+            off += nout
+
+        self.item_types: List[List[str]] = []
+        blocks = []
+        for d in range(n):
+            in_ch = in_channels if d == 0 else channels[d - 1]
+            out_ch = self.out_channels if d == 0 else in_ch
+            C, f = channels[d], factors[d]
+            its = item_list(items[d], True, context_channels[d], attentions[d], cross_attentions[d])
+            self.item_types.append(its)
+            blk = _P()
+            blk.down = _conv_params(in_ch, C, f)
+            blk.items_down = nn.ModuleList([self._make_item(t, d, C, ("down", i), bank_add)
+                                            for i, t in enumerate(its)])
+            blk.items_up = nn.ModuleList([self._make_item(t, d, C, ("up", i), bank_add) for i, t in enumerate(its)])
+            blk.up = _conv_params(C, out_ch, 3)
+            if in_ch != out_ch:
+                blk.skip_adapter = _conv_params(in_ch, out_ch, 1)
+            bank_add((d, "skip"), out_ch)
+            blk.in_ch, blk.out_ch = in_ch, out_ch
+            blocks.append(blk)
+        self.blocks = nn.ModuleList(blocks)
+        self.bank_total = off
+        self.bank_weight = nn.Parameter(torch.cat(bank_w, 0).contiguous())
+        self.bank_bias = nn.Parameter(torch.cat(bank_b, 0).contiguous())
+
+    def _make_item(self, t: str, d: int, C: int, key, bank_add) -> nn.Module:
+        p = _P()
+        if t == ITEM_RESNET:
+            p.gn1, p.conv1 = _norm_params(C), _conv_params(C, C, 3)
+            p.gn2, p.conv2 = _norm_params(C), _conv_params(C, C, 3)
+        elif t == ITEM_MODULATION:
+            bank_add((d,) + key, 2 * C)
+        elif t == ITEM_INJECT:
+            p.conv = _conv_params(C + self.context_channels[d], C, 1)
+        elif t in (ITEM_ATTENTION, ITEM_CROSS_ATTENTION):
+            assert self.heads and self.head_features, "attention_heads and attention_features are required"
+            cf = C
+            if t == ITEM_CROSS_ATTENTION:
+                assert self.embedding_features, "embedding_features is required for cross attention"
+                cf = self.embedding_features
+            mid = self.heads * self.head_features
+            p.norm, p.norm_context = _norm_params(C), _norm_params(cf)
+            p.to_q = _linear_params(C, mid, bias=False)
+            p.to_kv = _linear_params(cf, 2 * mid, bias=False)
+            p.to_out = _linear_params(mid, C, bias=False)
+        else:
+            raise ValueError(t)
+        return p
+
+    # ------------------------------------------------------------------ state-dict interchange with the oracle
+    def load_oracle_state_dict(self, sd: Dict[str, Tensor]) -> None:
+        """Loads a state dict in oracle/a_unet_restatement.py naming (per-module Modulation / skip Linears)."""
+        own = dict(self.named_parameters())
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k == "time_weights" or k.startswith("time_"):
+                    own[k].copy_(v)
+                    continue
+                parts = k.split(".")
+                d = int(parts[1])
+                if parts[2] in ("items_down", "items_up") and parts[4] == "to_scale_shift":
+                    off, nout = self.bank_slices[(d, parts[2][6:], int(parts[3]))]
+                    (self.bank_weight if parts[5] == "weight" else self.bank_bias)[off:off + nout].copy_(v)
+                elif parts[2] == "skip":
+                    off, nout = self.bank_slices[(d, "skip")]
+                    (self.bank_weight if parts[4] == "weight" else self.bank_bias)[off:off + nout].copy_(v)
+                else:
+                    own[k].copy_(v)
+
+    def oracle_named_grads(self, grads: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        """Maps {own parameter name: tensor} to oracle naming (splitting the bank)."""
+        out = {}
+        for k, v in grads.items():
+            if k in ("bank_weight", "bank_bias"):
+                continue
+            out[k] = v
+        for key, (off, nout) in self.bank_slices.items():
+            if key[1] == "skip":
+                base = f"blocks.{key[0]}.skip.to_scale"
+            else:
+                base = f"blocks.{key[0]}.items_{key[1]}.{key[2]}.to_scale_shift"
+            out[base + ".weight"] = grads["bank_weight"][off:off + nout]
+            out[base + ".bias"] = grads["bank_bias"][off:off + nout]
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: Tensor, time: Optional[Tensor] = None, *, features: Optional[Tensor] = None,
+                embedding: Optional[Tensor] = None, channels: Optional[Sequence[Optional[Tensor]]] = None,
+                x_append: Optional[Tensor] = None) -> Tensor:
+        assert time is not None, "TimeConditioningPlugin requires time in forward"
+        params = list(self.parameters())
+        ctx_list = [c for c in (channels or []) if c is not None]
+        return _UNetFn.apply(self, x, time, features, embedding, x_append, channels, len(ctx_list), *ctx_list,
+                             *params)
+
+
+class _Run:
+    """One forward execution: issues kernels, and (when grad is needed) records the tape."""
+
+    def __init__(self, net: UNetV0Net, need_grad: bool):
+        self.net = net
+        self.need_grad = need_grad
+        self.tape: List = []           # list of callables g -> g_prev
+        self.grads: Dict[str, Tensor] = {}
+        self.pnames = {id(p): n for n, p in net.named_parameters()}
+
+    # -- gradient destination views -------------------------------------------------------
+    def g(self, p: nn.Parameter) -> Tensor:
+        return self.grads[self.pnames[id(p)]]
+
+    # -- conditioning ---------------------------------------------------------------------
+    def conditioning(self, time: Tensor, features: Optional[Tensor]):
+        n = self.net
+        t = time.reshape(-1).to(torch.float32).contiguous()
+        four = ops.time_fourier_fwd(t, n.time_weights)
+        pre = [ops.linear_fwd(four, n.time_linear.weight, n.time_linear.bias)]
+        acts = [ops.act_fwd(pre[0], ACT_GELU)]
+        for lin in n.time_mlp:
+            pre.append(ops.linear_fwd(acts[-1], lin.weight, lin.bias))
+            acts.append(ops.act_fwd(pre[-1], ACT_GELU))
+        feats = acts[-1] if features is None else ops.add(features.contiguous(), acts[-1])
+        ss_all = ops.linear_fwd(feats, n.bank_weight, n.bank_bias, act=ACT_SILU)
+        self.t, self.four, self.pre, self.acts, self.feats, self.ss_all = t, four, pre, acts, feats, ss_all
+        if self.need_grad:
+            self.dss_all = torch.zeros_like(ss_all)
+        return ss_all
+
+    def conditioning_backward(self) -> Tensor:
+        """Back-propagates dss_all through the bank and the time MLP; returns d(features)."""
+        n = self.net
+        dfa = ops.linear_bwd_data(self.dss_all, n.bank_weight)
+        ops.linear_bwd_weight(self.dss_all, self.feats, act=ACT_SILU, dw=self.g(n.bank_weight),
+                              dbias=self.g(n.bank_bias))
+        dfeat = ops.act_bwd(self.feats, dfa, ACT_SILU)
+        dcur = dfeat
+        lins = [n.time_linear] + list(n.time_mlp)
+        for i in range(len(lins) - 1, -1, -1):
+            dp = ops.act_bwd(self.pre[i], dcur, ACT_GELU)
+            xin = self.four if i == 0 else self.acts[i - 1]
+            ops.linear_bwd_weight(dp, xin, act=ACT_NONE, dw=self.g(lins[i].weight), dbias=self.g(lins[i].bias))
+            dcur = ops.linear_bwd_data(dp, lins[i].weight)
+        ops.time_fourier_bwd(self.t, n.time_weights, dcur, dw=self.g(n.time_weights))
+        return dfeat
+
+    def ss(self, key):
+        off, nout = self.net.bank_slices[key]
+        return self.ss_all.view(-1)[off:], (self.dss_all.view(-1)[off:] if self.need_grad else None)
+
+    # -- items ----------------------------------------------------------------------------
+    def resnet(self, p, x: Tensor) -> Tensor:
+        G = self.net.groups
+        st1 = ops.gn_stats(x, G)
+        h1 = ops.conv1d(x, p.conv1.weight, p.conv1.bias, pad=1, prologue=1, pro_stats=st1, pro_gamma=p.gn1.weight,
+                        pro_beta=p.gn1.bias, groups=G)
+        st2 = ops.gn_stats(h1, G)
+        y = ops.conv1d(h1, p.conv2.weight, p.conv2.bias, pad=1, prologue=1, pro_stats=st2, pro_gamma=p.gn2.weight,
+                       pro_beta=p.gn2.bias, groups=G, res=x)
+        if self.need_grad:
+            def bwd(gy):
+                ops.conv1d_wgrad(h1, gy, 3, pad=1, prologue=1, pro_stats=st2, pro_gamma=p.gn2.weight,
+                                 pro_beta=p.gn2.bias, groups=G, dw=self.g(p.conv2.weight), dbias=self.g(p.conv2.bias))
+                dact2 = ops.conv1d(gy, p.conv2.weight, None, pad=1, transposed=True)
+                dh1, _, _ = ops.gn_silu_bwd(h1, dact2, st2, p.gn2.weight, p.gn2.bias, G, dgamma=self.g(p.gn2.weight),
+                                            dbeta=self.g(p.gn2.bias))
+                ops.conv1d_wgrad(x, dh1, 3, pad=1, prologue=1, pro_stats=st1, pro_gamma=p.gn1.weight,
+                                 pro_beta=p.gn1.bias, groups=G, dw=self.g(p.conv1.weight), dbias=self.g(p.conv1.bias))
+                dact1 = ops.conv1d(dh1, p.conv1.weight, None, pad=1, transposed=True)
+                dx, _, _ = ops.gn_silu_bwd(x, dact1, st1, p.gn1.weight, p.gn1.bias, G, dres=gy,
+                                           dgamma=self.g(p.gn1.weight), dbeta=self.g(p.gn1.bias))
+                return dx
+            self.tape.append(bwd)
+        return y
+
+    def modulation(self, key, x: Tensor) -> Tensor:
+        ss, dss = self.ss(key)
+        NT = self.net.bank_total
+        y, stats = ops.modulation_fwd(x, ss, NT)
+        if self.need_grad:
+            self.tape.append(lambda gy: ops.modulation_bwd(x, gy, ss, NT, stats, dss, NT))
+        return y
+
+    def inject(self, p, x: Tensor, ctx: Tensor, ctx_index: int) -> Tensor:
+        assert ctx.shape[0] == x.shape[0] and ctx.shape[2] == x.shape[2], "context `channels` shape mismatch"
+        ctx = ctx.contiguous()
+        y = ops.conv1d(x, p.conv.weight, p.conv.bias, x2=ctx, res=x)
+        if self.need_grad:
+            def bwd(gy):
+                ops.conv1d_wgrad(x, gy, 1, x2=ctx, dw=self.g(p.conv.weight), dbias=self.g(p.conv.bias))
+                C = x.shape[1]
+                w = p.conv.weight
+                # data gradient w.r.t. x only uses the first C input channels of the 1x1 weight
+                dx = ops.conv1d(gy, w[:, :C, :].contiguous(), None, transposed=True, res=gy)
+                if self.ctx_grads is not None and self.ctx_needs[ctx_index]:
+                    dctx = ops.conv1d(gy, w[:, C:, :].contiguous(), None, transposed=True)
+                    self.ctx_grads[ctx_index] = dctx
+                return dx
+            self.tape.append(bwd)
+        return y
+
+    def attention(self, p, x: Tensor, context: Optional[Tensor]) -> Tensor:
+        from . import attention as attn_host
+        return attn_host.attention_item(self, p, x, context)
+
+    def run_items(self, d: int, which: str, mods, x: Tensor, embedding, channels) -> Tensor:
+        for i, (t, p) in enumerate(zip(self.net.item_types[d], mods)):
+            if t == ITEM_RESNET:
+                x = self.resnet(p, x)
+            elif t == ITEM_MODULATION:
+                x = self.modulation((d, which, i), x)
+            elif t == ITEM_INJECT:
+                assert channels is not None and channels[d] is not None, f"Missing context `channels` at depth {d}"
+                x = self.inject(p, x, channels[d], self.ctx_index[d])
+            elif t == ITEM_ATTENTION:
+                x = self.attention(p, x, None)
+            elif t == ITEM_CROSS_ATTENTION:
+                assert embedding is not None, "You must provide a context when using context_features"
+                x = self.attention(p, x, embedding)
+        return x
+
+    # -- block recursion ------------------------------------------------------------------
+    def block(self, d: int, x: Tensor, x2: Optional[Tensor], embedding, channels, need_dx: bool) -> Tensor:
+        n = self.net
+        if d == len(n.blocks):
+            return x
+        blk = n.blocks[d]
+        f, NT = n.factors[d], n.bank_total
+        has_adapter = hasattr(blk, "skip_adapter")
+        if has_adapter:
+            skip = ops.conv1d(x, blk.skip_adapter.weight, blk.skip_adapter.bias, x2=x2)
+        else:
+            assert x2 is None
+            skip = x
+        h0 = ops.conv1d(x, blk.down.weight, blk.down.bias, stride=f, x2=x2)
+        tape_mark_down = len(self.tape)
+        h = self.run_items(d, "down", blk.items_down, h0, embedding, channels)
+        h = self.block(d + 1, h, None, embedding, channels, True)
+        h = self.run_items(d, "up", blk.items_up, h, embedding, channels)
+        sc, dsc = self.ss((d, "skip"))
+        u = torch.empty((x.shape[0], blk.out_ch, h.shape[2] * f), dtype=torch.float32, device=x.device) \
+            if self.need_grad else None
+        y = self._up_conv(blk, h, f, sc, NT, skip, u)
+        if self.need_grad:
+            h_up = h
+
+            def bwd_up(gy):
+                du = ops.skipmod_bwd(gy, u, sc, NT, dsc, NT)
+                ops.conv1d_wgrad(h_up, du, 3, pad=1, up=f, dw=self.g(blk.up.weight), dbias=self.g(blk.up.bias))
+                gh = ops.conv1d(du, blk.up.weight, None, pad=1, transposed=True, store=2 if f > 1 else 0, sp=f)
+                self.skip_grads.append(gy)
+                return gh
+
+            def bwd_down(gh):
+                gskip = self.skip_grads.pop()
+                ops.conv1d_wgrad(x, gh, f, stride=f, x2=x2, dw=self.g(blk.down.weight), dbias=self.g(blk.down.bias))
+                if has_adapter:
+                    ops.conv1d_wgrad(x, gskip, 1, x2=x2, dw=self.g(blk.skip_adapter.weight),
+                                     dbias=self.g(blk.skip_adapter.bias))
+                if not need_dx:
+                    return None
+                assert x2 is None, "input gradient through an appended-channel input is not needed on the hot path"
+                w = blk.down.weight
+                if has_adapter:
+                    gx = ops.conv1d(gskip, blk.skip_adapter.weight, None, transposed=True)
+                else:
+                    gx = gskip
+                if f == 1:
+                    return ops.conv1d(gh, w, None, transposed=True, res=gx)
+                M, R, KT = w.shape
+                return ops.conv1d(gh, w.view(M, R * KT, 1), None, transposed=True, store=1, sp=f, res=gx)
+
+            # tape order: [..., bwd_down, items_down..., inner..., items_up..., bwd_up]
+            self.tape.insert(tape_mark_down, bwd_down)
+            self.tape.append(bwd_up)
+        return y
+
+    def _up_conv(self, blk, h, f, sc, NT, skip, u):
+        # y = skip + scale[b,c] * (conv_k3(nearest_up_f(h)) + bias); u (optional) keeps the pre-merge value
+        return ops.conv1d(h, blk.up.weight, blk.up.bias, pad=1, up=f, e_scale=sc, e_bstride=NT, res=skip, out_pre=u)
+
+
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net: UNetV0Net, x, time, features, embedding, x_append, channels, n_ctx, *rest):
+        ctx_list, params = rest[:n_ctx], rest[n_ctx:]
+        need_grad = any(ctx.needs_input_grad)
+        run = _Run(net, need_grad)
+        run.skip_grads = []
+        run.ctx_index = {}
+        j = 0
+        for d, c in enumerate(channels or []):
+            if c is not None:
+                run.ctx_index[d] = j
+                j += 1
+        run.ctx_grads = [None] * n_ctx if need_grad else None
+        run.ctx_needs = [bool(c.requires_grad) for c in ctx_list]
+        x = x.contiguous()
+        x2 = x_append.contiguous() if x_append is not None else None
+        run.conditioning(time, features)
+        run.emb_grad = None
+        y = run.block(0, x, x2, embedding.contiguous() if embedding is not None else None, channels,
+                      need_dx=bool(ctx.needs_input_grad[1]))
+        ctx.run = run
+        ctx.params = params
+        ctx.n_ctx = n_ctx
+        ctx.has_features = features is not None
+        ctx.has_embedding = embedding is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        run: _Run = ctx.run
+        net = run.net
+        params = list(net.parameters())
+        total = sum(p.numel() for p in params)
+        flat = torch.zeros(total, dtype=torch.float32, device=gy.device)
+        off = 0
+        views = []
+        for name, p in net.named_parameters():
+            v = flat[off:off + p.numel()].view(p.shape)
+            run.grads[name] = v
+            views.append(v)
+            off += p.numel()
+        g = gy.contiguous()
+        for fn in reversed(run.tape):
+            g = fn(g)
+        dfeat = run.conditioning_backward()
+        run.flat_grad = flat
+        hook = getattr(net, "_grad_ready_hook", None)
+        if hook is not None:
+            hook(flat)
+        gx = g if ctx.needs_input_grad[1] else None
+        gfeat = dfeat if (ctx.has_features and ctx.needs_input_grad[3]) else None
+        gemb = run.emb_grad if (ctx.has_embedding and ctx.needs_input_grad[4]) else None
+        gctx = tuple(run.ctx_grads) if run.ctx_grads is not None else (None,) * ctx.n_ctx
+        ctx.run = None
+        return (None, gx, None, gfeat, gemb, None, None, None) + gctx + tuple(views)

@@ -64,6 +64,7 @@ typedef struct adp_conv_desc {
   const float* e_scale;    /* e_scale[b*e_bstride + m] or NULL (=1) */
   const float* res;        /* same layout as out, or NULL */
   float* out;
+  float* out_pre;          /* optional (store 0 only): bias + conv BEFORE e_scale / res, kept for the backward pass */
   int64_t B, R, R1, Lin, M, N; /* N = output positions per batch element BEFORE the store transform */
   int64_t KT, stride, dil, pad, up;
   int64_t transposed, prologue, groups, store, sp;

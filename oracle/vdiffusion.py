@@ -69,7 +69,8 @@ def resample(waveforms: Tensor, factor_in: int, factor_out: int, rolloff: float 
     t = torch.arange(0, -factor_out, step=-1, **kw)[:, None, None] / factor_out + idx
     t = (t * base).clamp(-lowpass_filter_width, lowpass_filter_width) * pi
     window = torch.cos(t / lowpass_filter_width / 2) ** 2
-    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / factor_in)
+    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t)
+    kernels = kernels * (window * (base / factor_in))
     w = F.pad(waveforms.reshape(b * c, length), (width, width + factor_in))
     out = F.conv1d(w[:, None], kernels, stride=factor_in)  # [(b c), k, l]
     out = out.reshape(b, c, factor_out, -1).permute(0, 1, 3, 2).reshape(b, c, -1)
