@@ -42,6 +42,7 @@ class WgradDesc(Structure):
 SIGNATURES = {
     "adp_version": (c_int, []),
     "adp_conv1d": (c_int, [POINTER(ConvDesc), P]),
+    "adp_conv1d_tile": (I, [POINTER(ConvDesc)]),
     "adp_conv1d_wgrad_ws_bytes": (I, [POINTER(WgradDesc)]),
     "adp_conv1d_wgrad": (c_int, [POINTER(WgradDesc), P]),
     "adp_gn_stats_ws_bytes": (I, [I, I, I, I]),

@@ -389,6 +389,18 @@ extern "C" int adp_conv1d(const adp_conv_desc* dp, void* stream) {
   return dispatch_conv<4, 4>(d, stream);
 }
 
+// which tile the dispatcher picks for this problem: BM * 1000 + BN (introspection for profiling / roofline reports)
+extern "C" int64_t adp_conv1d_tile(const adp_conv_desc* dp) {
+  if (!dp) return ADP_ERR_NULL;
+  const adp_conv_desc& d = *dp;
+  if (d.M <= 32) return 32 * 1000 + 128;
+  if (d.stride != 4) {
+    const int64_t big = adp_cdiv(d.M, 128) * adp_cdiv(d.N, 128) * d.B;
+    if (d.M >= 128 && big >= 384) return 128 * 1000 + 128;
+  }
+  return 64 * 1000 + 64;
+}
+
 extern "C" int64_t adp_conv1d_wgrad_ws_bytes(const adp_wgrad_desc* dp) {
   if (!dp || !ks_supported(dp->KT, dp->stride) || dp->B <= 0 || dp->N <= 0) return ADP_ERR_UNSUPPORTED;
   int64_t PS, SPB;

@@ -15,6 +15,7 @@ from ._C import ConvDesc, WgradDesc, ptr
 
 GN_EPS = 1e-5
 LN_EPS = 1e-5
+PROFILE = None  # bench.py sets this to a list to time every conv launch with HIP events
 
 
 def _ws(nbytes: int, like: Tensor) -> Tensor:
@@ -54,7 +55,18 @@ def conv1d(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int =
     d = ConvDesc(ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(pro_stats), ptr(pro_gamma), ptr(pro_beta), ptr(e_scale),
                  ptr(res), ptr(out), ptr(out_pre), B, R, R1, Lin, M, N, KT, stride, dil, pad, up, int(transposed), prologue, groups,
                  store, sp, e_bstride)
+    if PROFILE is None:
+        _C.call("adp_conv1d", byref(d), _C.stream())
+        return out
+    # instrumented launch (bench.py roofline leg): HIP events on the stream the kernel is launched on
+    tile = _C.query("adp_conv1d_tile", byref(d))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     _C.call("adp_conv1d", byref(d), _C.stream())
+    e1.record()
+    flops = 2 * B * M * N * R * KT
+    nbytes = 4 * (B * R * Lin + out.numel() + w.numel() + (res.numel() if res is not None else 0))
+    PROFILE.append((f"conv_kernel<{tile // 1000},{tile % 1000},KT={KT}>", flops, nbytes, e0, e1))
     return out
 
 

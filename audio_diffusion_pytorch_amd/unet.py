@@ -204,6 +204,34 @@ class UNetV0Net(nn.Module):
             out[base + ".bias"] = grads["bank_bias"][off:off + nout]
         return out
 
+    # ------------------------------------------------------------------ flat gradient layout (parameter order)
+    def _param_offsets(self):
+        if getattr(self, "_offsets", None) is None:
+            off, table = 0, {}
+            for name, p in self.named_parameters():
+                table[name] = (off, off + p.numel())
+                off += p.numel()
+            self._offsets = table
+        return self._offsets
+
+    def block_param_range(self, d: int):
+        t = self._param_offsets()
+        spans = [v for k, v in t.items() if k.startswith(f"blocks.{d}.")]
+        return min(a for a, _ in spans), max(b for _, b in spans)
+
+    def nonblock_param_ranges(self):
+        """Maximal contiguous ranges of the parameters outside the blocks (time MLP + conditioning bank); their
+        gradients are final only after conditioning_backward."""
+        t = self._param_offsets()
+        spans = sorted(v for k, v in t.items() if not k.startswith("blocks."))
+        out = []
+        for a, b in spans:
+            if out and out[-1][1] == a:
+                out[-1] = (out[-1][0], b)
+            else:
+                out.append((a, b))
+        return out
+
     # ------------------------------------------------------------------ forward
     def forward(self, x: Tensor, time: Optional[Tensor] = None, *, features: Optional[Tensor] = None,
                 embedding: Optional[Tensor] = None, channels: Optional[Sequence[Optional[Tensor]]] = None,
@@ -289,7 +317,7 @@ class _Run:
                 dx, _, _ = ops.gn_silu_bwd(x, dact1, st1, p.gn1.weight, p.gn1.bias, G, dres=gy,
                                            dgamma=self.g(p.gn1.weight), dbeta=self.g(p.gn1.bias))
                 return dx
-            self.tape.append(bwd)
+            self.tape.append((bwd, None))
         return y
 
     def modulation(self, key, x: Tensor) -> Tensor:
@@ -297,7 +325,7 @@ class _Run:
         NT = self.net.bank_total
         y, stats = ops.modulation_fwd(x, ss, NT)
         if self.need_grad:
-            self.tape.append(lambda gy: ops.modulation_bwd(x, gy, ss, NT, stats, dss, NT))
+            self.tape.append((lambda gy: ops.modulation_bwd(x, gy, ss, NT, stats, dss, NT), None))
         return y
 
     def inject(self, p, x: Tensor, ctx: Tensor, ctx_index: int) -> Tensor:
@@ -315,7 +343,7 @@ class _Run:
                     dctx = ops.conv1d(gy, w[:, C:, :].contiguous(), None, transposed=True)
                     self.ctx_grads[ctx_index] = dctx
                 return dx
-            self.tape.append(bwd)
+            self.tape.append((bwd, None))
         return y
 
     def attention(self, p, x: Tensor, context: Optional[Tensor]) -> Tensor:
@@ -390,8 +418,8 @@ class _Run:
                 return ops.conv1d(gh, w.view(M, R * KT, 1), None, transposed=True, store=1, sp=f, res=gx)
 
             # tape order: [..., bwd_down, items_down..., inner..., items_up..., bwd_up]
-            self.tape.insert(tape_mark_down, bwd_down)
-            self.tape.append(bwd_up)
+            self.tape.insert(tape_mark_down, (bwd_down, d))   # tag d: block d's parameter gradients are complete
+            self.tape.append((bwd_up, None))
         return y
 
     def _up_conv(self, blk, h, f, sc, NT, skip, u):
@@ -441,14 +469,19 @@ class _UNetFn(torch.autograd.Function):
             run.grads[name] = v
             views.append(v)
             off += p.numel()
-        g = gy.contiguous()
-        for fn in reversed(run.tape):
-            g = fn(g)
-        dfeat = run.conditioning_backward()
-        run.flat_grad = flat
+        # data-parallel hook: called with (flat, start, end) as soon as a contiguous region of the flat
+        # gradient buffer is final (deepest blocks first), and with (flat, None, None) at the very end
         hook = getattr(net, "_grad_ready_hook", None)
+        g = gy.contiguous()
+        for fn, tag in reversed(run.tape):
+            g = fn(g)
+            if tag is not None and hook is not None:
+                hook(flat, *net.block_param_range(tag))
+        dfeat = run.conditioning_backward()
         if hook is not None:
-            hook(flat)
+            for a, b in net.nonblock_param_ranges():
+                hook(flat, a, b)
+            hook(flat, None, None)
         gx = g if ctx.needs_input_grad[1] else None
         gfeat = dfeat if (ctx.has_features and ctx.needs_input_grad[3]) else None
         gemb = run.emb_grad if (ctx.has_embedding and ctx.needs_input_grad[4]) else None

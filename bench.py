@@ -1,0 +1,217 @@
+"""Headline benchmark: denoising steps/s (UNetV0 fwd+bwd) at [B,2,2**18] on N MI355X (BASELINE.json `metric`).
+
+A "step" = one `loss = model(audio); loss.backward()` of DiffusionModel(UNetV0 README config) on one batch of
+synthetic randn waveforms already resident in HBM (VDiffusion noising + U-Net forward + MSE + full backward
+incl. every weight gradient; with N > 1 also the RCCL gradient all-reduce).  Workload at N=1 = BASELINE.json
+configs[1]: unconditional UNetV0 channels=[8,32,64,128,256,512,512,1024,1024], batch 4, fp32.  Weak scaling:
+every rank runs batch 4.  Prints ONE JSON line on rank 0.
+
+  python bench.py                                   # 1 GPU, defaults
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CHANNELS = [8, 32, 64, 128, 256, 512, 512, 1024, 1024]
+FACTORS = [1, 4, 4, 4, 2, 2, 2, 2, 2]
+ITEMS = [1, 2, 2, 2, 2, 2, 2, 4, 4]
+LENGTH = 2 ** 18
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_HBM_GBPS = 8000.0         # HBM3E spec; 6290 GB/s measured copy ceiling
+
+
+def build_model(dev):
+    import audio_diffusion_pytorch_amd as adp
+    torch.manual_seed(0)
+    model = adp.DiffusionModel(net_t=adp.UNetV0, in_channels=2, channels=CHANNELS, factors=FACTORS, items=ITEMS)
+    return model.to(dev)
+
+
+def cpu_baseline(batch: int, steps: int = 2):
+    """The reference CPU path (oracle restatement of the reference's a_unet composition + live v-diffusion math),
+    timed on this host's cores on a bounded sample: `steps` full fwd+bwd steps at the bench batch."""
+    from oracle import vdiffusion as ovd
+    from oracle.a_unet_restatement import UNetV0Oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    net = UNetV0Oracle(in_channels=2, channels=CHANNELS, factors=FACTORS, items=ITEMS)
+    x = torch.randn(batch, 2, LENGTH)
+
+    def step():
+        for p in net.parameters():
+            p.grad = None
+        loss = ovd.v_loss(net, x, torch.randn_like(x), torch.rand(batch))
+        loss.backward()
+
+    step()  # warm-up (oneDNN primitive creation)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(1.0 / dt, 4), "unit": "denoising steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} fwd+bwd steps of the same UNetV0 at batch {batch}, fp32, torch CPU ({cores} threads), "
+                      "after 1 warm-up step"}
+
+
+def roofline_leg(model, x):
+    """Times every conv launch of one eager step with HIP events on the launch stream and reports the kernel with
+    the largest total time (the dominant kernel) against the fp32 MFMA peak, plus the HBM-bound depth-0/1 ConvBlock
+    instantiation against the HBM peak."""
+    from audio_diffusion_pytorch_amd import ops
+    for p in model.parameters():
+        p.grad = None
+    ops.PROFILE = []
+    loss = model(x)
+    loss.backward()
+    torch.cuda.synchronize()
+    recs, ops.PROFILE = ops.PROFILE, None
+    agg = {}
+    for name, flops, nbytes, e0, e1 in recs:
+        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1)
+        a[2] += flops
+        a[3] += nbytes
+    dom = max(agg.items(), key=lambda kv: kv[1][1])
+    n, ms, fl, by = dom[1]
+    tf = fl / (ms * 1e-3) / 1e12
+    out = {"bound": "mfma", "kernel": dom[0], "launches": n, "avg_ms": round(ms / n, 4),
+           "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None}
+    extra = {}
+    for k, (cn, cms, cfl, cby) in agg.items():
+        extra[k] = {"launches": cn, "total_ms": round(cms, 3), "tflops": round(cfl / (cms * 1e-3) / 1e12, 2),
+                    "algo_gbps": round(cby / (cms * 1e-3) / 1e9, 1)}
+    hb = extra.get("conv_kernel<32,128,KT=3>")
+    hbm = None
+    if hb:
+        hbm = {"bound": "hbm", "kernel": "conv_kernel<32,128,KT=3> (depth 0-1 ConvBlocks)", "achieved": hb["algo_gbps"],
+               "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(hb["algo_gbps"] / PEAK_HBM_GBPS, 4)}
+    return out, hbm, extra
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE configs[1]: 4)")
+    ap.add_argument("--graph", type=int, default=-1, help="1: replay the step from a hipGraph, 0: eager; "
+                                                          "default: graph on 1 GPU, eager with RCCL")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from audio_diffusion_pytorch_amd import parallel
+    rank = parallel.init_process_group_from_env()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+
+    model = build_model(dev)
+    if world > 1:
+        model = parallel.DataParallel(model)
+    torch.manual_seed(1234 + rank)
+    x = torch.randn(args.batch, 2, LENGTH).to(dev)  # synthetic waveforms, resident in HBM before timing
+    use_graph = args.graph if args.graph >= 0 else (1 if world == 1 else 0)
+
+    def zero():
+        for p in model.parameters():
+            p.grad = None
+
+    def eager_step():
+        zero()
+        loss = model(x)
+        loss.backward()
+        return loss
+
+    graph = None
+    if use_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    eager_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            zero()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = model(x)
+                static_loss.backward()
+        except Exception as e:  # capture is a launch-overhead optimisation only; the kernels are identical
+            if rank == 0:
+                print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); timing eager launches",
+                      file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    step = graph.replay if graph is not None else eager_step
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    ms = dt / args.steps * 1e3
+    value = world * args.steps / dt  # denoising steps (U-Net fwd+bwd evaluations on a batch) per second, whole job
+    line = {
+        "metric": "denoising steps/s (UNetV0 fwd+bwd) at [B,2,2**18]", "value": round(value, 3),
+        "unit": "denoising steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: unconditional DiffusionModel(UNetV0 channels="
+                               "[8,32,64,128,256,512,512,1024,1024], factors=[1,4,4,4,2,2,2,2,2], "
+                               "items=[1,2,2,2,2,2,2,4,4]) fwd+bwd, audio=randn(4,2,2**18) per GPU, random-init weights",
+                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "length": LENGTH,
+                   "samples_per_s": round(value * args.batch, 2), "launch": "hipGraph replay" if graph else "eager",
+                   "parallelism": f"dp{world}" if world > 1 else "single",
+                   "optimizer": "none (the metric is fwd+bwd; gradients for all 176M parameters are produced)"},
+    }
+    if rank == 0 and world == 1 and not args.no_roofline:
+        try:
+            rf, hbm, extra = roofline_leg(model.module if world > 1 else model, x)
+            line["roofline"] = rf
+            if hbm:
+                line["roofline_hbm_convblock"] = hbm
+            line["kernels"] = extra
+        except Exception as e:
+            line["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.batch)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,8 @@ typedef struct adp_conv_desc {
 } adp_conv_desc;
 
 int adp_conv1d(const adp_conv_desc* d, void* stream);
+/* tile the dispatcher selects for this problem, BM*1000+BN (introspection for profiling / roofline reports) */
+int64_t adp_conv1d_tile(const adp_conv_desc* d);
 
 /* Weight (+bias) gradient of the same convolution, deterministic two-stage reduction:
  *   dw[m][r][t] = sum_{b,n} dy[b,m,n] * Xv[b, r, n*stride + t*dil - pad]     dbias[m] = sum_{b,n} dy[b,m,n]

@@ -1,0 +1,64 @@
+"""Data-parallel path: 2 processes over gloo on the CPU (kernels through the SIMT emulator).
+Gradients after the bucketed all-reduce must equal the single-process gradients on the concatenated batch."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = dict(in_channels=2, channels=[8, 16], factors=[2, 2], items=[1, 1], modulation_features=32)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import conftest
+    conftest._use_emulator()
+    import audio_diffusion_pytorch_amd as adp
+    from audio_diffusion_pytorch_amd.parallel import DataParallel
+    from test_unet import FixedSigmas
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)  # different init per rank: the wrapper must broadcast rank 0's parameters
+    sig = [0.2, 0.7, 0.4, 0.9]
+    model = adp.DiffusionModel(net_t=adp.UNetV0, diffusion_sigma_distribution=FixedSigmas(sig[2 * rank:2 * rank + 2]),
+                               **CFG)
+    dp = DataParallel(model, min_bucket_bytes=1024)
+    g = torch.Generator().manual_seed(7)
+    x, noise = torch.randn(4, 2, 64, generator=g), torch.randn(4, 2, 64, generator=g)
+    loss = dp(x[2 * rank:2 * rank + 2], noise=noise[2 * rank:2 * rank + 2])
+    loss.backward()
+    torch.save({"grads": {n: p.grad.clone() for n, p in model.net.named_parameters()},
+                "params": {n: p.detach().clone() for n, p in model.net.named_parameters()}},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp2_gloo_equals_single_process(emul, tmp_path):
+    import audio_diffusion_pytorch_amd as adp
+    from test_unet import FixedSigmas
+    port = 29500 + (os.getpid() % 500)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    for n in r0["grads"]:
+        assert torch.equal(r0["params"][n], r1["params"][n]), n          # broadcast happened
+        assert torch.allclose(r0["grads"][n], r1["grads"][n], atol=0, rtol=0), n  # same averaged gradient
+    # single process on the concatenated batch with rank 0's parameters
+    sig = [0.2, 0.7, 0.4, 0.9]
+    torch.manual_seed(0)
+    model = adp.DiffusionModel(net_t=adp.UNetV0, diffusion_sigma_distribution=FixedSigmas(sig), **CFG)
+    with torch.no_grad():
+        for n, p in model.net.named_parameters():
+            p.copy_(r0["params"][n])
+    g = torch.Generator().manual_seed(7)
+    x, noise = torch.randn(4, 2, 64, generator=g), torch.randn(4, 2, 64, generator=g)
+    model(x, noise=noise).backward()
+    gmax = max(p.grad.abs().max().item() for p in model.net.parameters())
+    for n, p in model.net.named_parameters():
+        err = (r0["grads"][n] - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-3 * gmax)
+        assert err < 1e-4, (n, err)
