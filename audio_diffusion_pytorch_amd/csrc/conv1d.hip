@@ -194,6 +194,276 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_kernel(adp_co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Pipelined stride-1 variant (KT = 1 or 3): the workhorse of every ResNet ConvBlock, upsample conv, 1x1
+// projection and data gradient.  Software pipeline per K-chunk of BKT channels:
+//     issue global loads of chunk c+1 into registers -> MFMA over chunk c from LDS buffer c&1 ->
+//     apply the prologue and write chunk c+1 into LDS buffer (c+1)&1 -> one barrier
+// so HBM/L2 latency hides under the matrix-core work, with two LDS buffers and a single barrier per chunk.
+// Weight tile in LDS: forward  As[q = r*KT+t][m]   (4 scalar loads of 4 rows -> one ds_write_b128 along m),
+//                     gradient As[r][m*KT + t']     (straight 16-byte copies of the contiguous [M][KT] run;
+//                                                    fragment reads stride KT=3 floats: conflict-free).
+// GroupNorm (mean, rstd*gamma, beta) per input channel and LayerNorm (mean, rstd) per staged position sit in
+// LDS for the whole kernel, so the prologue never waits on global memory.
+// ------------------------------------------------------------------------------------------------
+constexpr int PRO_RMAX = 1024;  // channels whose prologue constants fit the LDS tables
+
+template <int BM, int BN, int WM, int WN, int KT, int BKT>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_s1_kernel(adp_conv_desc d) {
+  constexpr int NWN = BN / WN, NW = (BM / WM) * NWN, NT = NW * 64;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int XSP = ((BN - 1) + (KT - 1) * DILMAX + 1) | 1;
+  constexpr int BMP = BM + 4;            // forward layout row stride (floats), multiple of 4
+  constexpr int RP = BM * KT + 4;        // gradient layout row stride
+  constexpr int QK = BKT * KT;
+  constexpr int A_ELEMS = QK * BMP;      // >= BKT * RP
+  constexpr int NA4 = (BM * QK / 4 + NT - 1) / NT;   // float4 items per thread per chunk
+  constexpr int NX = (BKT * XSP + NT - 1) / NT;      // x elements per thread per chunk
+  __shared__ __attribute__((aligned(16))) float As[2][A_ELEMS];
+  __shared__ float Xs[2][BKT * XSP];
+  __shared__ float Pa[PRO_RMAX], Pb[PRO_RMAX];  // GroupNorm: silu(x*Pa + Pb), Pb = beta - mean*Pa
+  __shared__ float Lmu[XSP], Lrs[XSP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int wm0 = (wave / NWN) * WM, wn0 = (wave % NWN) * WN;
+  const int64_t b = blockIdx.z, m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const int dil = (int)d.dil;
+  const int XS = (BN - 1) + (KT - 1) * dil + 1;
+  const int64_t ustart = n0 - d.pad;
+  const int64_t M = d.M, R = d.R, R1 = d.R1, Lin = d.Lin;
+  const int64_t Lv = Lin * d.up;
+  const int ush = (d.up == 4) ? 2 : (d.up == 2 ? 1 : 0);
+  const int prologue = (int)d.prologue;
+  const bool tr = d.transposed != 0;
+  // 16-byte weight loads are legal for the gradient layout when rows stay aligned and the tile is interior
+  const bool vecA = tr && ((M * KT) % 4 == 0) && (m0 + BM <= M);
+
+  // ---- one-time prologue tables
+  if (prologue != 0) {
+    for (int64_t r = tid; r < R; r += NT) {
+      float ga = d.pro_gamma ? d.pro_gamma[r] : 1.0f, mean = 0.0f;
+      if (prologue == 1) {
+        const int64_t g = r / (R / d.groups);
+        mean = d.pro_stats[(b * d.groups + g) * 2];
+        ga *= d.pro_stats[(b * d.groups + g) * 2 + 1];
+      }
+      Pa[r] = ga;
+      Pb[r] = (d.pro_beta ? d.pro_beta[r] : 0.0f) - mean * ga;
+    }
+    if (prologue == 2) {
+      for (int p = tid; p < XSP; p += NT) {
+        const int64_t u = ustart + p;
+        float mu = 0.0f, rs = 0.0f;
+        if (u >= 0 && u < Lv) {
+          const int64_t l = u >> ush;
+          mu = d.pro_stats[(b * Lin + l) * 2];
+          rs = d.pro_stats[(b * Lin + l) * 2 + 1];
+        }
+        Lmu[p] = mu;
+        Lrs[p] = rs;
+      }
+    }
+  }
+
+  float4 ra[NA4];
+  float rx[NX];
+
+  auto load_chunk = [&](int64_t r0) {
+    if (!tr) {
+#pragma unroll
+      for (int i = 0; i < NA4; ++i) {
+        const int e = tid + i * NT;
+        const int q = e % QK, m4 = e / QK;
+        const int rl = q / KT;
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (e < BM * QK / 4 && r0 + rl < R) {
+          const float* wp = d.w + ((m0 + 4 * m4) * R + r0) * KT + q;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (m0 + 4 * m4 + j < M) v[j] = wp[(int64_t)j * R * KT];
+        }
+        ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    } else {
+      constexpr int C4 = BM * KT / 4;  // float4 items per gradient-layout row
+#pragma unroll
+      for (int i = 0; i < NA4; ++i) {
+        const int e = tid + i * NT;
+        const int rl = e / C4, c4 = e % C4;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (e < BKT * C4 && r0 + rl < R) {
+          const float* wp = d.w + ((r0 + rl) * M + m0) * KT + 4 * c4;
+          if (vecA) {
+            v = *reinterpret_cast<const float4*>(wp);
+          } else {
+            const int64_t lim = (M - m0) * KT;  // valid floats in this row of the tile
+            float t4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t4[j] = (4 * c4 + j < lim) ? wp[j] : 0.0f;
+            v = make_float4(t4[0], t4[1], t4[2], t4[3]);
+          }
+        }
+        ra[i] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + i * NT;
+      const int rl = e / XSP, p = e % XSP;
+      const int64_t r = r0 + rl, u = ustart + p;
+      float v = 0.0f;
+      if (rl < BKT && p < XS && r < R && u >= 0 && u < Lv) {
+        const float* src = (r < R1) ? d.x + (b * R1 + r) * Lin : d.x2 + (b * (R - R1) + (r - R1)) * Lin;
+        v = src[u >> ush];
+      }
+      rx[i] = v;
+    }
+  };
+
+  auto store_chunk = [&](int buf, int64_t r0) {
+    float* Ab = As[buf];
+    float* Xb = Xs[buf];
+    if (!tr) {
+#pragma unroll
+      for (int i = 0; i < NA4; ++i) {
+        const int e = tid + i * NT;
+        const int q = e % QK, m4 = e / QK;
+        if (e < BM * QK / 4) *reinterpret_cast<float4*>(Ab + q * BMP + 4 * m4) = ra[i];
+      }
+    } else {
+      constexpr int C4 = BM * KT / 4;
+#pragma unroll
+      for (int i = 0; i < NA4; ++i) {
+        const int e = tid + i * NT;
+        const int rl = e / C4, c4 = e % C4;
+        if (e < BKT * C4) *reinterpret_cast<float4*>(Ab + rl * RP + 4 * c4) = ra[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + i * NT;
+      const int rl = e / XSP, p = e % XSP;
+      if (rl < BKT) {
+        const int64_t r = r0 + rl, u = ustart + p;
+        float v = rx[i];
+        if (prologue != 0 && p < XS && r < R && u >= 0 && u < Lv) {
+          const int rr = (int)r;
+          if (prologue == 1) v = adp_silu(fmaf(v, Pa[rr], Pb[rr]));
+          else v = fmaf((v - Lmu[p]) * Lrs[p], Pa[rr], Pb[rr]);
+        }
+        Xb[rl * XSP + p] = v;
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  if (prologue != 0) __syncthreads();
+  load_chunk(0);
+  store_chunk(0, 0);
+  __syncthreads();
+
+  int buf = 0;
+  for (int64_t r0 = 0; r0 < R; r0 += BKT, buf ^= 1) {
+    const bool more = r0 + BKT < R;
+    if (more) load_chunk(r0 + BKT);
+    const float* Ab = As[buf];
+    const float* Xb = Xs[buf];
+    const int kp = (int)((R - r0) < BKT ? (R - r0) : BKT);
+    const int kpairs = (kp + 1) >> 1;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      if (kpairs == BKT / 2) {
+#pragma unroll
+        for (int rp = 0; rp < BKT / 2; ++rp) {
+          const int row = 2 * rp + hi;
+          float a[TM], bb[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            a[i] = tr ? Ab[row * RP + (wm0 + 32 * i + l31) * KT + (KT - 1 - t)]
+                      : Ab[(row * KT + t) * BMP + wm0 + 32 * i + l31];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bb[j] = Xb[row * XSP + wn0 + 32 * j + l31 + t * dil];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = adp_mfma32(a[i], bb[j], acc[i][j]);
+        }
+      } else {
+        for (int rp = 0; rp < kpairs; ++rp) {
+          const int row = 2 * rp + hi;
+          float a[TM], bb[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            a[i] = tr ? Ab[row * RP + (wm0 + 32 * i + l31) * KT + (KT - 1 - t)]
+                      : Ab[(row * KT + t) * BMP + wm0 + 32 * i + l31];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bb[j] = Xb[row * XSP + wn0 + 32 * j + l31 + t * dil];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = adp_mfma32(a[i], bb[j], acc[i][j]);
+        }
+      }
+    }
+    if (more) store_chunk(buf ^ 1, r0 + BKT);
+    __syncthreads();
+  }
+
+  // ---- epilogue (identical contract to conv_kernel)
+  const int64_t N = d.N;
+  const int sp = (int)d.sp;
+  const int64_t ebs = d.e_bstride ? d.e_bstride : M;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int64_t n = n0 + wn0 + 32 * j + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const bool ok = (m < M) && (n < N);
+        float v = acc[i][j][r];
+        if (ok) {
+          if (d.bias) v += d.bias[m];
+          if (d.out_pre) d.out_pre[(b * M + m) * N + n] = v;
+          if (d.e_scale) v *= d.e_scale[b * ebs + m];
+        } else {
+          v = 0.0f;
+        }
+        if (d.store == 0) {
+          if (ok) {
+            const int64_t o = (b * M + m) * N + n;
+            if (d.res) v += d.res[o];
+            d.out[o] = v;
+          }
+        } else if (d.store == 1) {
+          if (ok) {
+            const int64_t o = (b * (M / sp) + m / sp) * (N * sp) + n * sp + (m % sp);
+            if (d.res) v += d.res[o];
+            d.out[o] = v;
+          }
+        } else {
+          v += __shfl_xor(v, 1, 64);
+          if (sp == 4) v += __shfl_xor(v, 2, 64);
+          if (ok && (l31 % sp) == 0) {
+            const int64_t o = (b * M + m) * (N / sp) + n / sp;
+            if (d.res) v += d.res[o];
+            d.out[o] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight gradient: block tile = 32 (m) x 32 (r) x KT taps; the 4 waves split the position range of
 // each staged chunk and are summed through LDS in a fixed order (deterministic); partial tiles of the
 // nsplit position ranges go to ws and are summed by wgrad_reduce_kernel.
@@ -322,15 +592,42 @@ int launch_conv(const adp_conv_desc& d, void* stream) {
   return ADP_LAUNCH_OK();
 }
 
-// tile choice: fill >= ~2 workgroups per CU when the problem allows; 32-row tiles for narrow layers
+template <int BM, int BN, int WM, int WN, int KT, int BKT>
+int launch_conv_s1(const adp_conv_desc& d, void* stream) {
+  dim3 grid((unsigned)adp_cdiv(d.N, BN), (unsigned)adp_cdiv(d.M, BM), (unsigned)d.B);
+  dim3 block((BM / WM) * (BN / WN) * 64);
+  ADP_LAUNCH((conv_s1_kernel<BM, BN, WM, WN, KT, BKT>), grid, block, stream, d);
+  return ADP_LAUNCH_OK();
+}
+
+// tile choice (shared with adp_conv1d_tile): 32-row tiles for narrow layers, 128x128 when that still fills
+// the chip with >= 1.5 workgroups per CU, else 64x64
+int64_t pick_tile(const adp_conv_desc& d) {
+  if (d.M <= 32) return 32 * 1000 + 128;
+  if (d.stride != 4) {
+    const int64_t big = adp_cdiv(d.M, 128) * adp_cdiv(d.N, 128) * d.B;
+    if (d.M >= 128 && big >= 384) return 128 * 1000 + 128;
+  }
+  return 64 * 1000 + 64;
+}
+
+bool s1_eligible(const adp_conv_desc& d) {
+  return d.stride == 1 && (d.KT == 1 || d.KT == 3) && (d.up == 1 || d.up == 2 || d.up == 4) &&
+         (d.prologue == 0 || d.R <= PRO_RMAX);
+}
+
 template <int KT, int S>
 int dispatch_conv(const adp_conv_desc& d, void* stream) {
-  const int64_t M = d.M, N = d.N, B = d.B;
-  if (M <= 32) return launch_conv<32, 128, 32, 32, KT, S>(d, stream);
-  if (S != 4) {
-    const int64_t big = adp_cdiv(M, 128) * adp_cdiv(N, 128) * B;
-    if (M >= 128 && big >= 384) return launch_conv<128, 128, 64, 64, KT, S>(d, stream);
+  const int64_t tile = pick_tile(d);
+  if constexpr (S == 1) {
+    if (s1_eligible(d)) {
+      if (tile == 32128) return launch_conv_s1<32, 128, 32, 32, KT, 32>(d, stream);
+      if (tile == 128128) return launch_conv_s1<128, 128, 64, 64, KT, 16>(d, stream);
+      return launch_conv_s1<64, 64, 32, 32, KT, 32>(d, stream);
+    }
   }
+  if (tile == 32128) return launch_conv<32, 128, 32, 32, KT, S>(d, stream);
+  if (tile == 128128) return launch_conv<128, 128, 64, 64, KT, S>(d, stream);
   return launch_conv<64, 64, 32, 32, KT, S>(d, stream);
 }
 
@@ -392,13 +689,7 @@ extern "C" int adp_conv1d(const adp_conv_desc* dp, void* stream) {
 // which tile the dispatcher picks for this problem: BM * 1000 + BN (introspection for profiling / roofline reports)
 extern "C" int64_t adp_conv1d_tile(const adp_conv_desc* dp) {
   if (!dp) return ADP_ERR_NULL;
-  const adp_conv_desc& d = *dp;
-  if (d.M <= 32) return 32 * 1000 + 128;
-  if (d.stride != 4) {
-    const int64_t big = adp_cdiv(d.M, 128) * adp_cdiv(d.N, 128) * d.B;
-    if (d.M >= 128 && big >= 384) return 128 * 1000 + 128;
-  }
-  return 64 * 1000 + 64;
+  return pick_tile(*dp);
 }
 
 extern "C" int64_t adp_conv1d_wgrad_ws_bytes(const adp_wgrad_desc* dp) {

@@ -270,3 +270,30 @@ def add(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
         out = torch.empty_like(a)
     _C.call("adp_add", ptr(a), ptr(b), a.numel(), ptr(out), _C.stream())
     return out
+
+
+def attn_fwd(q: Tensor, kv: Tensor, heads: int, head_features: int):
+    """q [B, H*D, n]; kv [B, 2*H*D, m] (k = first half of the channels, v = second half) -> o [B, H*D, n], lse."""
+    B, mid, n = q.shape
+    m = kv.shape[2]
+    H, D = heads, head_features
+    assert mid == H * D and kv.shape[1] == 2 * mid
+    o = torch.empty_like(q)
+    lse = torch.empty((B, H, n), dtype=torch.float32, device=q.device)
+    kvf = kv.view(-1)
+    _C.call("adp_attn_fwd", ptr(q), ptr(kvf), ptr(kvf[mid * m:]), B, H, D, n, m, mid * n, 2 * mid * m, ptr(o),
+            ptr(lse), _C.stream())
+    return o, lse
+
+
+def attn_bwd(q: Tensor, kv: Tensor, o: Tensor, dout: Tensor, lse: Tensor, heads: int, head_features: int):
+    """Returns (dq [B, H*D, n], dkv [B, 2*H*D, m])."""
+    B, mid, n = q.shape
+    m = kv.shape[2]
+    H, D = heads, head_features
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    ws = _ws(_C.query("adp_attn_bwd_ws_bytes", B, H, D, n, m), q)
+    kvf, dkvf = kv.view(-1), dkv.view(-1)
+    _C.call("adp_attn_bwd", ptr(q), ptr(kvf), ptr(kvf[mid * m:]), ptr(o), ptr(dout), ptr(lse), B, H, D, n, m,
+            mid * n, 2 * mid * m, ptr(dq), ptr(dkvf), ptr(dkvf[mid * m:]), ptr(ws), _C.stream())
+    return dq, dkv

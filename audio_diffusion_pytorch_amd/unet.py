@@ -257,6 +257,11 @@ class _Run:
     def g(self, p: nn.Parameter) -> Tensor:
         return self.grads[self.pnames[id(p)]]
 
+    def gspan(self, p_first: nn.Parameter, numel: int) -> Tensor:
+        """Flat gradient slice starting at `p_first` and covering `numel` floats (adjacent parameters)."""
+        a, _ = self.net._param_offsets()[self.pnames[id(p_first)]]
+        return self.flat[a:a + numel]
+
     # -- conditioning ---------------------------------------------------------------------
     def conditioning(self, time: Tensor, features: Optional[Tensor]):
         n = self.net
@@ -446,6 +451,7 @@ class _UNetFn(torch.autograd.Function):
         x2 = x_append.contiguous() if x_append is not None else None
         run.conditioning(time, features)
         run.emb_grad = None
+        run.want_emb_grad = bool(embedding is not None and ctx.needs_input_grad[4])
         y = run.block(0, x, x2, embedding.contiguous() if embedding is not None else None, channels,
                       need_dx=bool(ctx.needs_input_grad[1]))
         ctx.run = run
@@ -462,6 +468,7 @@ class _UNetFn(torch.autograd.Function):
         params = list(net.parameters())
         total = sum(p.numel() for p in params)
         flat = torch.zeros(total, dtype=torch.float32, device=gy.device)
+        run.flat = flat
         off = 0
         views = []
         for name, p in net.named_parameters():

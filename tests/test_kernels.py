@@ -299,3 +299,23 @@ def test_v_noise_mse_step(dev):
     xo = ops.v_step(x.to(dev), n.to(dev), ab4.to(dev))
     ref = 0.5 * (0.3 * x - 0.9 * n) + 0.8 * (0.9 * x + 0.3 * n)
     assert rel_err(xo, ref) < 1e-6
+
+
+# ------------------------------------------------------------------ attention core
+@pytest.mark.parametrize("B,H,D,n,m", [(2, 2, 64, 160, 160), (1, 3, 32, 70, 45), (1, 8, 64, 128, 64)])
+def test_attention_fwd_bwd(dev, B, H, D, n, m):
+    mid = H * D
+    q = rnd(B, mid, n, seed=1).requires_grad_()
+    kv = rnd(B, 2 * mid, m, seed=2).requires_grad_()
+    qh = q.view(B, H, D, n).transpose(2, 3)
+    kh = kv[:, :mid].reshape(B, H, D, m).transpose(2, 3)
+    vh = kv[:, mid:].reshape(B, H, D, m).transpose(2, 3)
+    att = torch.softmax(torch.einsum("bhnd,bhmd->bhnm", qh, kh) * D ** -0.5, dim=-1)
+    o_ref = torch.einsum("bhnm,bhmd->bhnd", att, vh).transpose(2, 3).reshape(B, mid, n)
+    o, lse = ops.attn_fwd(q.detach().to(dev), kv.detach().to(dev), H, D)
+    assert rel_err(o, o_ref) < TOL
+    do = rnd(B, mid, n, seed=3)
+    dq_ref, dkv_ref = torch.autograd.grad(o_ref, (q, kv), do)
+    dq, dkv = ops.attn_bwd(q.detach().to(dev), kv.detach().to(dev), o, do.to(dev), lse, H, D)
+    assert rel_err(dq, dq_ref) < TOL
+    assert rel_err(dkv, dkv_ref) < TOL

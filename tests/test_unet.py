@@ -149,3 +149,27 @@ def test_upsampler_append_channels(dev):
     loss.backward()
     assert abs(loss.item() - loss_ref.item()) < TOL * abs(loss_ref.item())
     compare_grads(up.net.net, oracle_wrap.net)
+
+
+ATTN = dict(in_channels=2, channels=[8, 16, 32], factors=[1, 2, 2], items=[1, 1, 2], modulation_features=32,
+            attentions=[0, 1, 1], cross_attentions=[0, 0, 1], attention_heads=2, attention_features=8,
+            embedding_features=12)
+
+
+def test_unet_attention_self_and_cross(dev):
+    """README attention layout at tiny size (self attention + cross attention over an injected embedding:
+    BASELINE config 4 feeds `embedding=` directly)."""
+    oracle, net = build_pair(ATTN, dev)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 2, 96, generator=g)
+    t = torch.tensor([0.15, 0.65])
+    emb = torch.randn(2, 5, 12, generator=g).requires_grad_()
+    y_ref = oracle(x, t, embedding=emb)
+    emb_d = emb.detach().to(dev).requires_grad_()
+    y = net(x.to(dev), t.to(dev), embedding=emb_d)
+    assert rel_err(y, y_ref) < TOL
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    y.backward(gy.to(dev))
+    compare_grads(net, oracle)
+    assert rel_err(emb_d.grad, emb.grad) < TOL
