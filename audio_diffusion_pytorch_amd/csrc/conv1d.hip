@@ -568,6 +568,163 @@ __global__ __launch_bounds__(256) void wgrad_kernel(adp_wgrad_desc d, int64_t PS
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pipelined stride-1 weight gradient for wide layers: block tile 64 (m) x 64 (r) x KT, the 4 waves form a
+// 2 x 2 grid of 32 x 32 x KT accumulators (no cross-wave reduction), position chunks of 64 are double-buffered
+// in LDS with register prefetch exactly like conv_s1_kernel.  A block walks a contiguous range of
+// (batch, chunk) pairs; with nsplit == 1 it writes dw/dbias directly, otherwise a partial to ws.
+// ------------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(256) void wgrad_s1_kernel(adp_wgrad_desc d, int64_t CPS, int64_t CPB, int64_t nsplit) {
+  constexpr int BKN = 64, NT = 256;
+  constexpr int DP = BKN + 1;
+  constexpr int XSP = (BKN + (KT - 1) * DILMAX + 1) | 1;
+  constexpr int NX = (64 * XSP + NT - 1) / NT;
+  __shared__ float Dys[2][64 * DP];
+  __shared__ float Xs[2][64 * XSP];
+  __shared__ float Pa[64], Pb[64];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int wm0 = (wave >> 1) * 32, wr0 = (wave & 1) * 32;
+  const int64_t split = blockIdx.x;
+  const int64_t m0 = (int64_t)blockIdx.y * 64, r0 = (int64_t)blockIdx.z * 64;
+  const int dil = (int)d.dil;
+  const int XS = BKN + (KT - 1) * dil;
+  const int64_t M = d.M, R = d.R, R1 = d.R1, N = d.N, Lin = d.Lin;
+  const int64_t Lv = Lin * d.up;
+  const int ush = (d.up == 4) ? 2 : (d.up == 2 ? 1 : 0);
+  const int prologue = (int)d.prologue;
+  const bool do_bias = (d.dbias != nullptr) && (blockIdx.z == 0) && (wr0 == 0);
+  const int64_t total = d.B * CPB;
+  const int64_t cbeg = split * CPS, cend = (cbeg + CPS < total) ? cbeg + CPS : total;
+
+  float rdy[16];
+  float rx[NX];
+  int64_t cur_b = -1;
+
+  auto load_chunk = [&](int64_t c) {
+    const int64_t b = c / CPB, p0 = (c % CPB) * BKN;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t m = m0 + wave + 4 * i, n = p0 + lane;
+      rdy[i] = (m < M && n < N) ? d.dy[(b * M + m) * N + n] : 0.0f;
+    }
+    const int64_t ustart = p0 - d.pad;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + i * NT;
+      const int rl = e / XSP, p = e % XSP;
+      const int64_t r = r0 + rl, u = ustart + p;
+      float v = 0.0f;
+      if (rl < 64 && p < XS && r < R && u >= 0 && u < Lv) {
+        const float* src = (r < R1) ? d.x + (b * R1 + r) * Lin : d.x2 + (b * (R - R1) + (r - R1)) * Lin;
+        v = src[u >> ush];
+      }
+      rx[i] = v;
+    }
+  };
+  // GroupNorm constants depend on the batch element: refreshed (by all threads, between barriers) when b changes
+  auto set_batch = [&](int64_t b) {
+    if (prologue == 1 && tid < 64) {
+      const int64_t r = r0 + tid;
+      float ga = 1.0f, be = 0.0f;
+      if (r < R) {
+        const int64_t g = r / (R / d.groups);
+        const float mean = d.pro_stats[(b * d.groups + g) * 2];
+        ga = (d.pro_gamma ? d.pro_gamma[r] : 1.0f) * d.pro_stats[(b * d.groups + g) * 2 + 1];
+        be = (d.pro_beta ? d.pro_beta[r] : 0.0f) - mean * ga;
+      }
+      Pa[tid] = ga;
+      Pb[tid] = be;
+    }
+  };
+  auto store_chunk = [&](int buf, int64_t c) {
+    const int64_t p0 = (c % CPB) * BKN;
+    float* Db = Dys[buf];
+    float* Xb = Xs[buf];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Db[(wave + 4 * i) * DP + lane] = rdy[i];
+    const int64_t ustart = p0 - d.pad;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + i * NT;
+      const int rl = e / XSP, p = e % XSP;
+      if (rl < 64) {
+        const int64_t r = r0 + rl, u = ustart + p;
+        float v = rx[i];
+        if (prologue == 1 && p < XS && r < R && u >= 0 && u < Lv) v = adp_silu(fmaf(v, Pa[rl], Pb[rl]));
+        Xb[rl * XSP + p] = v;
+      }
+    }
+  };
+
+  f32x16 acc[KT];
+  f32x16 accb;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accb[r] = 0.0f;
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  if (cbeg < cend) {
+    cur_b = cbeg / CPB;
+    set_batch(cur_b);
+    __syncthreads();
+    load_chunk(cbeg);
+    store_chunk(0, cbeg);
+    __syncthreads();
+  }
+  int buf = 0;
+  for (int64_t c = cbeg; c < cend; ++c, buf ^= 1) {
+    const bool more = c + 1 < cend;
+    if (more) load_chunk(c + 1);
+    const float* Db = Dys[buf];
+    const float* Xb = Xs[buf];
+#pragma unroll 8
+    for (int kk = 0; kk < BKN; kk += 2) {
+      const int k = kk + hi;
+      const float a = Db[(wm0 + l31) * DP + k];
+#pragma unroll
+      for (int t = 0; t < KT; ++t) acc[t] = adp_mfma32(a, Xb[(wr0 + l31) * XSP + k + t * dil], acc[t]);
+      if (do_bias) accb = adp_mfma32(a, 1.0f, accb);
+    }
+    if (more) {
+      const int64_t nb = (c + 1) / CPB;
+      if (nb != cur_b) {  // block-uniform: the next chunk starts a new batch element -> new GroupNorm constants
+        __syncthreads();
+        set_batch(nb);
+        cur_b = nb;
+        __syncthreads();
+      }
+      store_chunk(buf ^ 1, c + 1);
+    }
+    __syncthreads();
+  }
+
+  const bool direct = (nsplit == 1);
+  float* base = direct ? d.dw : d.ws + split * (M * R * KT);
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi, rr = r0 + wr0 + l31;
+      if (m < M && rr < R) {
+        float* o = base + (m * R + rr) * KT + t;
+        *o = (direct && d.accumulate) ? *o + acc[t][r] : acc[t][r];
+      }
+    }
+  if (do_bias && l31 == 0) {
+    float* bb = direct ? d.dbias : d.ws + nsplit * (M * R * KT) + split * M;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (m < M) bb[m] = (direct && d.accumulate) ? bb[m] + accb[r] : accb[r];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int64_t nsplit, int64_t cnt, int64_t M,
                                                            float* dw, float* dbias, int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -645,8 +802,44 @@ void wgrad_split(const adp_wgrad_desc& d, int BKN, int64_t* PS, int64_t* SPB) {
 
 int wgrad_bkn(int64_t S) { return S == 4 ? 64 : 128; }
 
+// wide stride-1 layers take the pipelined 64x64 kernel
+bool wgrad_s1_eligible(const adp_wgrad_desc& d) {
+  return d.stride == 1 && (d.KT == 1 || d.KT == 3) && (d.up == 1 || d.up == 2 || d.up == 4) && d.prologue != 2 &&
+         (d.M > 32 || d.R > 32);
+}
+// chunks per batch element, chunks per split, number of splits (~2 workgroups per CU)
+void wgrad_s1_split(const adp_wgrad_desc& d, int64_t* CPB, int64_t* CPS, int64_t* nsplit) {
+  const int64_t tiles = adp_cdiv(d.M, 64) * adp_cdiv(d.R, 64);
+  const int64_t cpb = adp_cdiv(d.N, 64), total = d.B * cpb;
+  int64_t ns = adp_cdiv(512, tiles);
+  if (ns > total) ns = total;
+  if (ns < 1) ns = 1;
+  const int64_t cps = adp_cdiv(total, ns);
+  *CPB = cpb;
+  *CPS = cps;
+  *nsplit = adp_cdiv(total, cps);
+}
+
+template <int KT>
+int launch_wgrad_s1(const adp_wgrad_desc& d, void* stream) {
+  int64_t CPB, CPS, nsplit;
+  wgrad_s1_split(d, &CPB, &CPS, &nsplit);
+  dim3 grid((unsigned)nsplit, (unsigned)adp_cdiv(d.M, 64), (unsigned)adp_cdiv(d.R, 64));
+  ADP_LAUNCH((wgrad_s1_kernel<KT>), grid, dim3(256), stream, d, CPS, CPB, nsplit);
+  if (nsplit > 1) {
+    const int64_t cnt = d.M * d.R * KT;
+    const int64_t tot = cnt + (d.dbias ? d.M : 0);
+    ADP_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)adp_cdiv(tot, 256)), dim3(256), stream, (const float*)d.ws,
+               nsplit, cnt, d.M, d.dw, d.dbias, (int)d.accumulate);
+  }
+  return ADP_LAUNCH_OK();
+}
+
 template <int KT, int S>
 int launch_wgrad(const adp_wgrad_desc& d, void* stream) {
+  if constexpr (S == 1) {
+    if (wgrad_s1_eligible(d)) return launch_wgrad_s1<KT>(d, stream);
+  }
   int64_t PS, SPB;
   wgrad_split(d, WgradCfg<KT, S>::BKN, &PS, &SPB);
   const int64_t nsplit = d.B * SPB;
@@ -694,9 +887,15 @@ extern "C" int64_t adp_conv1d_tile(const adp_conv_desc* dp) {
 
 extern "C" int64_t adp_conv1d_wgrad_ws_bytes(const adp_wgrad_desc* dp) {
   if (!dp || !ks_supported(dp->KT, dp->stride) || dp->B <= 0 || dp->N <= 0) return ADP_ERR_UNSUPPORTED;
-  int64_t PS, SPB;
-  wgrad_split(*dp, wgrad_bkn(dp->stride), &PS, &SPB);
-  const int64_t nsplit = dp->B * SPB;
+  int64_t nsplit;
+  if (wgrad_s1_eligible(*dp)) {
+    int64_t CPB, CPS;
+    wgrad_s1_split(*dp, &CPB, &CPS, &nsplit);
+  } else {
+    int64_t PS, SPB;
+    wgrad_split(*dp, wgrad_bkn(dp->stride), &PS, &SPB);
+    nsplit = dp->B * SPB;
+  }
   return nsplit * (dp->M * dp->R * dp->KT + dp->M) * (int64_t)sizeof(float);
 }
 

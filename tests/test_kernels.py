@@ -150,8 +150,8 @@ def test_conv1d_wgrad(dev, B, R, M, L, KT, stride, pad, up):
     assert rel_err(db, db_ref) < TOL
 
 
-def test_conv1d_wgrad_prologue_accumulate(dev):
-    B, C, L, G = 2, 16, 700, 8
+@pytest.mark.parametrize("B,C,L,G", [(2, 16, 700, 8), (3, 64, 200, 8), (5, 72, 90, 4)])
+def test_conv1d_wgrad_prologue_accumulate(dev, B, C, L, G):
     x = rnd(B, C, L, seed=1) * 1.3 + 0.2
     gamma, beta = rnd(C, seed=4) * 0.5 + 1, rnd(C, seed=5) * 0.1
     w = rnd(C, C, 3, seed=2, scale=0.2).requires_grad_()
