@@ -36,31 +36,39 @@ def build_model(dev):
     return model.to(dev)
 
 
-def cpu_baseline(batch: int, steps: int = 2):
-    """The reference CPU path (oracle restatement of the reference's a_unet composition + live v-diffusion math),
-    timed on this host's cores on a bounded sample: `steps` full fwd+bwd steps at the bench batch."""
+def cpu_baseline(batch: int, threads: int = 16, budget_s: float = 25.0):
+    """The reference CPU path (oracle restatement of the reference's a_unet composition + the live v-diffusion
+    math), timed on this host's cores on a BOUNDED sample: fwd+bwd steps of the same UNetV0 at batch 1 (one sample
+    of the bench batch) until ~budget_s seconds are spent, reported in bench steps/s (a bench step = `batch`
+    samples).  Thread count is capped: with every core of a large host (256 here) oneDNN's 8-channel depth-0
+    convs oversubscribe and run ~100x slower (measured 345 s/step), which says nothing about the CPU path."""
     from oracle import vdiffusion as ovd
     from oracle.a_unet_restatement import UNetV0Oracle
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, threads)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     net = UNetV0Oracle(in_channels=2, channels=CHANNELS, factors=FACTORS, items=ITEMS)
-    x = torch.randn(batch, 2, LENGTH)
+    x = torch.randn(1, 2, LENGTH)
 
     def step():
         for p in net.parameters():
             p.grad = None
-        loss = ovd.v_loss(net, x, torch.randn_like(x), torch.rand(batch))
+        loss = ovd.v_loss(net, x, torch.randn_like(x), torch.rand(1))
         loss.backward()
 
-    step()  # warm-up (oneDNN primitive creation)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    step()  # warm-up (oneDNN primitive creation)
+    warm = time.perf_counter() - t0
+    n, t0 = 0, time.perf_counter()
+    while n < 2 or (time.perf_counter() - t0 < budget_s - warm and n < 20):
         step()
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": round(1.0 / dt, 4), "unit": "denoising steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} fwd+bwd steps of the same UNetV0 at batch {batch}, fp32, torch CPU ({cores} threads), "
-                      "after 1 warm-up step"}
+        n += 1
+        if time.perf_counter() - t0 > 4 * budget_s:
+            break
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(1.0 / (dt * batch), 4), "unit": "denoising steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fwd+bwd steps of the same UNetV0 on ONE sample [1,2,2**18] ({dt:.2f} s each, fp32, torch "
+                      f"CPU, {cores} threads, after 1 warm-up step), scaled to the bench step of {batch} samples"}
 
 
 def roofline_leg(model, x):
