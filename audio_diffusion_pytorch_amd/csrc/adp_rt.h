@@ -26,6 +26,9 @@ __device__ __forceinline__ f32x4 adp_mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence
+__device__ __forceinline__ float adp_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 #define ADP_LAUNCH(kern, grid, block, stream, ...) \
   hipLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__)
 #define ADP_LAUNCH_OK() (hipGetLastError() == hipSuccess ? ADP_OK : ADP_ERR_LAUNCH)
@@ -47,6 +50,8 @@ __device__ __forceinline__ float adp_wave_max(float v) {
 }
 __device__ __forceinline__ float adp_sigmoid(float h) { return 1.0f / (1.0f + __expf(-h)); }
 __device__ __forceinline__ float adp_silu(float h) { return h * adp_sigmoid(h); }
+// hot-loop form: v_exp_f32 + v_rcp_f32, ~2 ulp (the 1e-3 parity contract has 4 orders of magnitude of slack)
+__device__ __forceinline__ float adp_silu_fast(float h) { return h * adp_rcp(1.0f + __expf(-h)); }
 // d silu(h) / dh
 __device__ __forceinline__ float adp_dsilu(float h) {
   float s = adp_sigmoid(h);

@@ -16,6 +16,7 @@
 // reads are unit-stride across the 32 lanes of a half-wave (conflict-free ds_read_b32).
 #include "adp_rt.h"
 #include "adp.h"
+#include "conv_internal.h"
 
 namespace {
 
@@ -873,6 +874,7 @@ extern "C" int adp_conv1d(const adp_conv_desc* dp, void* stream) {
   if (d.store == 1 && (d.sp < 1 || d.M % d.sp != 0)) return ADP_ERR_SHAPE;
   if (d.store == 2 && ((d.sp != 2 && d.sp != 4) || d.N % d.sp != 0 || d.bias)) return ADP_ERR_UNSUPPORTED;
   if (d.B > 65535 || adp_cdiv(d.M, 32) > 65535) return ADP_ERR_SHAPE;
+  if (adp_conv_mm_eligible(d)) return adp_conv_mm(d, stream);
   if (d.KT == 1) return dispatch_conv<1, 1>(d, stream);
   if (d.KT == 2) return dispatch_conv<2, 2>(d, stream);
   if (d.KT == 3) return dispatch_conv<3, 1>(d, stream);
@@ -882,6 +884,7 @@ extern "C" int adp_conv1d(const adp_conv_desc* dp, void* stream) {
 // which tile the dispatcher picks for this problem: BM * 1000 + BN (introspection for profiling / roofline reports)
 extern "C" int64_t adp_conv1d_tile(const adp_conv_desc* dp) {
   if (!dp) return ADP_ERR_NULL;
+  if (adp_conv_mm_eligible(*dp)) return adp_conv_mm_tile(*dp);
   return pick_tile(*dp);
 }
 

@@ -1,0 +1,8 @@
+// Private to libadp_hip.so: kernel families behind adp_conv1d / adp_conv1d_wgrad (not part of the C-ABI).
+#pragma once
+#include "adp.h"
+
+// conv_mm.hip: pipelined split-K-in-block implicit GEMM (stride 1, kernel 1/3, channels % 32 == 0)
+bool adp_conv_mm_eligible(const adp_conv_desc& d);
+int adp_conv_mm(const adp_conv_desc& d, void* stream);
+int64_t adp_conv_mm_tile(const adp_conv_desc& d);  // NKG * 1000000 + BM * 1000 + BN

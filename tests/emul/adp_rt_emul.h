@@ -277,6 +277,7 @@ static inline float atomicAdd(float* p, float v) {
   return o;
 }
 #define __expf(x) expf(x)
+static inline float adp_rcp(float x) { return 1.0f / x; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
 

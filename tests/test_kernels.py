@@ -111,6 +111,50 @@ def test_conv1d_concat_and_skipmod(dev):
     assert rel_err(out, ref) < TOL
 
 
+# ------------------------------------------------------------------ deep-layer GEMM conv (conv_mm.hip)
+MM_CASES = [
+    # B, R, M, L, KT, pad, dil -- every (tile, K-group) variant of the split-K-in-block kernel, multi-chunk K,
+    # ragged last position tile, dilation, kernel 1
+    (1, 64, 64, 128, 3, 1, 1),        # 32x64 tile, 4 K groups, 2 chunks
+    (2, 96, 32, 72, 3, 1, 1),         # ragged N (72 = 64 + 8), 3 chunks
+    (3, 32, 64, 64 * 64, 3, 1, 1),    # 192 tiles -> 64x64 tile, 4 K groups
+    (1, 32, 64, 64 * 384, 3, 1, 1),   # 384 tiles -> 64x64 tile, 2 K groups
+    (1, 32, 64, 64 * 768, 1, 0, 1),   # 768 tiles -> 64x64 tile, 1 K group, kernel 1
+    (2, 64, 96, 100, 1, 0, 1),        # M % 64 != 0 -> 32-row tile, kernel 1, 2 chunks
+    (1, 32, 32, 64, 3, 3, 3),         # dilation 3
+]
+
+
+@pytest.mark.parametrize("B,R,M,L,KT,pad,dil", MM_CASES)
+def test_conv_mm_family(dev, B, R, M, L, KT, pad, dil):
+    from audio_diffusion_pytorch_amd import _C
+    G = 8
+    x = (rnd(B, R, L, seed=1) * 1.3 + 0.2).requires_grad_()
+    w, b = rnd(M, R, KT, seed=2, scale=0.2), rnd(M, seed=3)
+    gamma, beta = rnd(R, seed=4) * 0.5 + 1, rnd(R, seed=5) * 0.1
+    xd, wd = x.detach().to(dev), w.to(dev)
+    d = _C.ConvDesc(_C.ptr(xd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(xd), None, B, R, R, L, M, L,
+                    KT, 1, dil, pad, 1, 0, 0, 1, 0, 1, 0)
+    assert _C.query("adp_conv1d_tile", d) >= 1000000, "case must dispatch to the conv_mm family"
+    # plain forward + bias
+    y = F.conv1d(x, w, b, padding=pad, dilation=dil)
+    out = ops.conv1d(xd, wd, b.to(dev), pad=pad, dil=dil)
+    assert out.shape == y.shape
+    assert rel_err(out, y) < TOL
+    # data gradient (transposed weight view)
+    dy = rnd(*y.shape, seed=9)
+    (dx_ref,) = torch.autograd.grad(y, x, dy)
+    dx = ops.conv1d(dy.to(dev), wd, None, pad=(KT - 1) * dil - pad, dil=dil, transposed=True)
+    assert rel_err(dx, dx_ref) < TOL
+    # GroupNorm + SiLU prologue, residual epilogue
+    res = rnd(B, M, L, seed=6)
+    ref = F.conv1d(ref_gn_silu(x.detach(), G, gamma, beta), w, b, padding=pad, dilation=dil) + res
+    stats = ops.gn_stats(xd, G)
+    out = ops.conv1d(xd, wd, b.to(dev), pad=pad, dil=dil, prologue=1, pro_stats=stats, pro_gamma=gamma.to(dev),
+                     pro_beta=beta.to(dev), groups=G, res=res.to(dev))
+    assert rel_err(out, ref) < TOL
+
+
 # ------------------------------------------------------------------ conv data gradients
 @pytest.mark.parametrize("B,R,M,L,KT,stride,pad,up", CONV_CASES)
 def test_conv1d_dgrad(dev, B, R, M, L, KT, stride, pad, up):
