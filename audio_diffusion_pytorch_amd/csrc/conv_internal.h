@@ -6,3 +6,8 @@
 bool adp_conv_mm_eligible(const adp_conv_desc& d);
 int adp_conv_mm(const adp_conv_desc& d, void* stream);
 int64_t adp_conv_mm_tile(const adp_conv_desc& d);  // NKG * 1000000 + BM * 1000 + BN
+
+// wgrad_mm.hip: pipelined weight gradient of the stride-1 'same' convolutions (kernel 3 / 1, channels % 32 == 0)
+bool adp_wgrad_mm_eligible(const adp_wgrad_desc& d);
+int64_t adp_wgrad_mm_ws_floats(const adp_wgrad_desc& d);
+int adp_wgrad_mm(const adp_wgrad_desc& d, void* stream);

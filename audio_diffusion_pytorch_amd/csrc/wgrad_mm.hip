@@ -1,0 +1,312 @@
+// Weight (+bias) gradient of the stride-1 'same' convolutions (kernel 3 pad 1, kernel 1 pad 0) on the f32 matrix
+// cores -- autograd's conv weight gradient for the ResnetItem ConvBlocks of
+// /root/reference/audio_diffusion_pytorch/components.py:89.
+//
+//   dw[m][r][t] = sum_{b,n} dy[b,m,n] * Xa[b, r, n + t - pad]        dbias[m] = sum_{b,n} dy[b,m,n]
+//
+// GEMM view: output (m, r) per tap, contraction over positions.  A block owns a BM x BR tile of (m, r) for all
+// KT taps (KT accumulator tiles per wave: the dy fragment is shared by the taps); positions are staged in chunks
+// of 64, double-buffered in LDS with register prefetch and one barrier per chunk, exactly like conv_mm.hip.  The
+// NKG wave groups of a block split every chunk's 64 positions (in-block split-K, summed through LDS in a fixed
+// order), and when the (m, r) tile grid is smaller than the chip the position range is additionally split across
+// workgroups (partials to the workspace, summed by wgrad_reduce_kernel): deterministic, no atomics.
+//   fragments: lane (row, hi) reads 4 consecutive positions 8s+4hi.. of its dy row (one ds_read_b128) and the
+//   12 positions around them of its x row (three ds_read_b128, tap t / position j -> register j + 4 - pad + t);
+//   row strides are 4 mod 8 dwords, so the 16-byte reads are bank-conflict free.
+//   The GroupNorm+SiLU of the conv input is recomputed on the way into LDS (per-slot gamma/beta in registers,
+//   the (mean, rstd) pair of the chunk's batch element fetched with the prefetch).
+//   dbias is summed by the dy loader threads on the VALU (each staging slot owns one row), not on the MFMA.
+#include "adp_rt.h"
+#include "adp.h"
+#include "conv_internal.h"
+
+namespace {
+
+constexpr int WG_BKN = 64;  // positions per staged chunk
+
+template <int BM, int BR, int NKG, int KT, int PRO>
+__global__ __launch_bounds__((BM / 32) * (BR / 32) * NKG * 64) void wgrad_mm_kernel(adp_wgrad_desc d, int CPB, int CPS,
+                                                                                  int nsplit) {
+  constexpr int BKN = WG_BKN, PPW = BKN / NKG;
+  constexpr int NQR = BR / 32, NQ = (BM / 32) * NQR, NW = NQ * NKG, NT = NW * 64;
+  constexpr int PAD = (KT - 1) / 2;
+  constexpr int DS = BKN + 4, XS = BKN + 12;  // row strides (floats), both 4 mod 8
+  constexpr int DQ = BKN / 4, XQ = (BKN + 8) / 4;
+  constexpr int D_ELEMS = BM * DS, X_ELEMS = BR * XS;
+  constexpr int ND4 = (BM * DQ + NT - 1) / NT, NX4 = (BR * XQ + NT - 1) / NT;
+  constexpr int RED = NQ * KT * 1024;
+  constexpr int STAGE = 2 * (D_ELEMS + X_ELEMS);
+  constexpr int SM = STAGE > RED ? STAGE : RED;
+  static_assert(PPW % 8 == 0, "a wave consumes positions in groups of 8");
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int quad = wave % NQ, kg = wave / NQ;
+  const int wm0 = (quad / NQR) * 32, wr0 = (quad % NQR) * 32;
+
+  const int M = (int)d.M, R = (int)d.R, L = (int)d.Lin, N = (int)d.N, G = (int)d.groups;
+  const int split = blockIdx.x;
+  const int m0 = blockIdx.y * BM, r0 = blockIdx.z * BR;
+  const int total = (int)d.B * CPB;
+  const int cbeg = split * CPS, cend = (cbeg + CPS < total) ? cbeg + CPS : total;
+  const bool do_bias = (d.dbias != nullptr) && (blockIdx.z == 0);
+
+  // ---- staging slots (chunk independent parts); slot indices wrap instead of being guarded
+  int d_src[ND4], d_dst[ND4], d_pos[ND4];
+#pragma unroll
+  for (int i = 0; i < ND4; ++i) {
+    const int e = (tid + i * NT) % (BM * DQ);
+    const int row = e / DQ, q = e - row * DQ;
+    d_dst[i] = row * DS + 4 * q;
+    d_src[i] = (m0 + row) * N + 4 * q;
+    d_pos[i] = 4 * q;
+  }
+  int x_src[NX4], x_dst[NX4], x_pos[NX4], x_st[NX4];
+  float x_ga[NX4], x_be[NX4];
+#pragma unroll
+  for (int i = 0; i < NX4; ++i) {
+    const int e = (tid + i * NT) % (BR * XQ);
+    const int row = e / XQ, q = e - row * XQ;
+    x_dst[i] = row * XS + 4 * q;
+    x_src[i] = (r0 + row) * L;
+    x_pos[i] = 4 * q - 4;
+    if (PRO == 1) {
+      const int r = r0 + row;
+      x_st[i] = (r / (R / G)) * 2;
+      x_ga[i] = d.pro_gamma ? d.pro_gamma[r] : 1.0f;
+      x_be[i] = d.pro_beta ? d.pro_beta[r] : 0.0f;
+    }
+  }
+
+  f32x16 acc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  float bsum[ND4];
+#pragma unroll
+  for (int i = 0; i < ND4; ++i) bsum[i] = 0.0f;
+
+  f32x4 rd[ND4], rx[NX4];
+  float rmean[NX4], rrstd[NX4];
+  bool d_ok[ND4], x_ok[NX4];
+
+  // chunk c -> batch element b, first position p0
+  int b = cbeg / CPB, p0 = (cbeg - b * CPB) * BKN;
+
+#define WG_LOAD()                                                                                          \
+  {                                                                                                        \
+    const float* dyb = d.dy + (int64_t)b * M * N + p0;                                                     \
+    _Pragma("unroll") for (int i = 0; i < ND4; ++i) {                                                      \
+      d_ok[i] = (p0 + d_pos[i] < N);                                                                       \
+      rd[i] = *reinterpret_cast<const f32x4*>(dyb + (d_ok[i] ? d_src[i] : d_src[i] - d_pos[i] - p0));      \
+    }                                                                                                      \
+    const float* xbp = d.x + (int64_t)b * R * L;                                                           \
+    _Pragma("unroll") for (int i = 0; i < NX4; ++i) {                                                      \
+      const int u = p0 + x_pos[i];                                                                         \
+      x_ok[i] = (u >= 0 && u < L);                                                                         \
+      rx[i] = *reinterpret_cast<const f32x4*>(xbp + x_src[i] + (x_ok[i] ? u : 0));                         \
+      if (PRO == 1) {                                                                                      \
+        rmean[i] = d.pro_stats[(int64_t)b * G * 2 + x_st[i]];                                              \
+        rrstd[i] = d.pro_stats[(int64_t)b * G * 2 + x_st[i] + 1];                                          \
+      }                                                                                                    \
+    }                                                                                                      \
+  }
+
+  if (cbeg < cend) WG_LOAD();
+
+  for (int c = cbeg; c < cend; ++c) {
+    float* Db = smem + ((c - cbeg) & 1) * (D_ELEMS + X_ELEMS);
+    float* Xb = Db + D_ELEMS;
+    // ---- registers -> LDS
+#pragma unroll
+    for (int i = 0; i < ND4; ++i) {
+      f32x4 v = rd[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = d_ok[i] ? v[j] : 0.0f;
+      // dbias: this slot's row is fixed; wrapped duplicate slots (tid + i*NT >= BM*DQ) must not count twice
+      if (tid + i * NT < BM * DQ) bsum[i] += (v[0] + v[1]) + (v[2] + v[3]);
+      *reinterpret_cast<f32x4*>(Db + d_dst[i]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NX4; ++i) {
+      f32x4 v = rx[i];
+      if (PRO == 1) {
+        const float pa = x_ga[i] * rrstd[i], pb = x_be[i] - rmean[i] * pa;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = adp_silu_fast(fmaf(v[j], pa, pb));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = x_ok[i] ? v[j] : 0.0f;
+      *reinterpret_cast<f32x4*>(Xb + x_dst[i]) = v;
+    }
+    __syncthreads();
+    // ---- prefetch the next chunk
+    p0 += BKN;
+    if (p0 >= N) {
+      p0 = 0;
+      ++b;
+    }
+    if (c + 1 < cend) WG_LOAD();
+    // ---- matrix cores over this wave's share of the chunk's positions
+#pragma unroll
+    for (int s = 0; s < PPW / 8; ++s) {
+      const int base = kg * PPW + 8 * s + 4 * hi;
+      const f32x4 dq = *reinterpret_cast<const f32x4*>(Db + (wm0 + l31) * DS + base);
+      float xq[12];
+      const float* xp = Xb + (wr0 + l31) * XS + base;
+      if (KT == 3) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xp + 4 * q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xq[4 * q + j] = v[j];
+        }
+      } else {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xq[4 + j] = v[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < KT; ++t) acc[t] = adp_mfma32(dq[j], xq[j + 4 - PAD + t], acc[t]);
+    }
+  }
+#undef WG_LOAD
+  __syncthreads();
+
+  // ---- fixed-order sum of the K groups through LDS, one group per round
+  if (NKG > 1) {
+    for (int g = 1; g < NKG; ++g) {
+      if (kg == g) {
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) smem[((quad * KT + t) * 16 + r) * 64 + lane] = acc[t][r];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] += smem[((quad * KT + t) * 16 + r) * 64 + lane];
+      }
+      __syncthreads();
+    }
+  }
+
+  const bool direct = (nsplit == 1);
+  const int64_t cnt = (int64_t)M * R * KT;
+  if (kg == 0) {
+    float* base = direct ? d.dw : d.ws + (int64_t)split * cnt;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi, rr = r0 + wr0 + l31;
+        float* o = base + ((int64_t)m * R + rr) * KT + t;
+        *o = (direct && d.accumulate) ? *o + acc[t][r] : acc[t][r];
+      }
+  }
+  if (do_bias) {
+    // a dy row is staged by DQ = 16 consecutive lanes of one slot: sum them in a fixed order
+    float* bb = direct ? d.dbias : d.ws + (int64_t)nsplit * cnt + (int64_t)split * M;
+#pragma unroll
+    for (int i = 0; i < ND4; ++i) {
+      float s = bsum[i];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 8, 64);
+      const int e = tid + i * NT;
+      if (e < BM * DQ && (e % DQ) == 0) {
+        const int m = m0 + e / DQ;
+        bb[m] = (direct && d.accumulate) ? bb[m] + s : s;
+      }
+    }
+  }
+}
+
+struct WgPlan {
+  int bm, nkg;          // tile edge (BM = BR) and in-block K groups
+  int64_t cpb, cps, nsplit;
+};
+
+WgPlan wg_plan(const adp_wgrad_desc& d) {
+  WgPlan p;
+  p.bm = (d.M % 64 == 0 && d.R % 64 == 0) ? 64 : 32;
+  p.nkg = 4;
+  const int64_t tiles = (d.M / p.bm) * (d.R / p.bm);
+  p.cpb = adp_cdiv(d.N, WG_BKN);
+  const int64_t total = d.B * p.cpb;
+  // 16-wave workgroups (64x64): one per CU fills the SIMDs; 4-wave workgroups (32x32): four per CU
+  const int64_t target = (p.bm == 64) ? 256 : 1024;
+  int64_t ns = adp_cdiv(target, tiles);
+  if (ns > total) ns = total;
+  if (ns < 1) ns = 1;
+  p.cps = adp_cdiv(total, ns);
+  p.nsplit = adp_cdiv(total, p.cps);
+  return p;
+}
+
+__global__ __launch_bounds__(256) void wgrad_mm_reduce_kernel(const float* ws, int64_t nsplit, int64_t cnt, int64_t M,
+                                                              float* dw, float* dbias, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < cnt) {
+    float s = 0.0f;
+    for (int64_t k = 0; k < nsplit; ++k) s += ws[k * cnt + i];
+    dw[i] = accumulate ? dw[i] + s : s;
+  } else if (dbias && i < cnt + M) {
+    const int64_t m = i - cnt;
+    const float* wsb = ws + nsplit * cnt;
+    float s = 0.0f;
+    for (int64_t k = 0; k < nsplit; ++k) s += wsb[k * M + m];
+    dbias[m] = accumulate ? dbias[m] + s : s;
+  }
+}
+
+template <int BM, int KT, int PRO>
+int launch_wg(const adp_wgrad_desc& d, const WgPlan& p, void* stream) {
+  dim3 grid((unsigned)p.nsplit, (unsigned)(d.M / BM), (unsigned)(d.R / BM));
+  ADP_LAUNCH((wgrad_mm_kernel<BM, BM, 4, KT, PRO>), grid, dim3((BM / 32) * (BM / 32) * 4 * 64), stream, d, (int)p.cpb,
+             (int)p.cps, (int)p.nsplit);
+  if (p.nsplit > 1) {
+    const int64_t cnt = d.M * d.R * KT, tot = cnt + (d.dbias ? d.M : 0);
+    ADP_LAUNCH(wgrad_mm_reduce_kernel, dim3((unsigned)adp_cdiv(tot, 256)), dim3(256), stream, (const float*)d.ws,
+               p.nsplit, cnt, d.M, d.dw, d.dbias, (int)d.accumulate);
+  }
+  return ADP_LAUNCH_OK();
+}
+
+template <int KT, int PRO>
+int pick_wg(const adp_wgrad_desc& d, void* stream) {
+  const WgPlan p = wg_plan(d);
+  if (p.bm == 64) return launch_wg<64, KT, PRO>(d, p, stream);
+  return launch_wg<32, KT, PRO>(d, p, stream);
+}
+
+}  // namespace
+
+bool adp_wgrad_mm_eligible(const adp_wgrad_desc& d) {
+  if (d.stride != 1 || d.up != 1 || d.R1 != d.R || d.dil != 1) return false;
+  if (!((d.KT == 3 && d.pad == 1) || (d.KT == 1 && d.pad == 0))) return false;
+  if (d.prologue != 0 && d.prologue != 1) return false;
+  if (d.R % 32 != 0 || d.M % 32 != 0 || d.Lin % 4 != 0 || d.N % 4 != 0 || d.N != d.Lin) return false;
+  if ((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.dy)) & 15) return false;
+  if (d.M * d.N >= (int64_t)1 << 31 || d.R * d.Lin >= (int64_t)1 << 31 || d.B * adp_cdiv(d.N, WG_BKN) >= (int64_t)1 << 31)
+    return false;
+  if (d.M / 32 > 65535 || d.R / 32 > 65535) return false;
+  return true;
+}
+
+int64_t adp_wgrad_mm_ws_floats(const adp_wgrad_desc& d) {
+  const WgPlan p = wg_plan(d);
+  return p.nsplit * (d.M * d.R * d.KT + d.M);
+}
+
+int adp_wgrad_mm(const adp_wgrad_desc& d, void* stream) {
+  if (d.KT == 3) return d.prologue == 1 ? pick_wg<3, 1>(d, stream) : pick_wg<3, 0>(d, stream);
+  return d.prologue == 1 ? pick_wg<1, 1>(d, stream) : pick_wg<1, 0>(d, stream);
+}
