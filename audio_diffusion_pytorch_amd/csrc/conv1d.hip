@@ -726,22 +726,6 @@ __global__ __launch_bounds__(256) void wgrad_s1_kernel(adp_wgrad_desc d, int64_t
   }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int64_t nsplit, int64_t cnt, int64_t M,
-                                                           float* dw, float* dbias, int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < cnt) {
-    float s = 0.0f;
-    for (int64_t k = 0; k < nsplit; ++k) s += ws[k * cnt + i];
-    dw[i] = accumulate ? dw[i] + s : s;
-  } else if (dbias && i < cnt + M) {
-    const int64_t m = i - cnt;
-    const float* wsb = ws + nsplit * cnt;
-    float s = 0.0f;
-    for (int64_t k = 0; k < nsplit; ++k) s += wsb[k * M + m];
-    dbias[m] = accumulate ? dbias[m] + s : s;
-  }
-}
-
 template <int BM, int BN, int WM, int WN, int KT, int S>
 int launch_conv(const adp_conv_desc& d, void* stream) {
   dim3 grid((unsigned)adp_cdiv(d.N, BN), (unsigned)adp_cdiv(d.M, BM), (unsigned)d.B);
@@ -828,10 +812,7 @@ int launch_wgrad_s1(const adp_wgrad_desc& d, void* stream) {
   dim3 grid((unsigned)nsplit, (unsigned)adp_cdiv(d.M, 64), (unsigned)adp_cdiv(d.R, 64));
   ADP_LAUNCH((wgrad_s1_kernel<KT>), grid, dim3(256), stream, d, CPS, CPB, nsplit);
   if (nsplit > 1) {
-    const int64_t cnt = d.M * d.R * KT;
-    const int64_t tot = cnt + (d.dbias ? d.M : 0);
-    ADP_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)adp_cdiv(tot, 256)), dim3(256), stream, (const float*)d.ws,
-               nsplit, cnt, d.M, d.dw, d.dbias, (int)d.accumulate);
+    return adp_wgrad_reduce(d.ws, nsplit, d.M * d.R * KT, d.M, d.dw, d.dbias, (int)d.accumulate, stream);
   }
   return ADP_LAUNCH_OK();
 }
@@ -846,11 +827,7 @@ int launch_wgrad(const adp_wgrad_desc& d, void* stream) {
   const int64_t nsplit = d.B * SPB;
   dim3 grid((unsigned)nsplit, (unsigned)adp_cdiv(d.M, 32), (unsigned)adp_cdiv(d.R, 32));
   ADP_LAUNCH((wgrad_kernel<KT, S>), grid, dim3(256), stream, d, PS, SPB);
-  const int64_t cnt = d.M * d.R * KT;
-  const int64_t tot = cnt + (d.dbias ? d.M : 0);
-  ADP_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)adp_cdiv(tot, 256)), dim3(256), stream, (const float*)d.ws, nsplit,
-             cnt, d.M, d.dw, d.dbias, (int)d.accumulate);
-  return ADP_LAUNCH_OK();
+  return adp_wgrad_reduce(d.ws, nsplit, d.M * d.R * KT, d.M, d.dw, d.dbias, (int)d.accumulate, stream);
 }
 
 bool ks_supported(int64_t KT, int64_t S) {

@@ -11,3 +11,5 @@ int64_t adp_conv_mm_tile(const adp_conv_desc& d);  // NKG * 1000000 + BM * 1000 
 bool adp_wgrad_mm_eligible(const adp_wgrad_desc& d);
 int64_t adp_wgrad_mm_ws_floats(const adp_wgrad_desc& d);
 int adp_wgrad_mm(const adp_wgrad_desc& d, void* stream);
+int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, float* dw, float* dbias, int accumulate,
+                     void* stream);

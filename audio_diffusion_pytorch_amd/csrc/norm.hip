@@ -139,87 +139,187 @@ __global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* ab, int
   dbeta[c] = accumulate ? dbeta[c] + bs : bs;
 }
 
-// ---- LayerNorm over channels (per position): tile = 64 positions x all channels, 4 waves stride channels ---
-// mode 0: y = xhat * (1 + ss[b*bstride + c]) + ss[b*bstride + C + c]      (Modulation)
-// y == NULL: statistics only.
-__global__ __launch_bounds__(256) void chan_ln_fwd_kernel(const float* x, const float* ss, int64_t bstride, int64_t C,
-                                                          int64_t L, float eps, float* y, float* stats) {
-  __shared__ float red[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t l = (int64_t)blockIdx.x * 64 + lane, b = blockIdx.y;
+// ---- LayerNorm over channels (per position) ------------------------------------------------------------------
+// One workgroup owns TL consecutive positions x ALL channels and keeps its [C x TL] slab in registers, so x (and
+// dy) are read from HBM exactly once.  Lanes run along L first (TL = 16/32/64 positions = 64/128/256-byte row
+// segments), the remaining lane bits and the waves stride the channels (CG = NT/TL channel groups, each thread
+// holds channels cg, cg+CG, ...).  Deep layers have few positions (depth 8 at batch 4: 512) but 1024 channels:
+// they take TL = 16 with 1024-thread workgroups, so even 32 workgroups keep 512 waves of loads in flight.
+// mode: y = xhat * (1 + ss[b*bstride + c]) + ss[b*bstride + C + c]      (Modulation); y == NULL: statistics only.
+template <int TL, int NT, int VPT>
+__global__ __launch_bounds__(NT) void chan_ln_fwd_kernel(const float* x, const float* ss, int64_t bstride, int C, int L,
+                                                         float eps, float* y, float* stats) {
+  constexpr int CG = NT / TL, NW = NT / 64, GPW = 64 / TL;  // channel groups, waves, channel groups per wave
+  __shared__ float red[NW][TL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane % TL, cg = wave * GPW + lane / TL;
+  const int l = blockIdx.x * TL + p, b = blockIdx.y;
   const bool valid = l < L;
-  const float* xb = x + b * C * L;
+  const float* xb = x + (int64_t)b * C * L + l;
+  float v[VPT];
   float s = 0.0f;
-  for (int64_t c = wave; c < C; c += 4) s += valid ? xb[c * L + l] : 0.0f;
-  red[wave][lane] = s;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = cg + i * CG;
+    v[i] = (valid && c < C) ? xb[(int64_t)c * L] : 0.0f;
+    s += v[i];
+  }
+#pragma unroll
+  for (int o = TL; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+  if (lane < TL) red[wave][p] = s;
   __syncthreads();
-  const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+  float tot = 0.0f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) tot += red[w][p];
+  const float mean = tot / (float)C;
   __syncthreads();
   float q = 0.0f;
-  for (int64_t c = wave; c < C; c += 4) {
-    const float dlt = valid ? xb[c * L + l] - mean : 0.0f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = cg + i * CG;
+    const float dlt = (c < C) ? v[i] - mean : 0.0f;
     q = fmaf(dlt, dlt, q);
   }
-  red[wave][lane] = q;
+#pragma unroll
+  for (int o = TL; o < 64; o <<= 1) q += __shfl_xor(q, o, 64);
+  if (lane < TL) red[wave][p] = q;
   __syncthreads();
-  const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
-  const float rstd = 1.0f / sqrtf(var + eps);
-  if (wave == 0 && valid) {
-    stats[(b * L + l) * 2] = mean;
-    stats[(b * L + l) * 2 + 1] = rstd;
+  tot = 0.0f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) tot += red[w][p];
+  const float rstd = 1.0f / sqrtf(tot / (float)C + eps);
+  if (tid < TL && valid) {
+    stats[((int64_t)b * L + l) * 2] = mean;
+    stats[((int64_t)b * L + l) * 2 + 1] = rstd;
   }
   if (y == nullptr) return;
-  float* yb = y + b * C * L;
+  float* yb = y + (int64_t)b * C * L + l;
   const float* sb = ss + b * bstride;
-  for (int64_t c = wave; c < C; c += 4) {
-    const float sc = 1.0f + sb[c], sft = sb[C + c];
-    if (valid) yb[c * L + l] = fmaf((xb[c * L + l] - mean) * rstd, sc, sft);
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = cg + i * CG;
+    if (valid && c < C) yb[(int64_t)c * L] = fmaf((v[i] - mean) * rstd, 1.0f + sb[c], sb[C + c]);
   }
 }
 
 // Backward of y = xhat * mul_c + add_c with mul_c = 1 + ss[b*bstride + c] (gamma == NULL) or gamma[c].
 // dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)), g = dy * mul_c   (+ dres)
 // partial per-channel sums over the tile: ws[b][0][c][tile] = sum dy*xhat, ws[b][1][c][tile] = sum dy
-__global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const float* x, const float* dy, const float* ss,
-                                                          int64_t bstride, const float* gamma, const float* stats,
-                                                          const float* dres, int64_t C, int64_t L, int64_t NT,
-                                                          float* dx, float* ws) {
-  __shared__ float red[2][4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t tile = blockIdx.x, l = tile * 64 + lane, b = blockIdx.y;
+template <int TL, int NT, int VPT>
+__global__ __launch_bounds__(NT) void chan_ln_bwd_kernel(const float* x, const float* dy, const float* ss,
+                                                         int64_t bstride, const float* gamma, const float* stats,
+                                                         const float* dres, int C, int L, int NTL, float* dx,
+                                                         float* ws) {
+  constexpr int CG = NT / TL, NW = NT / 64, GPW = 64 / TL;
+  __shared__ float red[2][NW][TL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane % TL, cg = wave * GPW + lane / TL;
+  const int tile = blockIdx.x, l = tile * TL + p, b = blockIdx.y;
   const bool valid = l < L;
-  const float* xb = x + b * C * L;
-  const float* db = dy + b * C * L;
-  const float mean = valid ? stats[(b * L + l) * 2] : 0.0f;
-  const float rstd = valid ? stats[(b * L + l) * 2 + 1] : 0.0f;
+  const int64_t boff = (int64_t)b * C * L + l;
+  const float mean = valid ? stats[((int64_t)b * L + l) * 2] : 0.0f;
+  const float rstd = valid ? stats[((int64_t)b * L + l) * 2 + 1] : 0.0f;
+  float xh[VPT], g[VPT];
   float s1 = 0.0f, s2 = 0.0f;
-  for (int64_t c = wave; c < C; c += 4) {
-    const float mul = gamma ? gamma[c] : 1.0f + ss[b * bstride + c];
-    const float d = valid ? db[c * L + l] : 0.0f;
-    const float xh = valid ? (xb[c * L + l] - mean) * rstd : 0.0f;
-    const float g = d * mul;
-    s1 += g;
-    s2 = fmaf(g, xh, s2);
-    const float pa = adp_wave_sum(d * xh), pb = adp_wave_sum(d);
-    if (lane == 0) {
-      ws[((b * 2 + 0) * C + c) * NT + tile] = pa;
-      ws[((b * 2 + 1) * C + c) * NT + tile] = pb;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = cg + i * CG;
+    const bool ok = valid && c < C;
+    const float mul = (c < C) ? (gamma ? gamma[c] : 1.0f + ss[b * bstride + c]) : 0.0f;
+    const float d = ok ? dy[boff + (int64_t)c * L] : 0.0f;
+    xh[i] = ok ? (x[boff + (int64_t)c * L] - mean) * rstd : 0.0f;
+    g[i] = d * mul;
+    s1 += g[i];
+    s2 = fmaf(g[i], xh[i], s2);
+    // per-channel sums over the tile's positions (lanes p = 0..TL-1 of this channel group)
+    float pa = d * xh[i], pb = d;
+#pragma unroll
+    for (int o = 1; o < TL; o <<= 1) {
+      pa += __shfl_xor(pa, o, 64);
+      pb += __shfl_xor(pb, o, 64);
+    }
+    if (p == 0 && c < C) {
+      ws[(((int64_t)b * 2 + 0) * C + c) * NTL + tile] = pa;
+      ws[(((int64_t)b * 2 + 1) * C + c) * NTL + tile] = pb;
     }
   }
-  red[0][wave][lane] = s1;
-  red[1][wave][lane] = s2;
-  __syncthreads();
-  const float m1 = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / (float)C;
-  const float m2 = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / (float)C;
-  float* ob = dx + b * C * L;
-  for (int64_t c = wave; c < C; c += 4) {
-    if (!valid) continue;
-    const float mul = gamma ? gamma[c] : 1.0f + ss[b * bstride + c];
-    const float xh = (xb[c * L + l] - mean) * rstd;
-    float v = rstd * (db[c * L + l] * mul - m1 - xh * m2);
-    if (dres) v += dres[(b * C + c) * L + l];
-    ob[c * L + l] = v;
+#pragma unroll
+  for (int o = TL; o < 64; o <<= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
   }
+  if (lane < TL) {
+    red[0][wave][p] = s1;
+    red[1][wave][p] = s2;
+  }
+  __syncthreads();
+  float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    m1 += red[0][w][p];
+    m2 += red[1][w][p];
+  }
+  m1 /= (float)C;
+  m2 /= (float)C;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = cg + i * CG;
+    if (valid && c < C) {
+      float v = rstd * (g[i] - m1 - xh[i] * m2);
+      if (dres) v += dres[boff + (int64_t)c * L];
+      dx[boff + (int64_t)c * L] = v;
+    }
+  }
+}
+
+// tile shape by channel count (registers: VPT = ceil(C / CG) values per thread) and by how many tiles there are
+struct LnCfg {
+  int tl, nt;
+};
+LnCfg ln_cfg(int64_t C) {
+  if (C <= 64) return {64, 256};     // CG 4,  VPT 16
+  if (C <= 128) return {32, 256};    // CG 8,  VPT 16
+  if (C <= 256) return {32, 1024};   // CG 32, VPT 8
+  return {16, 1024};                 // CG 64, VPT 16 (C <= 1024)
+}
+constexpr int64_t LN_CMAX = 1024;
+
+int launch_ln_fwd(const float* x, const float* ss, int64_t bstride, int64_t B, int64_t C, int64_t L, float eps, float* y,
+                  float* stats, void* stream) {
+  const LnCfg k = ln_cfg(C);
+  dim3 grid((unsigned)adp_cdiv(L, k.tl), (unsigned)B);
+  if (k.tl == 64)
+    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 16>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats);
+  else if (k.tl == 32 && k.nt == 256)
+    ADP_LAUNCH((chan_ln_fwd_kernel<32, 256, 16>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats);
+  else if (k.tl == 32)
+    ADP_LAUNCH((chan_ln_fwd_kernel<32, 1024, 8>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y,
+               stats);
+  else
+    ADP_LAUNCH((chan_ln_fwd_kernel<16, 1024, 16>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y,
+               stats);
+  return ADP_LAUNCH_OK();
+}
+
+int launch_ln_bwd(const float* x, const float* dy, const float* ss, int64_t bstride, const float* gamma,
+                  const float* stats, const float* dres, int64_t B, int64_t C, int64_t L, float* dx, float* ws,
+                  void* stream) {
+  const LnCfg k = ln_cfg(C);
+  const int NTL = (int)adp_cdiv(L, k.tl);
+  dim3 grid((unsigned)NTL, (unsigned)B);
+  if (k.tl == 64)
+    ADP_LAUNCH((chan_ln_bwd_kernel<64, 256, 16>), grid, dim3(256), stream, x, dy, ss, bstride, gamma, stats, dres,
+               (int)C, (int)L, NTL, dx, ws);
+  else if (k.tl == 32 && k.nt == 256)
+    ADP_LAUNCH((chan_ln_bwd_kernel<32, 256, 16>), grid, dim3(256), stream, x, dy, ss, bstride, gamma, stats, dres,
+               (int)C, (int)L, NTL, dx, ws);
+  else if (k.tl == 32)
+    ADP_LAUNCH((chan_ln_bwd_kernel<32, 1024, 8>), grid, dim3(1024), stream, x, dy, ss, bstride, gamma, stats, dres,
+               (int)C, (int)L, NTL, dx, ws);
+  else
+    ADP_LAUNCH((chan_ln_bwd_kernel<16, 1024, 16>), grid, dim3(1024), stream, x, dy, ss, bstride, gamma, stats, dres,
+               (int)C, (int)L, NTL, dx, ws);
+  return ADP_LAUNCH_OK();
 }
 
 // out[b*bstride + j] (or out[j] summed over b) = sum_t ws[(b*W + j)*NT + t]; one wave per row
@@ -327,33 +427,31 @@ extern "C" int adp_gn_param_grad(const float* ab, int64_t B, int64_t C, int64_t 
 extern "C" int adp_modulation_fwd(const float* x, const float* ss, int64_t ss_bstride, int64_t B, int64_t C,
                                   int64_t L, float eps, float* y, float* stats, void* stream) {
   if (!x || !ss || !y || !stats) return ADP_ERR_NULL;
-  if (B <= 0 || C <= 0 || L <= 0 || B > 65535) return ADP_ERR_SHAPE;
-  ADP_LAUNCH(chan_ln_fwd_kernel, dim3((unsigned)adp_cdiv(L, 64), (unsigned)B), dim3(256), stream, x, ss, ss_bstride,
-             C, L, eps, y, stats);
-  return ADP_LAUNCH_OK();
+  if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
+  if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
+  return launch_ln_fwd(x, ss, ss_bstride, B, C, L, eps, y, stats, stream);
 }
 
 extern "C" int adp_ln_stats(const float* x, int64_t B, int64_t C, int64_t L, float eps, float* stats, void* stream) {
   if (!x || !stats) return ADP_ERR_NULL;
-  if (B <= 0 || C <= 0 || L <= 0 || B > 65535) return ADP_ERR_SHAPE;
-  ADP_LAUNCH(chan_ln_fwd_kernel, dim3((unsigned)adp_cdiv(L, 64), (unsigned)B), dim3(256), stream, x,
-             (const float*)nullptr, (int64_t)0, C, L, eps, (float*)nullptr, stats);
-  return ADP_LAUNCH_OK();
+  if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
+  if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
+  return launch_ln_fwd(x, (const float*)nullptr, (int64_t)0, B, C, L, eps, (float*)nullptr, stats, stream);
 }
 
 extern "C" int64_t adp_chan_ln_bwd_ws_bytes(int64_t B, int64_t C, int64_t L) {
   if (B <= 0 || C <= 0 || L <= 0) return ADP_ERR_SHAPE;
-  return B * 2 * C * adp_cdiv(L, 64) * (int64_t)sizeof(float);
+  return B * 2 * C * adp_cdiv(L, ln_cfg(C).tl) * (int64_t)sizeof(float);
 }
 
 extern "C" int adp_modulation_bwd(const float* x, const float* dy, const float* ss, int64_t ss_bstride,
                                   const float* stats, int64_t B, int64_t C, int64_t L, float* dx, float* dss,
                                   int64_t dss_bstride, float* ws, void* stream) {
   if (!x || !dy || !ss || !stats || !dx || !dss || !ws) return ADP_ERR_NULL;
-  if (B <= 0 || C <= 0 || L <= 0 || B > 65535) return ADP_ERR_SHAPE;
-  const int64_t NT = adp_cdiv(L, 64);
-  ADP_LAUNCH(chan_ln_bwd_kernel, dim3((unsigned)NT, (unsigned)B), dim3(256), stream, x, dy, ss, ss_bstride,
-             (const float*)nullptr, stats, (const float*)nullptr, C, L, NT, dx, ws);
+  if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
+  if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
+  const int64_t NT = adp_cdiv(L, ln_cfg(C).tl);
+  launch_ln_bwd(x, dy, ss, ss_bstride, (const float*)nullptr, stats, (const float*)nullptr, B, C, L, dx, ws, stream);
   ADP_LAUNCH(reduce_rows_kernel, dim3((unsigned)adp_cdiv(B * 2 * C, 4)), dim3(256), stream, (const float*)ws, B,
              2 * C, NT, dss_bstride, 0, 0, dss);
   return ADP_LAUNCH_OK();
@@ -363,10 +461,10 @@ extern "C" int adp_ln_bwd(const float* x, const float* dxn, const float* stats, 
                           int64_t B, int64_t C, int64_t L, int64_t accumulate, float* dx, float* dgamma_dbeta,
                           float* ws, void* stream) {
   if (!x || !dxn || !stats || !gamma || !dx || !dgamma_dbeta || !ws) return ADP_ERR_NULL;
-  if (B <= 0 || C <= 0 || L <= 0 || B > 65535) return ADP_ERR_SHAPE;
-  const int64_t NT = adp_cdiv(L, 64);
-  ADP_LAUNCH(chan_ln_bwd_kernel, dim3((unsigned)NT, (unsigned)B), dim3(256), stream, x, dxn, (const float*)nullptr,
-             (int64_t)0, gamma, stats, dres, C, L, NT, dx, ws);
+  if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
+  if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
+  const int64_t NT = adp_cdiv(L, ln_cfg(C).tl);
+  launch_ln_bwd(x, dxn, (const float*)nullptr, (int64_t)0, gamma, stats, dres, B, C, L, dx, ws, stream);
   // dgamma_dbeta = [dgamma (C) | dbeta (C)]
   ADP_LAUNCH(reduce_rows_kernel, dim3((unsigned)adp_cdiv(2 * C, 4)), dim3(256), stream, (const float*)ws, B, 2 * C,
              NT, (int64_t)0, 1, (int)accumulate, dgamma_dbeta);

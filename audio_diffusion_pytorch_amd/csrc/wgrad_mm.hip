@@ -244,6 +244,7 @@ WgPlan wg_plan(const adp_wgrad_desc& d) {
   // 16-wave workgroups (64x64): one per CU fills the SIMDs; 4-wave workgroups (32x32): four per CU
   const int64_t target = (p.bm == 64) ? 256 : 1024;
   int64_t ns = adp_cdiv(target, tiles);
+  if (ns > total / 8) ns = total / 8;  // a workgroup should amortise its start-up over >= 8 chunks
   if (ns > total) ns = total;
   if (ns < 1) ns = 1;
   p.cps = adp_cdiv(total, ns);
@@ -251,21 +252,45 @@ WgPlan wg_plan(const adp_wgrad_desc& d) {
   return p;
 }
 
-__global__ __launch_bounds__(256) void wgrad_mm_reduce_kernel(const float* ws, int64_t nsplit, int64_t cnt, int64_t M,
-                                                              float* dw, float* dbias, int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+}  // namespace
+
+// Second stage of every split weight gradient: out[i] = sum_k ws[k][i] (dw: i < cnt, dbias: cnt <= i < cnt + M, its
+// partials start at ws + nsplit*cnt).  64 outputs x 16 split lanes per workgroup: rows of 256 contiguous bytes,
+// 16 independent accumulation chains per output instead of one serial walk over all splits; the 16 lane sums are
+// combined in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void adp_wgrad_reduce_kernel(const float* ws, int64_t nsplit, int64_t cnt, int64_t M,
+                                                                float* dw, float* dbias, int accumulate) {
+  __shared__ float part[16][64];
+  const int il = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + il;
+  const int64_t tot = cnt + (dbias ? M : 0);
+  float s = 0.0f;
   if (i < cnt) {
-    float s = 0.0f;
-    for (int64_t k = 0; k < nsplit; ++k) s += ws[k * cnt + i];
-    dw[i] = accumulate ? dw[i] + s : s;
-  } else if (dbias && i < cnt + M) {
-    const int64_t m = i - cnt;
-    const float* wsb = ws + nsplit * cnt;
-    float s = 0.0f;
-    for (int64_t k = 0; k < nsplit; ++k) s += wsb[k * M + m];
-    dbias[m] = accumulate ? dbias[m] + s : s;
+    for (int64_t k = ks; k < nsplit; k += 16) s += ws[k * cnt + i];
+  } else if (i < tot) {
+    const float* wsb = ws + nsplit * cnt + (i - cnt);
+    for (int64_t k = ks; k < nsplit; k += 16) s += wsb[k * M];
+  }
+  part[ks][il] = s;
+  __syncthreads();
+  if (ks == 0 && i < tot) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][il];
+    float* o = (i < cnt) ? dw + i : dbias + (i - cnt);
+    *o = accumulate ? *o + t : t;
   }
 }
+
+int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, float* dw, float* dbias, int accumulate,
+                     void* stream) {
+  const int64_t tot = cnt + (dbias ? M : 0);
+  ADP_LAUNCH(adp_wgrad_reduce_kernel, dim3((unsigned)adp_cdiv(tot, 64)), dim3(1024), stream, ws, nsplit, cnt, M, dw,
+             dbias, accumulate);
+  return ADP_LAUNCH_OK();
+}
+
+namespace {
 
 template <int BM, int KT, int PRO>
 int launch_wg(const adp_wgrad_desc& d, const WgPlan& p, void* stream) {
@@ -273,9 +298,7 @@ int launch_wg(const adp_wgrad_desc& d, const WgPlan& p, void* stream) {
   ADP_LAUNCH((wgrad_mm_kernel<BM, BM, 4, KT, PRO>), grid, dim3((BM / 32) * (BM / 32) * 4 * 64), stream, d, (int)p.cpb,
              (int)p.cps, (int)p.nsplit);
   if (p.nsplit > 1) {
-    const int64_t cnt = d.M * d.R * KT, tot = cnt + (d.dbias ? d.M : 0);
-    ADP_LAUNCH(wgrad_mm_reduce_kernel, dim3((unsigned)adp_cdiv(tot, 256)), dim3(256), stream, (const float*)d.ws,
-               p.nsplit, cnt, d.M, d.dw, d.dbias, (int)d.accumulate);
+    return adp_wgrad_reduce(d.ws, p.nsplit, d.M * d.R * KT, d.M, d.dw, d.dbias, (int)d.accumulate, stream);
   }
   return ADP_LAUNCH_OK();
 }
