@@ -17,6 +17,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // exact-f32 matrix core ops (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32)
 __device__ __forceinline__ f32x16 adp_mfma32(float a, float b, f32x16 c) {

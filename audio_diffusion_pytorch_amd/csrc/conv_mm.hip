@@ -27,23 +27,47 @@
 
 namespace {
 
-constexpr int MM_BKT = 32;        // channels per staged chunk
+constexpr int MM_BKT = 32;        // channels per staged chunk (16 for the stride-4 variant); R must divide by it
 constexpr int MM_PRO_RMAX = 1024; // channels whose GroupNorm constants fit the LDS table
+
+// four consecutive virtual positions u0..u0+3 (u0 % 4 == 0) of a row upsampled by UP: 4 / 2 / 1 source floats
+template <int UP>
+__device__ __forceinline__ f32x4 load_xquad(const float* p) {
+  f32x4 v;
+  if (UP == 1) {
+    v = *reinterpret_cast<const f32x4*>(p);
+  } else if (UP == 2) {
+    const f32x2 t = *reinterpret_cast<const f32x2*>(p);
+    v[0] = t[0];
+    v[1] = t[0];
+    v[2] = t[1];
+    v[3] = t[1];
+  } else {
+    const float t = *p;
+    v[0] = t;
+    v[1] = t;
+    v[2] = t;
+    v[3] = t;
+  }
+  return v;
+}
 
 template <int A, int B>
 struct cmax {
   static constexpr int v = A > B ? A : B;
 };
 
-template <int BM, int BN, int NKG, int KT, bool TR, int PRO>
+// S: conv stride (1, or kernel = stride = 2 / 4 for DownsampleItem); UP: nearest-upsample factor folded into the X
+// loader (UpsampleItem: the [B, C, L*UP] intermediate is never materialised); BKT: channels per staged chunk.
+template <int BM, int BN, int NKG, int KT, int S, int UP, bool TR, int PRO, int BKT>
 __global__ __launch_bounds__((BM / 32) * (BN / 32) * NKG * 64) void conv_mm_kernel(adp_conv_desc d) {
-  constexpr int BKT = MM_BKT, CPW = BKT / NKG;
+  constexpr int CPW = BKT / NKG;
   constexpr int NQN = BN / 32, NQ = (BM / 32) * NQN, NW = NQ * NKG, NT = NW * 64;
   constexpr int QK = BKT * KT;
   constexpr int AS = TR ? (BM * KT + 4) : (QK + 4);  // A row stride in floats
   constexpr int AROWS = TR ? BKT : BM;
   constexpr int AQ = (TR ? BM * KT : QK) / 4;        // float4 per A row
-  constexpr int XSP = BN + 8, XQ = XSP / 4;          // X row: positions n0-4 .. n0+BN+3
+  constexpr int XSP = BN * S + 8, XQ = XSP / 4;      // X row: (virtual) positions n0*S-4 .. n0*S+BN*S+3
   constexpr int A_ELEMS = AROWS * AS, X_ELEMS = BKT * XSP;
   constexpr int NA4 = (AROWS * AQ + NT - 1) / NT, NX4 = (BKT * XQ + NT - 1) / NT;
   constexpr int RED = (NKG - 1) * NQ * 1024;
@@ -59,6 +83,7 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * NKG * 64) void conv_mm_kern
 
   const int M = (int)d.M, R = (int)d.R, L = (int)d.Lin, N = (int)d.N;
   const int dil = (int)d.dil, pad = (int)d.pad;
+  const int Lv = L * UP;  // length of the (virtual) upsampled row
 
   // ---- XCD-aware decode of the 1-D grid
   int id = blockIdx.x;
@@ -99,10 +124,10 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * NKG * 64) void conv_mm_kern
   for (int i = 0; i < NX4; ++i) {
     const int e = (tid + i * NT) % (BKT * XQ);
     const int rl = e / XQ, pq = e - rl * XQ;
-    const int u = n0 - 4 + 4 * pq;
+    const int u = n0 * S - 4 + 4 * pq;
     x_dst[i] = rl * XSP + 4 * pq;
-    x_ok[i] = (u >= 0 && u < L);  // L % 4 == 0: a quad is entirely inside or outside the row
-    x_src[i] = rl * L + (x_ok[i] ? u : 0);
+    x_ok[i] = (u >= 0 && u < Lv);  // Lv % 4 == 0: a quad is entirely inside or outside the row
+    x_src[i] = rl * L + (x_ok[i] ? u / UP : 0);  // nearest upsample: source index = floor(u / UP), exact
     x_row[i] = rl;
   }
 
@@ -111,7 +136,7 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * NKG * 64) void conv_mm_kern
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
   // lane-constant fragment offsets
-  const int xfrag = 4 * hi * XSP + wn0 + l31 + 4 - pad;               // + (ci + c) * XSP + t * dil
+  const int xfrag = 4 * hi * XSP + (wn0 + l31) * S + 4 - pad;         // + (ci + c) * XSP + t * dil
   const int afrag = TR ? 4 * hi * AS + (wm0 + l31) * KT                // + (ci + c) * AS + (KT - 1 - t)
                        : (wm0 + l31) * AS + 4 * hi * KT;               // + ci * KT + (c * KT + t)
 
@@ -126,7 +151,7 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * NKG * 64) void conv_mm_kern
 #pragma unroll
     for (int i = 0; i < NA4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(wp + a_src[i]);
 #pragma unroll
-    for (int i = 0; i < NX4; ++i) rx[i] = *reinterpret_cast<const f32x4*>(xb + x_src[i]);
+    for (int i = 0; i < NX4; ++i) rx[i] = load_xquad<UP>(xb + x_src[i]);
   }
   if (PRO == 1) __syncthreads();
 
@@ -158,7 +183,7 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * NKG * 64) void conv_mm_kern
       for (int i = 0; i < NA4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(wp + a_src[i]);
       const float* xp = xb + (int64_t)rn * L;
 #pragma unroll
-      for (int i = 0; i < NX4; ++i) rx[i] = *reinterpret_cast<const f32x4*>(xp + x_src[i]);
+      for (int i = 0; i < NX4; ++i) rx[i] = load_xquad<UP>(xp + x_src[i]);
     }
     // ---- matrix cores over this wave's share of the chunk
 #pragma unroll
@@ -248,44 +273,56 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * NKG * 64) void conv_mm_kern
   }
 }
 
-template <int BM, int BN, int NKG, int KT, bool TR, int PRO>
+template <int BM, int BN, int NKG, int KT, int S, int UP, bool TR, int PRO, int BKT>
 int launch_mm(const adp_conv_desc& d, void* stream) {
   const int64_t blocks = (d.M / BM) * adp_cdiv(d.N, BN) * d.B;
-  ADP_LAUNCH((conv_mm_kernel<BM, BN, NKG, KT, TR, PRO>), dim3((unsigned)blocks), dim3((BM / 32) * (BN / 32) * NKG * 64),
-             stream, d);
+  ADP_LAUNCH((conv_mm_kernel<BM, BN, NKG, KT, S, UP, TR, PRO, BKT>), dim3((unsigned)blocks),
+             dim3((BM / 32) * (BN / 32) * NKG * 64), stream, d);
   return ADP_LAUNCH_OK();
 }
 
 // ~1024 SIMDs want >= 2 waves each; a 64x64 tile carries 4 waves per K group.  Returns NKG*1e6 + BM*1e3 + BN.
+// The stride-4 variant stages 16 channels per chunk (its X rows are 4x wider), which caps NKG at 2.
 int64_t mm_tile(const adp_conv_desc& d) {
   const int64_t tiles64 = (d.M % 64 == 0) ? (d.M / 64) * adp_cdiv(d.N, 64) * d.B : 0;
+  const int64_t kmax = (d.stride == 4) ? 2 : 4;
   if (tiles64 >= 160) {
     if (tiles64 >= 768) return 1064064;
-    if (tiles64 >= 384) return 2064064;
+    if (tiles64 >= 384 || kmax == 2) return 2064064;
     return 4064064;
   }
-  return 4032064;
+  return kmax * 1000000 + 32064;
 }
 
-template <int KT, bool TR, int PRO>
+template <int KT, int S, int UP, bool TR, int PRO, int BKT>
 int pick_mm(const adp_conv_desc& d, void* stream) {
   switch (mm_tile(d)) {
-    case 1064064: return launch_mm<64, 64, 1, KT, TR, PRO>(d, stream);
-    case 2064064: return launch_mm<64, 64, 2, KT, TR, PRO>(d, stream);
-    case 4064064: return launch_mm<64, 64, 4, KT, TR, PRO>(d, stream);
-    default: return launch_mm<32, 64, 4, KT, TR, PRO>(d, stream);
+    case 1064064: return launch_mm<64, 64, 1, KT, S, UP, TR, PRO, BKT>(d, stream);
+    case 2064064: return launch_mm<64, 64, 2, KT, S, UP, TR, PRO, BKT>(d, stream);
+    case 2032064: return launch_mm<32, 64, 2, KT, S, UP, TR, PRO, BKT>(d, stream);
+    default: break;
   }
+  if constexpr (BKT >= 32) {
+    if (mm_tile(d) == 4064064) return launch_mm<64, 64, 4, KT, S, UP, TR, PRO, BKT>(d, stream);
+    return launch_mm<32, 64, 4, KT, S, UP, TR, PRO, BKT>(d, stream);
+  }
+  return ADP_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
 bool adp_conv_mm_eligible(const adp_conv_desc& d) {
-  if (d.stride != 1 || d.up != 1 || d.R1 != d.R || (d.KT != 1 && d.KT != 3)) return false;
+  if (d.R1 != d.R) return false;
+  const bool plain = d.stride == 1 && (d.KT == 1 || d.KT == 3) && d.up == 1;                    // ConvBlock family
+  const bool upc = d.stride == 1 && d.KT == 3 && (d.up == 2 || d.up == 4) && !d.transposed && d.prologue == 0;
+  const bool down = (d.stride == 2 || d.stride == 4) && d.KT == d.stride && d.up == 1 && d.pad == 0 && d.dil == 1 &&
+                    !d.transposed && d.prologue == 0;
+  if (!plain && !upc && !down) return false;
   if (d.prologue != 0 && d.prologue != 1) return false;
   if (d.prologue == 1 && d.R > MM_PRO_RMAX) return false;
-  if (d.R % MM_BKT != 0 || d.M % 32 != 0 || d.Lin % 4 != 0) return false;
+  if (d.R % MM_BKT != 0 || d.M % 32 != 0 || (d.Lin * d.up) % 4 != 0) return false;
   if (d.pad > 4 || (d.KT - 1) * d.dil - d.pad > 4) return false;  // halo of 4 positions on both sides of the X tile
-  if (d.N > d.Lin + 4) return false;
+  if ((d.N - 1) * d.stride + (d.KT - 1) * d.dil - d.pad >= d.Lin * d.up + 4) return false;
   if ((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.w)) & 15) return false;
   if (d.B * d.R * d.Lin >= (int64_t)1 << 31 || d.M * d.R * d.KT >= (int64_t)1 << 31) return false;
   return true;
@@ -295,10 +332,14 @@ int64_t adp_conv_mm_tile(const adp_conv_desc& d) { return mm_tile(d); }
 
 int adp_conv_mm(const adp_conv_desc& d, void* stream) {
   const bool tr = d.transposed != 0;
+  if (d.stride == 2) return pick_mm<2, 2, 1, false, 0, 32>(d, stream);
+  if (d.stride == 4) return pick_mm<4, 4, 1, false, 0, 16>(d, stream);
+  if (d.up == 2) return pick_mm<3, 1, 2, false, 0, 32>(d, stream);
+  if (d.up == 4) return pick_mm<3, 1, 4, false, 0, 32>(d, stream);
   if (d.KT == 3) {
-    if (d.prologue == 1) return tr ? pick_mm<3, true, 1>(d, stream) : pick_mm<3, false, 1>(d, stream);
-    return tr ? pick_mm<3, true, 0>(d, stream) : pick_mm<3, false, 0>(d, stream);
+    if (d.prologue == 1) return tr ? pick_mm<3, 1, 1, true, 1, 32>(d, stream) : pick_mm<3, 1, 1, false, 1, 32>(d, stream);
+    return tr ? pick_mm<3, 1, 1, true, 0, 32>(d, stream) : pick_mm<3, 1, 1, false, 0, 32>(d, stream);
   }
-  if (d.prologue == 1) return tr ? pick_mm<1, true, 1>(d, stream) : pick_mm<1, false, 1>(d, stream);
-  return tr ? pick_mm<1, true, 0>(d, stream) : pick_mm<1, false, 0>(d, stream);
+  if (d.prologue == 1) return tr ? pick_mm<1, 1, 1, true, 1, 32>(d, stream) : pick_mm<1, 1, 1, false, 1, 32>(d, stream);
+  return tr ? pick_mm<1, 1, 1, true, 0, 32>(d, stream) : pick_mm<1, 1, 1, false, 0, 32>(d, stream);
 }

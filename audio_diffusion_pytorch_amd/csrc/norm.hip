@@ -277,7 +277,7 @@ struct LnCfg {
   int tl, nt;
 };
 LnCfg ln_cfg(int64_t C) {
-  if (C <= 64) return {64, 256};     // CG 4,  VPT 16
+  if (C <= 64) return {64, 256};     // CG 4,  VPT 2 / 8 / 16
   if (C <= 128) return {32, 256};    // CG 8,  VPT 16
   if (C <= 256) return {32, 1024};   // CG 32, VPT 8
   return {16, 1024};                 // CG 64, VPT 16 (C <= 1024)
@@ -288,7 +288,11 @@ int launch_ln_fwd(const float* x, const float* ss, int64_t bstride, int64_t B, i
                   float* stats, void* stream) {
   const LnCfg k = ln_cfg(C);
   dim3 grid((unsigned)adp_cdiv(L, k.tl), (unsigned)B);
-  if (k.tl == 64)
+  if (k.tl == 64 && C <= 8)
+    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 2>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats);
+  else if (k.tl == 64 && C <= 32)
+    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 8>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats);
+  else if (k.tl == 64)
     ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 16>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats);
   else if (k.tl == 32 && k.nt == 256)
     ADP_LAUNCH((chan_ln_fwd_kernel<32, 256, 16>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats);
@@ -307,7 +311,13 @@ int launch_ln_bwd(const float* x, const float* dy, const float* ss, int64_t bstr
   const LnCfg k = ln_cfg(C);
   const int NTL = (int)adp_cdiv(L, k.tl);
   dim3 grid((unsigned)NTL, (unsigned)B);
-  if (k.tl == 64)
+  if (k.tl == 64 && C <= 8)
+    ADP_LAUNCH((chan_ln_bwd_kernel<64, 256, 2>), grid, dim3(256), stream, x, dy, ss, bstride, gamma, stats, dres,
+               (int)C, (int)L, NTL, dx, ws);
+  else if (k.tl == 64 && C <= 32)
+    ADP_LAUNCH((chan_ln_bwd_kernel<64, 256, 8>), grid, dim3(256), stream, x, dy, ss, bstride, gamma, stats, dres,
+               (int)C, (int)L, NTL, dx, ws);
+  else if (k.tl == 64)
     ADP_LAUNCH((chan_ln_bwd_kernel<64, 256, 16>), grid, dim3(256), stream, x, dy, ss, bstride, gamma, stats, dres,
                (int)C, (int)L, NTL, dx, ws);
   else if (k.tl == 32 && k.nt == 256)

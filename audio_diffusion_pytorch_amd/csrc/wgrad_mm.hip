@@ -24,14 +24,38 @@ namespace {
 
 constexpr int WG_BKN = 64;  // positions per staged chunk
 
-template <int BM, int BR, int NKG, int KT, int PRO>
+// S: conv stride (1, or kernel = stride = 2 / 4: DownsampleItem, no halo, lane reads 4*S consecutive floats);
+// UP: nearest-upsample factor folded into the x loader (UpsampleItem).
+template <int UP>
+__device__ __forceinline__ f32x4 wg_load_xquad(const float* p) {
+  f32x4 v;
+  if (UP == 1) {
+    v = *reinterpret_cast<const f32x4*>(p);
+  } else if (UP == 2) {
+    const f32x2 t = *reinterpret_cast<const f32x2*>(p);
+    v[0] = t[0];
+    v[1] = t[0];
+    v[2] = t[1];
+    v[3] = t[1];
+  } else {
+    const float t = *p;
+    v[0] = t;
+    v[1] = t;
+    v[2] = t;
+    v[3] = t;
+  }
+  return v;
+}
+
+template <int BM, int BR, int NKG, int KT, int S, int UP, int PRO>
 __global__ __launch_bounds__((BM / 32) * (BR / 32) * NKG * 64) void wgrad_mm_kernel(adp_wgrad_desc d, int CPB, int CPS,
                                                                                   int nsplit) {
   constexpr int BKN = WG_BKN, PPW = BKN / NKG;
   constexpr int NQR = BR / 32, NQ = (BM / 32) * NQR, NW = NQ * NKG, NT = NW * 64;
   constexpr int PAD = (KT - 1) / 2;
-  constexpr int DS = BKN + 4, XS = BKN + 12;  // row strides (floats), both 4 mod 8
-  constexpr int DQ = BKN / 4, XQ = (BKN + 8) / 4;
+  constexpr int HALO = (S == 1) ? 4 : 0;                       // positions staged on each side of the chunk's x rows
+  constexpr int DS = BKN + 4, XS = BKN * S + 2 * HALO + 4;     // row strides (floats), both 4 mod 8
+  constexpr int DQ = BKN / 4, XQ = (BKN * S + 2 * HALO) / 4;
   constexpr int D_ELEMS = BM * DS, X_ELEMS = BR * XS;
   constexpr int ND4 = (BM * DQ + NT - 1) / NT, NX4 = (BR * XQ + NT - 1) / NT;
   constexpr int RED = NQ * KT * 1024;
@@ -46,6 +70,7 @@ __global__ __launch_bounds__((BM / 32) * (BR / 32) * NKG * 64) void wgrad_mm_ker
   const int wm0 = (quad / NQR) * 32, wr0 = (quad % NQR) * 32;
 
   const int M = (int)d.M, R = (int)d.R, L = (int)d.Lin, N = (int)d.N, G = (int)d.groups;
+  const int Lv = L * UP;
   const int split = blockIdx.x;
   const int m0 = blockIdx.y * BM, r0 = blockIdx.z * BR;
   const int total = (int)d.B * CPB;
@@ -70,7 +95,7 @@ __global__ __launch_bounds__((BM / 32) * (BR / 32) * NKG * 64) void wgrad_mm_ker
     const int row = e / XQ, q = e - row * XQ;
     x_dst[i] = row * XS + 4 * q;
     x_src[i] = (r0 + row) * L;
-    x_pos[i] = 4 * q - 4;
+    x_pos[i] = 4 * q - HALO;
     if (PRO == 1) {
       const int r = r0 + row;
       x_st[i] = (r / (R / G)) * 2;
@@ -104,9 +129,9 @@ __global__ __launch_bounds__((BM / 32) * (BR / 32) * NKG * 64) void wgrad_mm_ker
     }                                                                                                      \
     const float* xbp = d.x + (int64_t)b * R * L;                                                           \
     _Pragma("unroll") for (int i = 0; i < NX4; ++i) {                                                      \
-      const int u = p0 + x_pos[i];                                                                         \
-      x_ok[i] = (u >= 0 && u < L);                                                                         \
-      rx[i] = *reinterpret_cast<const f32x4*>(xbp + x_src[i] + (x_ok[i] ? u : 0));                         \
+      const int u = p0 * S + x_pos[i];                                                                     \
+      x_ok[i] = (u >= 0 && u < Lv);                                                                        \
+      rx[i] = wg_load_xquad<UP>(xbp + x_src[i] + (x_ok[i] ? u / UP : 0));                                  \
       if (PRO == 1) {                                                                                      \
         rmean[i] = d.pro_stats[(int64_t)b * G * 2 + x_st[i]];                                              \
         rrstd[i] = d.pro_stats[(int64_t)b * G * 2 + x_st[i] + 1];                                          \
@@ -154,24 +179,38 @@ __global__ __launch_bounds__((BM / 32) * (BR / 32) * NKG * 64) void wgrad_mm_ker
     for (int s = 0; s < PPW / 8; ++s) {
       const int base = kg * PPW + 8 * s + 4 * hi;
       const f32x4 dq = *reinterpret_cast<const f32x4*>(Db + (wm0 + l31) * DS + base);
-      float xq[12];
-      const float* xp = Xb + (wr0 + l31) * XS + base;
-      if (KT == 3) {
+      float xq[S == 1 ? 12 : 4 * S];
+      if (S == 1) {
+        const float* xp = Xb + (wr0 + l31) * XS + base;
+        if (KT == 3) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+          for (int q = 0; q < 3; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xp + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xq[4 * q + j] = v[j];
+          }
+        } else {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xp + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xq[4 + j] = v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < KT; ++t) acc[t] = adp_mfma32(dq[j], xq[j + 4 - PAD + t], acc[t]);
+      } else {
+        const float* xp = Xb + (wr0 + l31) * XS + base * S;
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(xp + 4 * q);
 #pragma unroll
           for (int j = 0; j < 4; ++j) xq[4 * q + j] = v[j];
         }
-      } else {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xp + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xq[4 + j] = v[j];
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < KT; ++t) acc[t] = adp_mfma32(dq[j], xq[j * S + t], acc[t]);
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int t = 0; t < KT; ++t) acc[t] = adp_mfma32(dq[j], xq[j + 4 - PAD + t], acc[t]);
     }
   }
 #undef WG_LOAD
@@ -236,7 +275,7 @@ struct WgPlan {
 
 WgPlan wg_plan(const adp_wgrad_desc& d) {
   WgPlan p;
-  p.bm = (d.M % 64 == 0 && d.R % 64 == 0) ? 64 : 32;
+  p.bm = (d.M % 64 == 0 && d.R % 64 == 0 && d.stride != 4) ? 64 : 32;  // stride 4: x rows are 4x wider in LDS
   p.nkg = 4;
   const int64_t tiles = (d.M / p.bm) * (d.R / p.bm);
   p.cpb = adp_cdiv(d.N, WG_BKN);
@@ -282,9 +321,32 @@ __global__ __launch_bounds__(1024) void adp_wgrad_reduce_kernel(const float* ws,
   }
 }
 
+// few splits: one thread per output walks them (the 16-lane form would idle most of its lanes)
+__global__ __launch_bounds__(256) void adp_wgrad_reduce_small_kernel(const float* ws, int64_t nsplit, int64_t cnt,
+                                                                     int64_t M, float* dw, float* dbias,
+                                                                     int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < cnt) {
+    float s = 0.0f;
+    for (int64_t k = 0; k < nsplit; ++k) s += ws[k * cnt + i];
+    dw[i] = accumulate ? dw[i] + s : s;
+  } else if (dbias && i < cnt + M) {
+    const int64_t m = i - cnt;
+    const float* wsb = ws + nsplit * cnt;
+    float s = 0.0f;
+    for (int64_t k = 0; k < nsplit; ++k) s += wsb[k * M + m];
+    dbias[m] = accumulate ? dbias[m] + s : s;
+  }
+}
+
 int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, float* dw, float* dbias, int accumulate,
                      void* stream) {
   const int64_t tot = cnt + (dbias ? M : 0);
+  if (nsplit <= 8) {
+    ADP_LAUNCH(adp_wgrad_reduce_small_kernel, dim3((unsigned)adp_cdiv(tot, 256)), dim3(256), stream, ws, nsplit, cnt, M,
+               dw, dbias, accumulate);
+    return ADP_LAUNCH_OK();
+  }
   ADP_LAUNCH(adp_wgrad_reduce_kernel, dim3((unsigned)adp_cdiv(tot, 64)), dim3(1024), stream, ws, nsplit, cnt, M, dw,
              dbias, accumulate);
   return ADP_LAUNCH_OK();
@@ -292,31 +354,37 @@ int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, fl
 
 namespace {
 
-template <int BM, int KT, int PRO>
+template <int BM, int KT, int S, int UP, int PRO>
 int launch_wg(const adp_wgrad_desc& d, const WgPlan& p, void* stream) {
   dim3 grid((unsigned)p.nsplit, (unsigned)(d.M / BM), (unsigned)(d.R / BM));
-  ADP_LAUNCH((wgrad_mm_kernel<BM, BM, 4, KT, PRO>), grid, dim3((BM / 32) * (BM / 32) * 4 * 64), stream, d, (int)p.cpb,
-             (int)p.cps, (int)p.nsplit);
+  ADP_LAUNCH((wgrad_mm_kernel<BM, BM, 4, KT, S, UP, PRO>), grid, dim3((BM / 32) * (BM / 32) * 4 * 64), stream, d,
+             (int)p.cpb, (int)p.cps, (int)p.nsplit);
   if (p.nsplit > 1) {
     return adp_wgrad_reduce(d.ws, p.nsplit, d.M * d.R * KT, d.M, d.dw, d.dbias, (int)d.accumulate, stream);
   }
   return ADP_LAUNCH_OK();
 }
 
-template <int KT, int PRO>
+template <int KT, int S, int UP, int PRO>
 int pick_wg(const adp_wgrad_desc& d, void* stream) {
   const WgPlan p = wg_plan(d);
-  if (p.bm == 64) return launch_wg<64, KT, PRO>(d, p, stream);
-  return launch_wg<32, KT, PRO>(d, p, stream);
+  if constexpr (S != 4) {
+    if (p.bm == 64) return launch_wg<64, KT, S, UP, PRO>(d, p, stream);
+  }
+  return launch_wg<32, KT, S, UP, PRO>(d, p, stream);
 }
 
 }  // namespace
 
 bool adp_wgrad_mm_eligible(const adp_wgrad_desc& d) {
-  if (d.stride != 1 || d.up != 1 || d.R1 != d.R || d.dil != 1) return false;
-  if (!((d.KT == 3 && d.pad == 1) || (d.KT == 1 && d.pad == 0))) return false;
+  if (d.R1 != d.R || d.dil != 1) return false;
+  const bool plain = d.stride == 1 && d.up == 1 && ((d.KT == 3 && d.pad == 1) || (d.KT == 1 && d.pad == 0));
+  const bool upc = d.stride == 1 && (d.up == 2 || d.up == 4) && d.KT == 3 && d.pad == 1 && d.prologue == 0;
+  const bool down = (d.stride == 2 || d.stride == 4) && d.KT == d.stride && d.pad == 0 && d.up == 1 && d.prologue == 0;
+  if (!plain && !upc && !down) return false;
   if (d.prologue != 0 && d.prologue != 1) return false;
-  if (d.R % 32 != 0 || d.M % 32 != 0 || d.Lin % 4 != 0 || d.N % 4 != 0 || d.N != d.Lin) return false;
+  if (d.R % 32 != 0 || d.M % 32 != 0 || (d.Lin * d.up) % 4 != 0 || d.N % 4 != 0) return false;
+  if (d.N * d.stride != d.Lin * d.up) return false;
   if ((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.dy)) & 15) return false;
   if (d.M * d.N >= (int64_t)1 << 31 || d.R * d.Lin >= (int64_t)1 << 31 || d.B * adp_cdiv(d.N, WG_BKN) >= (int64_t)1 << 31)
     return false;
@@ -330,6 +398,10 @@ int64_t adp_wgrad_mm_ws_floats(const adp_wgrad_desc& d) {
 }
 
 int adp_wgrad_mm(const adp_wgrad_desc& d, void* stream) {
-  if (d.KT == 3) return d.prologue == 1 ? pick_wg<3, 1>(d, stream) : pick_wg<3, 0>(d, stream);
-  return d.prologue == 1 ? pick_wg<1, 1>(d, stream) : pick_wg<1, 0>(d, stream);
+  if (d.stride == 2) return pick_wg<2, 2, 1, 0>(d, stream);
+  if (d.stride == 4) return pick_wg<4, 4, 1, 0>(d, stream);
+  if (d.up == 2) return pick_wg<3, 1, 2, 0>(d, stream);
+  if (d.up == 4) return pick_wg<3, 1, 4, 0>(d, stream);
+  if (d.KT == 3) return d.prologue == 1 ? pick_wg<3, 1, 1, 1>(d, stream) : pick_wg<3, 1, 1, 0>(d, stream);
+  return d.prologue == 1 ? pick_wg<1, 1, 1, 1>(d, stream) : pick_wg<1, 1, 1, 0>(d, stream);
 }

@@ -493,5 +493,11 @@ class _UNetFn(torch.autograd.Function):
         gfeat = dfeat if (ctx.has_features and ctx.needs_input_grad[3]) else None
         gemb = run.emb_grad if (ctx.has_embedding and ctx.needs_input_grad[4]) else None
         gctx = tuple(run.ctx_grads) if run.ctx_grads is not None else (None,) * ctx.n_ctx
+        # AccumulateGrad adopts an incoming gradient without a copy only when nobody else holds it: drop every
+        # reference of ours to the per-parameter views (they stay views of the one flat buffer RCCL reduced)
+        run.grads.clear()
+        run.flat = None
         ctx.run = None
-        return (None, gx, None, gfeat, gemb, None, None, None) + gctx + tuple(views)
+        out = (None, gx, None, gfeat, gemb, None, None, None) + gctx + tuple(views)
+        del views, flat, v
+        return out

@@ -41,6 +41,11 @@ struct f32x16 {
   float& operator[](int i) { return v[i]; }
   const float& operator[](int i) const { return v[i]; }
 };
+struct f32x2 {
+  float v[2];
+  float& operator[](int i) { return v[i]; }
+  const float& operator[](int i) const { return v[i]; }
+};
 struct f32x4 {
   float v[4];
   float& operator[](int i) { return v[i]; }

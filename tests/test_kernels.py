@@ -155,6 +155,37 @@ def test_conv_mm_family(dev, B, R, M, L, KT, pad, dil):
     assert rel_err(out, ref) < TOL
 
 
+MM_RESAMPLE_CASES = [
+    # B, R, M, Lin, KT, stride, pad, up -- DownsampleItem (kernel = stride) and UpsampleItem (nearest + k3) on conv_mm
+    (2, 32, 64, 256, 2, 2, 0, 1),
+    (1, 64, 32, 136, 2, 2, 0, 1),     # ragged tile, 2 chunks
+    (2, 32, 64, 512, 4, 4, 0, 1),     # 16-channel chunks
+    (1, 64, 128, 256, 4, 4, 0, 1),
+    (2, 32, 32, 66, 3, 1, 1, 2),      # Lin * up = 132: ragged
+    (1, 64, 64, 40, 3, 1, 1, 4),
+    (3, 96, 32, 64, 3, 1, 1, 2),
+]
+
+
+@pytest.mark.parametrize("B,R,M,L,KT,stride,pad,up", MM_RESAMPLE_CASES)
+def test_conv_mm_resample(dev, B, R, M, L, KT, stride, pad, up):
+    from audio_diffusion_pytorch_amd import _C
+    x, w, b = rnd(B, R, L, seed=1), rnd(M, R, KT, seed=2, scale=0.2), rnd(M, seed=3)
+    xr = F.interpolate(x, scale_factor=up, mode="nearest") if up > 1 else x
+    ref = F.conv1d(xr, w, b, stride=stride, padding=pad)
+    xd, wd = x.to(dev), w.to(dev)
+    d = _C.ConvDesc(_C.ptr(xd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(xd), None, B, R, R, L, M,
+                    ref.shape[-1], KT, stride, 1, pad, up, 0, 0, 1, 0, 1, 0)
+    assert _C.query("adp_conv1d_tile", d) >= 1000000, "case must dispatch to the conv_mm family"
+    # with the SkipModulate epilogue of the up path: out = skip + scale[b, m] * (conv + bias), pre-merge value kept
+    skip, scale = rnd(*ref.shape, seed=5), rnd(B, M, seed=6)
+    pre = torch.empty(ref.shape, device=dev)
+    out = ops.conv1d(xd, wd, b.to(dev), stride=stride, pad=pad, up=up, e_scale=scale.to(dev).view(-1), e_bstride=M,
+                     res=skip.to(dev), out_pre=pre)
+    assert rel_err(pre, ref) < TOL
+    assert rel_err(out, skip + scale[:, :, None] * ref) < TOL
+
+
 # ------------------------------------------------------------------ conv data gradients
 @pytest.mark.parametrize("B,R,M,L,KT,stride,pad,up", CONV_CASES)
 def test_conv1d_dgrad(dev, B, R, M, L, KT, stride, pad, up):
@@ -250,6 +281,24 @@ def test_wgrad_mm_family(dev, B, R, M, L, KT):
                               accumulate=True)
     assert rel_err(dw, dw_ref + dw0) < TOL
     assert rel_err(db, db_ref + db0) < TOL
+
+
+@pytest.mark.parametrize("B,R,M,L,KT,stride,pad,up", MM_RESAMPLE_CASES + [(2, 64, 64, 128, 2, 2, 0, 1),
+                                                                         (2, 64, 128, 20, 3, 1, 1, 4)])
+def test_wgrad_mm_resample(dev, B, R, M, L, KT, stride, pad, up):
+    """Weight gradients of DownsampleItem (kernel = stride) and UpsampleItem (nearest + k3) on wgrad_mm."""
+    x = rnd(B, R, L, seed=1)
+    w = rnd(M, R, KT, seed=2, scale=0.2).requires_grad_()
+    b = rnd(M, seed=3).requires_grad_()
+    xr = F.interpolate(x, scale_factor=up, mode="nearest") if up > 1 else x
+    y = F.conv1d(xr, w, b, stride=stride, padding=pad)
+    if y.shape[-1] % 4 != 0:
+        pytest.skip("wgrad_mm needs N % 4 == 0 (falls back to the generic kernel, covered above)")
+    dy = rnd(*y.shape, seed=9)
+    dw_ref, db_ref = torch.autograd.grad(y, (w, b), dy)
+    dw, db = ops.conv1d_wgrad(x.to(dev), dy.to(dev), KT, stride=stride, pad=pad, up=up)
+    assert rel_err(dw, dw_ref) < TOL
+    assert rel_err(db, db_ref) < TOL
 
 
 # ------------------------------------------------------------------ GroupNorm+SiLU backward
