@@ -852,6 +852,7 @@ extern "C" int adp_conv1d(const adp_conv_desc* dp, void* stream) {
   if (d.store == 2 && ((d.sp != 2 && d.sp != 4) || d.N % d.sp != 0 || d.bias)) return ADP_ERR_UNSUPPORTED;
   if (d.B > 65535 || adp_cdiv(d.M, 32) > 65535) return ADP_ERR_SHAPE;
   if (adp_conv_mm_eligible(d)) return adp_conv_mm(d, stream);
+  if (adp_conv_direct_eligible(d)) return adp_conv_direct(d, stream);
   if (d.KT == 1) return dispatch_conv<1, 1>(d, stream);
   if (d.KT == 2) return dispatch_conv<2, 2>(d, stream);
   if (d.KT == 3) return dispatch_conv<3, 1>(d, stream);
@@ -862,6 +863,7 @@ extern "C" int adp_conv1d(const adp_conv_desc* dp, void* stream) {
 extern "C" int64_t adp_conv1d_tile(const adp_conv_desc* dp) {
   if (!dp) return ADP_ERR_NULL;
   if (adp_conv_mm_eligible(*dp)) return adp_conv_mm_tile(*dp);
+  if (adp_conv_direct_eligible(*dp)) return 8 * 1000 + 999;  // direct VALU kernel: 8 output channels x 1024 positions
   return pick_tile(*dp);
 }
 
@@ -869,6 +871,7 @@ extern "C" int64_t adp_conv1d_wgrad_ws_bytes(const adp_wgrad_desc* dp) {
   if (!dp || !ks_supported(dp->KT, dp->stride) || dp->B <= 0 || dp->N <= 0) return ADP_ERR_UNSUPPORTED;
   int64_t nsplit;
   if (adp_wgrad_mm_eligible(*dp)) return adp_wgrad_mm_ws_floats(*dp) * (int64_t)sizeof(float);
+  if (adp_wgrad_direct_eligible(*dp)) return adp_wgrad_direct_ws_floats(*dp) * (int64_t)sizeof(float);
   if (wgrad_s1_eligible(*dp)) {
     int64_t CPB, CPS;
     wgrad_s1_split(*dp, &CPB, &CPS, &nsplit);
@@ -893,6 +896,7 @@ extern "C" int adp_conv1d_wgrad(const adp_wgrad_desc* dp, void* stream) {
   if (d.prologue == 1 && (d.groups < 1 || d.R % d.groups != 0)) return ADP_ERR_SHAPE;
   if (adp_cdiv(d.M, 32) > 65535 || adp_cdiv(d.R, 32) > 65535) return ADP_ERR_SHAPE;
   if (adp_wgrad_mm_eligible(d)) return adp_wgrad_mm(d, stream);
+  if (adp_wgrad_direct_eligible(d)) return adp_wgrad_direct(d, stream);
   if (d.KT == 1) return launch_wgrad<1, 1>(d, stream);
   if (d.KT == 2) return launch_wgrad<2, 2>(d, stream);
   if (d.KT == 3) return launch_wgrad<3, 1>(d, stream);

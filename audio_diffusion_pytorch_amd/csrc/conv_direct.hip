@@ -1,0 +1,259 @@
+// Direct (VALU) Conv1d for the narrow ends of the U-Net: depth-0/1 layers with 2-8 channels on one side
+// (ResnetItem at channels = 8, the first DownsampleItem, the last UpsampleItem + SkipModulate merge and their data
+// gradients; /root/reference/audio_diffusion_pytorch/components.py:84-99).
+//
+// These layers are pure streaming: 8 x 8 x 3 weights against 2**18 positions.  A 32x32 matrix-core tile would be
+// 75-94 % padding there, so the contraction runs on the vector ALU instead and the kernel is organised around HBM:
+//   * one thread owns FOUR consecutive output positions (16-byte loads / stores along L, the contiguous axis) and
+//     MB = 8 output channels; a workgroup covers 1024 positions, grid.y tiles the output channels;
+//   * per input channel a thread loads its window once (one 16-byte load + the halo scalars, which hit the lines
+//     its neighbours fetch), applies the GroupNorm+SiLU prologue in registers, and reuses it for all MB outputs;
+//     the nearest-upsample gather (source index = u / UP, integer, exact) and the kernel = stride windows of
+//     DownsampleItem are just different window loaders;
+//   * the MB x R x KT weights of the workgroup live in LDS in consumption order (the transposed view of the data
+//     gradient is resolved while staging them) and are read with wave-uniform (broadcast) 16-byte LDS loads;
+//   * epilogue = adp_conv1d's: bias, pre-merge copy, e_scale[b,m], residual, plain or pooled (sum of sp) store.
+#include "adp_rt.h"
+#include "adp.h"
+#include "conv_internal.h"
+
+namespace {
+
+constexpr int DC_MB = 8;       // output channels per thread
+constexpr int DC_NCH = 8;      // input-channel chunks whose weights fit the LDS table
+
+template <int KT, int S>
+struct DcCfg {
+  static constexpr int RCH = (S == 1) ? 8 : (S == 2 ? 4 : 2);  // input channels per register chunk
+  static constexpr int W = 3 * S + KT;                          // window: positions touched by 4 outputs
+  static constexpr int WBLK = ((RCH * KT + 3) / 4) * 4;         // weights of one (m, chunk), padded to 16 bytes
+};
+
+// window of virtual positions ustart .. ustart+W-1 of one input row (upsampled by UP, zero outside [0, Lv)),
+// n0s = first position whose 4-aligned quad can be fetched with one wide load (S == 1: the four outputs' centre)
+template <int KT, int S, int UP>
+__device__ __forceinline__ void dc_load_window(const float* row, int ustart, int Lv, float* win) {
+  constexpr int W = DcCfg<KT, S>::W;
+  if (UP == 1 && S == 1) {
+    // ustart = n0 - PAD with n0 % 4 == 0 and PAD = (KT-1)/2: the aligned quad sits PAD elements into the window
+    constexpr int PAD = (KT - 1) / 2;
+    const int n0 = ustart + PAD;
+    if (n0 + 3 < Lv) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(row + n0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) win[PAD + j] = q[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) win[PAD + j] = (n0 + j < Lv) ? row[n0 + j] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < PAD; ++i) {
+      const int ul = ustart + i, ur = n0 + 4 + i;
+      win[i] = (ul >= 0) ? row[ul] : 0.0f;
+      win[PAD + 4 + i] = (ur < Lv) ? row[ur] : 0.0f;
+    }
+  } else if (UP == 1) {
+    // kernel = stride: 4*S contiguous, 16-byte aligned inputs
+#pragma unroll
+    for (int q4 = 0; q4 < W / 4; ++q4) {
+      const int u = ustart + 4 * q4;
+      f32x4 q;
+      if (u >= 0 && u + 3 < Lv) {
+        q = *reinterpret_cast<const f32x4*>(row + u);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = (u + j >= 0 && u + j < Lv) ? row[u + j] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) win[4 * q4 + j] = q[j];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      const int u = ustart + i;
+      win[i] = (u >= 0 && u < Lv) ? row[u / UP] : 0.0f;  // consecutive i share a source element: L1 hits
+    }
+  }
+}
+
+template <int KT, int S, int UP>
+__global__ __launch_bounds__(256) void conv_direct_kernel(adp_conv_desc d) {
+  using C = DcCfg<KT, S>;
+  constexpr int MB = DC_MB, RCH = C::RCH, W = C::W, WBLK = C::WBLK;
+  __shared__ __attribute__((aligned(16))) float Ws[MB * DC_NCH * WBLK];
+
+  const int tid = threadIdx.x;
+  const int M = (int)d.M, R = (int)d.R, R1 = (int)d.R1, L = (int)d.Lin, N = (int)d.N;
+  const int pad = (int)d.pad, Lv = L * UP;
+  const int b = blockIdx.z, m0 = blockIdx.y * MB;
+  const int n0 = (blockIdx.x * 256 + tid) * 4;
+  const int nch = (R + RCH - 1) / RCH;
+
+  // ---- weights of this workgroup's MB output channels, in consumption order [m][chunk][r_local][t]
+  for (int e = tid; e < MB * nch * WBLK; e += 256) {
+    const int m = e / (nch * WBLK), rem = e - m * (nch * WBLK);
+    const int ch = rem / WBLK, k = rem - ch * WBLK;
+    const int rl = k / KT, t = k - rl * KT, r = ch * RCH + rl;
+    float v = 0.0f;
+    if (k < RCH * KT && r < R && m0 + m < M)
+      v = d.transposed ? d.w[((int64_t)r * M + m0 + m) * KT + (KT - 1 - t)] : d.w[((int64_t)(m0 + m) * R + r) * KT + t];
+    Ws[e] = v;
+  }
+  __syncthreads();
+  if (n0 >= N) return;
+
+  float acc[MB][4];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[m][p] = 0.0f;
+
+  const int ustart = n0 * S - pad;
+  const int cpg = (d.prologue == 1) ? R / (int)d.groups : 1;
+  for (int ch = 0; ch < nch; ++ch) {
+    float win[RCH][W];
+#pragma unroll
+    for (int rl = 0; rl < RCH; ++rl) {
+      const int r = ch * RCH + rl;
+      if (r < R) {  // block-uniform
+        const float* row = (r < R1) ? d.x + ((int64_t)b * R1 + r) * L : d.x2 + ((int64_t)b * (R - R1) + (r - R1)) * L;
+        dc_load_window<KT, S, UP>(row, ustart, Lv, win[rl]);
+        if (d.prologue == 1) {
+          const int g = r / cpg;
+          const float mean = d.pro_stats[((int64_t)b * d.groups + g) * 2];
+          const float pa = (d.pro_gamma ? d.pro_gamma[r] : 1.0f) * d.pro_stats[((int64_t)b * d.groups + g) * 2 + 1];
+          const float pb = (d.pro_beta ? d.pro_beta[r] : 0.0f) - mean * pa;
+#pragma unroll
+          for (int i = 0; i < W; ++i) {
+            const int u = ustart + i;
+            const float a = adp_silu_fast(fmaf(win[rl][i], pa, pb));
+            win[rl][i] = (u >= 0 && u < Lv) ? a : 0.0f;  // zero padding is applied after the activation
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < W; ++i) win[rl][i] = 0.0f;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const float* wp = Ws + (m * nch + ch) * WBLK;
+      float wv[WBLK];
+#pragma unroll
+      for (int q = 0; q < WBLK / 4; ++q) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(wp + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wv[4 * q + j] = t4[j];
+      }
+#pragma unroll
+      for (int rl = 0; rl < RCH; ++rl)
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) acc[m][p] = fmaf(wv[rl * KT + t], win[rl][p * S + t], acc[m][p]);
+    }
+  }
+
+  // ---- epilogue
+  const int sp = (int)d.sp;
+  const int64_t ebs = d.e_bstride ? d.e_bstride : M;
+  const bool full = (n0 + 3 < N);
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+    const int mm = m0 + m;
+    if (mm >= M) break;
+    float v[4];
+    const float bias = d.bias ? d.bias[mm] : 0.0f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) v[p] = acc[m][p] + bias;
+    const int64_t o = ((int64_t)b * M + mm) * N + n0;
+    if (d.out_pre) {
+      if (full) {
+        f32x4 q;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) q[p] = v[p];
+        *reinterpret_cast<f32x4*>(d.out_pre + o) = q;
+      } else {
+        for (int p = 0; p < 4 && n0 + p < N; ++p) d.out_pre[o + p] = v[p];
+      }
+    }
+    if (d.e_scale) {
+      const float es = d.e_scale[b * ebs + mm];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) v[p] *= es;
+    }
+    if (d.store == 0) {
+      if (full) {
+        f32x4 q;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) q[p] = v[p];
+        if (d.res) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(d.res + o);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) q[p] += rr[p];
+        }
+        *reinterpret_cast<f32x4*>(d.out + o) = q;
+      } else {
+        for (int p = 0; p < 4 && n0 + p < N; ++p) d.out[o + p] = v[p] + (d.res ? d.res[o + p] : 0.0f);
+      }
+    } else {
+      // pooled store (gradient of the nearest upsample): N % sp == 0 and sp in {2, 4}, so a thread's four
+      // positions cover whole groups
+      const int64_t op = ((int64_t)b * M + mm) * (N / sp) + n0 / sp;
+      if (sp == 4) {
+        float s = (v[0] + v[1]) + (v[2] + v[3]);
+        if (d.res) s += d.res[op];
+        d.out[op] = s;
+      } else {
+        float s0 = v[0] + v[1], s1 = v[2] + v[3];
+        if (d.res) {
+          s0 += d.res[op];
+          s1 += d.res[op + 1];
+        }
+        d.out[op] = s0;
+        d.out[op + 1] = s1;
+      }
+    }
+  }
+}
+
+template <int KT, int S, int UP>
+int launch_dc(const adp_conv_desc& d, void* stream) {
+  dim3 grid((unsigned)adp_cdiv(d.N, 1024), (unsigned)adp_cdiv(d.M, DC_MB), (unsigned)d.B);
+  ADP_LAUNCH((conv_direct_kernel<KT, S, UP>), grid, dim3(256), stream, d);
+  return ADP_LAUNCH_OK();
+}
+
+}  // namespace
+
+bool adp_conv_direct_eligible(const adp_conv_desc& d) {
+  if (d.dil != 1 || (d.prologue != 0 && d.prologue != 1) || (d.store != 0 && d.store != 2)) return false;
+  const bool s1 = d.stride == 1 && (d.KT == 1 || d.KT == 3) && (d.up == 1 || d.up == 2 || d.up == 4);
+  const bool down = (d.stride == 2 || d.stride == 4) && d.KT == d.stride && d.up == 1 && d.pad == 0;
+  if (!s1 && !down) return false;
+  if (s1 && d.pad != (d.KT - 1) / 2) return false;
+  // narrow layers only: the contraction is on the VALU
+  const int64_t rch = d.stride == 1 ? 8 : (d.stride == 2 ? 4 : 2);
+  if (d.R > rch * DC_NCH) return false;
+  if (d.R > 8 && d.M > 8) return false;
+  if (d.N % 4 != 0 || (d.Lin * d.up) % 4 != 0) return false;
+  if (d.store == 2 && ((d.sp != 2 && d.sp != 4) || d.N % d.sp != 0 || d.out_pre)) return false;
+  if ((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.out) | reinterpret_cast<uintptr_t>(d.res) |
+       reinterpret_cast<uintptr_t>(d.out_pre) | reinterpret_cast<uintptr_t>(d.x2)) & 15)
+    return false;
+  if (d.B > 65535 || adp_cdiv(d.M, DC_MB) > 65535 || d.Lin * d.up >= (int64_t)1 << 30) return false;
+  return true;
+}
+
+int adp_conv_direct(const adp_conv_desc& d, void* stream) {
+  if (d.stride == 2) return launch_dc<2, 2, 1>(d, stream);
+  if (d.stride == 4) return launch_dc<4, 4, 1>(d, stream);
+  if (d.KT == 3) {
+    if (d.up == 2) return launch_dc<3, 1, 2>(d, stream);
+    if (d.up == 4) return launch_dc<3, 1, 4>(d, stream);
+    return launch_dc<3, 1, 1>(d, stream);
+  }
+  if (d.up == 2) return launch_dc<1, 1, 2>(d, stream);
+  if (d.up == 4) return launch_dc<1, 1, 4>(d, stream);
+  return launch_dc<1, 1, 1>(d, stream);
+}

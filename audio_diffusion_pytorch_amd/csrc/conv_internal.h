@@ -13,3 +13,12 @@ int64_t adp_wgrad_mm_ws_floats(const adp_wgrad_desc& d);
 int adp_wgrad_mm(const adp_wgrad_desc& d, void* stream);
 int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, float* dw, float* dbias, int accumulate,
                      void* stream);
+
+// conv_direct.hip: VALU direct convolution for the narrow (2-8 channel) ends of the U-Net
+bool adp_conv_direct_eligible(const adp_conv_desc& d);
+int adp_conv_direct(const adp_conv_desc& d, void* stream);
+
+// wgrad_direct.hip: VALU streaming weight gradient for the narrow layers (M * R <= 256)
+bool adp_wgrad_direct_eligible(const adp_wgrad_desc& d);
+int64_t adp_wgrad_direct_ws_floats(const adp_wgrad_desc& d);
+int adp_wgrad_direct(const adp_wgrad_desc& d, void* stream);

@@ -186,6 +186,62 @@ def test_conv_mm_resample(dev, B, R, M, L, KT, stride, pad, up):
     assert rel_err(out, skip + scale[:, :, None] * ref) < TOL
 
 
+DIRECT_CASES = [
+    # B, R, M, Lin, KT, stride, pad, up -- narrow layers on the VALU direct kernel (conv_direct.hip)
+    (2, 8, 8, 2052, 3, 1, 1, 1),      # two workgroups of 1024 positions + ragged tail
+    (1, 2, 8, 1024, 1, 1, 0, 1),
+    (2, 8, 2, 512, 3, 1, 1, 1),
+    (1, 8, 32, 1024, 4, 4, 0, 1),
+    (2, 4, 16, 64, 2, 2, 0, 1),
+    (1, 32, 8, 60, 3, 1, 1, 4),
+    (2, 16, 8, 34, 3, 1, 1, 2),
+    (1, 8, 40, 64, 3, 1, 1, 1),       # 5 output-channel groups
+]
+
+
+@pytest.mark.parametrize("B,R,M,L,KT,stride,pad,up", DIRECT_CASES)
+def test_conv_direct_family(dev, B, R, M, L, KT, stride, pad, up):
+    from audio_diffusion_pytorch_amd import _C
+    x = rnd(B, R, L, seed=1).requires_grad_()
+    w, b = rnd(M, R, KT, seed=2, scale=0.2), rnd(M, seed=3)
+    xr = F.interpolate(x, scale_factor=up, mode="nearest") if up > 1 else x
+    ref = F.conv1d(xr, w, b, stride=stride, padding=pad)
+    xd, wd = x.detach().to(dev), w.to(dev)
+    d = _C.ConvDesc(_C.ptr(xd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(xd), None, B, R, R, L, M,
+                    ref.shape[-1], KT, stride, 1, pad, up, 0, 0, 1, 0, 1, 0)
+    assert _C.query("adp_conv1d_tile", d) == 8999, "case must dispatch to the direct kernel"
+    skip, scale = rnd(*ref.shape, seed=5), rnd(B, M, seed=6)
+    pre = torch.empty(ref.shape, device=dev)
+    out = ops.conv1d(xd, wd, b.to(dev), stride=stride, pad=pad, up=up, e_scale=scale.to(dev).view(-1), e_bstride=M,
+                     res=skip.to(dev), out_pre=pre)
+    assert rel_err(pre, ref.detach()) < TOL
+    assert rel_err(out, skip + scale[:, :, None] * ref.detach()) < TOL
+    if stride == 1:
+        dy = rnd(*ref.shape, seed=9)
+        (dx_ref,) = torch.autograd.grad(ref, x, dy)
+        dx = ops.conv1d(dy.to(dev), wd, None, pad=(KT - 1) - pad, transposed=True, store=2 if up > 1 else 0, sp=up)
+        assert rel_err(dx, dx_ref) < TOL
+
+
+def test_conv_direct_concat_gn(dev):
+    """x2 channel concat (AppendChannelsPlugin) and the GroupNorm+SiLU prologue on the direct kernel."""
+    B, R1, R2, M, L, G = 2, 2, 2, 8, 256, 2
+    x, x2 = rnd(B, R1, L, seed=1), rnd(B, R2, L, seed=2)
+    w, b = rnd(M, R1 + R2, 1, seed=3, scale=0.3), rnd(M, seed=4)
+    ref = F.conv1d(torch.cat([x, x2], 1), w, b)
+    out = ops.conv1d(x.to(dev), w.to(dev), b.to(dev), x2=x2.to(dev))
+    assert rel_err(out, ref) < TOL
+    C = 8
+    xx, ww = rnd(B, C, L, seed=5) * 1.4 + 0.3, rnd(C, C, 3, seed=6, scale=0.2)
+    gamma, beta, res = rnd(C, seed=7) * 0.5 + 1, rnd(C, seed=8) * 0.1, rnd(B, C, L, seed=9)
+    ref = F.conv1d(ref_gn_silu(xx, G, gamma, beta), ww, b, padding=1) + res
+    xd = xx.to(dev)
+    stats = ops.gn_stats(xd, G)
+    out = ops.conv1d(xd, ww.to(dev), b.to(dev), pad=1, prologue=1, pro_stats=stats, pro_gamma=gamma.to(dev),
+                     pro_beta=beta.to(dev), groups=G, res=res.to(dev))
+    assert rel_err(out, ref) < TOL
+
+
 # ------------------------------------------------------------------ conv data gradients
 @pytest.mark.parametrize("B,R,M,L,KT,stride,pad,up", CONV_CASES)
 def test_conv1d_dgrad(dev, B, R, M, L, KT, stride, pad, up):
@@ -299,6 +355,26 @@ def test_wgrad_mm_resample(dev, B, R, M, L, KT, stride, pad, up):
     dw, db = ops.conv1d_wgrad(x.to(dev), dy.to(dev), KT, stride=stride, pad=pad, up=up)
     assert rel_err(dw, dw_ref) < TOL
     assert rel_err(db, db_ref) < TOL
+
+
+@pytest.mark.parametrize("B,R,M,L,KT,stride,pad,up", DIRECT_CASES[:7] + [(3, 8, 8, 1300, 3, 1, 1, 1)])
+def test_wgrad_direct_family(dev, B, R, M, L, KT, stride, pad, up):
+    """Weight gradients of the narrow layers on the VALU streaming kernel (wgrad_direct.hip), incl. x2 concat."""
+    x = rnd(B, R, L, seed=1)
+    w = rnd(M, R, KT, seed=2, scale=0.2).requires_grad_()
+    b = rnd(M, seed=3).requires_grad_()
+    xr = F.interpolate(x, scale_factor=up, mode="nearest") if up > 1 else x
+    y = F.conv1d(xr, w, b, stride=stride, padding=pad)
+    dy = rnd(*y.shape, seed=9)
+    dw_ref, db_ref = torch.autograd.grad(y, (w, b), dy)
+    dw, db = ops.conv1d_wgrad(x.to(dev), dy.to(dev), KT, stride=stride, pad=pad, up=up)
+    assert rel_err(dw, dw_ref) < TOL
+    assert rel_err(db, db_ref) < TOL
+    if R >= 2 and up == 1:
+        r1 = R // 2
+        dw2, _ = ops.conv1d_wgrad(x[:, :r1].contiguous().to(dev), dy.to(dev), KT, stride=stride, pad=pad,
+                                  x2=x[:, r1:].contiguous().to(dev))
+        assert rel_err(dw2, dw_ref) < TOL
 
 
 # ------------------------------------------------------------------ GroupNorm+SiLU backward
