@@ -41,6 +41,7 @@ class WgradDesc(Structure):
 # name -> (restype, argtypes); mirrors include/adp.h one to one
 SIGNATURES = {
     "adp_version": (c_int, []),
+    "adp_launch_trace": (I, [I, ctypes.c_char_p, I]),
     "adp_conv1d": (c_int, [POINTER(ConvDesc), P]),
     "adp_conv1d_tile": (I, [POINTER(ConvDesc)]),
     "adp_conv1d_wgrad_ws_bytes": (I, [POINTER(WgradDesc)]),
@@ -131,8 +132,60 @@ def check(code: int, what: str):
         raise RuntimeError(f"{what} failed: {ERRORS.get(code, code)} ({code})")
 
 
+# ---- launch profiling (bench.py's roofline leg): when PROFILE is a list, every C-ABI call is bracketed by HIP
+# events on the stream it launches on and labelled with the kernel instantiation(s) it dispatched.
+PROFILE = None
+_TAG = None
+
+
+def tag(**meta):
+    """Attach algorithmic flops / bytes / a shape label to the next profiled call (no-op when not profiling)."""
+    global _TAG
+    if PROFILE is not None:
+        _TAG = meta
+
+
+def _decode_trace(text: str) -> str:
+    """'(kern<BM, BN>)@int ns::launch(...) [BM = 64, BN = 32]' -> 'kern<64, 32>' (rocprofv3's spelling)."""
+    import re
+    names = []
+    for item in text.split("\n"):
+        if not item:
+            continue
+        kern, _, site = item.partition("@")
+        kern = kern.strip()
+        while kern.startswith("(") and kern.endswith(")"):
+            kern = kern[1:-1].strip()
+        m = re.search(r"\[(?:with )?([^\]]*)\]\s*$", site)
+        env = {}
+        if m:
+            for kv in m.group(1).replace(";", ",").split(","):
+                k, _, v = kv.partition("=")
+                if v:
+                    env[k.strip().split()[-1]] = v.strip()
+        if "<" in kern:
+            head, _, rest = kern.partition("<")
+            args = [a.strip() for a in rest.rsplit(">", 1)[0].split(",")]
+            kern = head + "<" + ", ".join(env.get(a, a) for a in args) + ">"
+        names.append(kern)
+    return " + ".join(names)
+
+
 def call(name: str, *args):
-    check(getattr(lib(), name)(*args), name)
+    global _TAG
+    if PROFILE is None:
+        check(getattr(lib(), name)(*args), name)
+        return
+    l = lib()
+    l.adp_launch_trace(1, None, 0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()  # torch's current stream == the stream passed to the kernel (see stream())
+    check(getattr(l, name)(*args), name)
+    e1.record()
+    buf = ctypes.create_string_buffer(4096)
+    l.adp_launch_trace(0, buf, 4096)
+    PROFILE.append((name, _decode_trace(buf.value.decode()), _TAG or {}, e0, e1))
+    _TAG = None
 
 
 def query(name: str, *args) -> int:

@@ -30,10 +30,18 @@ __device__ __forceinline__ f32x4 adp_mfma16(float a, float b, f32x4 c) {
 // v_rcp_f32 (1 ulp) instead of the IEEE division sequence
 __device__ __forceinline__ float adp_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-#define ADP_LAUNCH(kern, grid, block, stream, ...) \
-  hipLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__)
+#define ADP_LAUNCH(kern, grid, block, stream, ...)                                     \
+  do {                                                                                 \
+    adp_rt_note_launch(#kern, __PRETTY_FUNCTION__);                                    \
+    hipLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__);      \
+  } while (0)
 #define ADP_LAUNCH_OK() (hipGetLastError() == hipSuccess ? ADP_OK : ADP_ERR_LAUNCH)
 #endif
+
+// Launch trace (introspection only, see adp_launch_trace in adp.h): when tracing is on, every ADP_LAUNCH appends
+// "<kernel expression>@<launcher signature with its template arguments>" to a per-thread buffer.  Defined in
+// elementwise.hip.
+void adp_rt_note_launch(const char* kern, const char* site);
 
 #include <stdint.h>
 

@@ -122,7 +122,34 @@ unsigned stream_grid(int64_t n) {
 
 }  // namespace
 
-extern "C" int adp_version(void) { return 100; }
+extern "C" int adp_version(void) { return 101; }
+
+// ---- launch trace (profiling introspection; off by default, host-side only, per thread)
+namespace {
+thread_local bool g_trace_on = false;
+thread_local char g_trace[4096];
+thread_local size_t g_trace_len = 0;
+}  // namespace
+
+void adp_rt_note_launch(const char* kern, const char* site) {
+  if (!g_trace_on) return;
+  const char* parts[4] = {g_trace_len ? "\n" : "", kern, "@", site};
+  for (const char* p : parts)
+    for (; *p && g_trace_len + 1 < sizeof(g_trace); ++p) g_trace[g_trace_len++] = *p;
+  g_trace[g_trace_len] = 0;
+}
+
+extern "C" int64_t adp_launch_trace(int64_t enable, char* buf, int64_t cap) {
+  int64_t n = 0;
+  if (buf && cap > 0) {
+    for (; n + 1 < cap && (size_t)n < g_trace_len; ++n) buf[n] = g_trace[n];
+    buf[n] = 0;
+  }
+  g_trace_len = 0;
+  g_trace[0] = 0;
+  g_trace_on = enable != 0;
+  return n;
+}
 
 extern "C" int adp_v_noise(const float* x, const float* noise, const float* sigma, int64_t B, int64_t per,
                            float* x_noisy, float* v_target, void* stream) {

@@ -15,7 +15,6 @@ from ._C import ConvDesc, WgradDesc, ptr
 
 GN_EPS = 1e-5
 LN_EPS = 1e-5
-PROFILE = None  # bench.py sets this to a list to time every conv launch with HIP events
 
 
 def _ws(nbytes: int, like: Tensor) -> Tensor:
@@ -55,18 +54,11 @@ def conv1d(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int =
     d = ConvDesc(ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(pro_stats), ptr(pro_gamma), ptr(pro_beta), ptr(e_scale),
                  ptr(res), ptr(out), ptr(out_pre), B, R, R1, Lin, M, N, KT, stride, dil, pad, up, int(transposed), prologue, groups,
                  store, sp, e_bstride)
-    if PROFILE is None:
-        _C.call("adp_conv1d", byref(d), _C.stream())
-        return out
-    # instrumented launch (bench.py roofline leg): HIP events on the stream the kernel is launched on
-    tile = _C.query("adp_conv1d_tile", byref(d))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    if _C.PROFILE is not None:  # algorithmic work of this launch: A_in + A_out (+A_res) + weights
+        _C.tag(flops=2 * B * M * N * R * KT,
+               bytes=4 * (B * R * Lin + out.numel() + w.numel() + (res.numel() if res is not None else 0)),
+               shape=f"B{B} R{R} M{M} N{N} KT{KT} s{stride} up{up} tr{int(transposed)} pro{prologue}")
     _C.call("adp_conv1d", byref(d), _C.stream())
-    e1.record()
-    flops = 2 * B * M * N * R * KT
-    nbytes = 4 * (B * R * Lin + out.numel() + w.numel() + (res.numel() if res is not None else 0))
-    PROFILE.append((f"conv_kernel<{tile // 1000},{tile % 1000},KT={KT}>", flops, nbytes, e0, e1))
     return out
 
 
@@ -86,6 +78,9 @@ def conv1d_wgrad(x: Tensor, dy: Tensor, KT: int, *, stride: int = 1, dil: int = 
                   B, R, R1, Lin, M, N, KT, stride, dil, pad, up, prologue, groups, int(accumulate))
     ws = _ws(_C.query("adp_conv1d_wgrad_ws_bytes", byref(d)), x)
     d.ws = ptr(ws)
+    if _C.PROFILE is not None:  # A_x + A_dy + weight-gradient write
+        _C.tag(flops=2 * B * M * N * R * KT, bytes=4 * (B * R * Lin + dy.numel() + dw.numel()),
+               shape=f"B{B} R{R} M{M} N{N} KT{KT} s{stride} up{up} pro{prologue}")
     _C.call("adp_conv1d_wgrad", byref(d), _C.stream())
     return dw, dbias
 
@@ -94,6 +89,7 @@ def gn_stats(x: Tensor, groups: int, eps: float = GN_EPS, out: Optional[Tensor] 
     B, C, L = x.shape
     stats = out if out is not None else torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
     ws = _ws(_C.query("adp_gn_stats_ws_bytes", B, C, L, groups), x)
+    _C.tag(bytes=4 * x.numel(), shape=f"B{B} C{C} L{L}")
     _C.call("adp_gn_stats", ptr(x), B, C, L, groups, eps, ptr(stats), ptr(ws), _C.stream())
     return stats
 
@@ -106,10 +102,12 @@ def gn_silu_bwd(x: Tensor, dact: Tensor, stats: Tensor, gamma: Tensor, beta: Ten
     NS = _C.query("adp_row_nsplit", B * C, L)
     ab = torch.empty((B, C, NS, 2), dtype=torch.float32, device=x.device)
     s = _C.stream()
+    _C.tag(bytes=8 * x.numel(), shape=f"B{B} C{C} L{L}")
     _C.call("adp_gn_silu_bwd_reduce", ptr(x), ptr(dact), ptr(stats), ptr(gamma), ptr(beta), B, C, L, groups, NS,
             ptr(ab), s)
     if dx is None:
         dx = torch.empty_like(x)
+    _C.tag(bytes=(12 + (4 if dres is not None else 0)) * x.numel(), shape=f"B{B} C{C} L{L}")
     _C.call("adp_gn_silu_bwd_apply", ptr(x), ptr(dact), ptr(stats), ptr(gamma), ptr(beta), ptr(ab), ptr(dres), B, C,
             L, groups, NS, ptr(dx), s)
     if dgamma is None:
@@ -128,6 +126,7 @@ def modulation_fwd(x: Tensor, ss: Tensor, ss_bstride: int, eps: float = LN_EPS, 
         y = torch.empty_like(x)
     if stats is None:
         stats = torch.empty((B, L, 2), dtype=torch.float32, device=x.device)
+    _C.tag(bytes=8 * x.numel(), shape=f"B{B} C{C} L{L}")
     _C.call("adp_modulation_fwd", ptr(x), ptr(ss), ss_bstride, B, C, L, eps, ptr(y), ptr(stats), _C.stream())
     return y, stats
 
@@ -138,6 +137,7 @@ def modulation_bwd(x: Tensor, dy: Tensor, ss: Tensor, ss_bstride: int, stats: Te
     if dx is None:
         dx = torch.empty_like(x)
     ws = _ws(_C.query("adp_chan_ln_bwd_ws_bytes", B, C, L), x)
+    _C.tag(bytes=12 * x.numel(), shape=f"B{B} C{C} L{L}")
     _C.call("adp_modulation_bwd", ptr(x), ptr(dy), ptr(ss), ss_bstride, ptr(stats), B, C, L, ptr(dx), ptr(dss),
             dss_bstride, ptr(ws), _C.stream())
     return dx
@@ -169,6 +169,7 @@ def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], act: int = 0, post:
     N = w.shape[0]
     if y is None:
         y = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    _C.tag(bytes=4 * (w.numel() + x.numel() + y.numel()), shape=f"B{B} K{K} N{N}")
     _C.call("adp_linear_fwd", ptr(x), ptr(w), ptr(bias), B, K, N, act, post, ptr(y), N, _C.stream())
     return y
 
@@ -179,6 +180,7 @@ def linear_bwd_data(dy: Tensor, w: Tensor, dxa: Optional[Tensor] = None, accumul
     if dxa is None:
         dxa = torch.empty((B, K), dtype=torch.float32, device=dy.device)
     ws = _ws(_C.query("adp_linear_bwd_data_ws_bytes", B, K, N), dy)
+    _C.tag(bytes=4 * (w.numel() + B * N + dxa.numel()), shape=f"B{B} K{K} N{N}")
     _C.call("adp_linear_bwd_data", ptr(dy), N, ptr(w), B, K, N, int(accumulate), ptr(dxa), ptr(ws), _C.stream())
     return dxa
 
@@ -191,6 +193,7 @@ def linear_bwd_weight(dy: Tensor, x: Tensor, act: int = 0, dw: Optional[Tensor] 
         dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
     if dbias is None and want_bias:
         dbias = torch.empty((N,), dtype=torch.float32, device=dy.device)
+    _C.tag(bytes=4 * (dw.numel() + B * N + x.numel()), shape=f"B{B} K{K} N{N}")
     _C.call("adp_linear_bwd_weight", ptr(dy), N, ptr(x), B, K, N, act, int(accumulate), ptr(dw), ptr(dbias),
             _C.stream())
     return dw, dbias
@@ -231,6 +234,7 @@ def skipmod_bwd(g: Tensor, x: Tensor, scale: Tensor, scale_bstride: int, dscale:
     if dx is None:
         dx = torch.empty_like(x)
     ws = _ws(_C.query("adp_skipmod_bwd_ws_bytes", B, C, L), x)
+    _C.tag(bytes=12 * x.numel(), shape=f"B{B} C{C} L{L}")
     _C.call("adp_skipmod_bwd", ptr(g), ptr(x), ptr(scale), scale_bstride, B, C, L, ptr(dx), ptr(dscale),
             dscale_bstride, ptr(ws), _C.stream())
     return dx

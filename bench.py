@@ -71,41 +71,81 @@ def cpu_baseline(batch: int, threads: int = 16, budget_s: float = 25.0):
                       f"CPU, {cores} threads, after 1 warm-up step), scaled to the bench step of {batch} samples"}
 
 
-def roofline_leg(model, x):
-    """Times every conv launch of one eager step with HIP events on the launch stream and reports the kernel with
-    the largest total time (the dominant kernel) against the fp32 MFMA peak, plus the HBM-bound depth-0/1 ConvBlock
-    instantiation against the HBM peak."""
-    from audio_diffusion_pytorch_amd import ops
+def roofline_leg(model, x, top: int = 14):
+    """One instrumented eager step: every C-ABI call is bracketed by HIP events on the stream it launches on
+    (`_C.call`), labelled with the kernel instantiation it dispatched (the spelling rocprofv3 prints) and with its
+    ALGORITHMIC flops / bytes.  Reports
+      roofline                 the single kernel with the largest total time, against the bound that limits it
+                               (f32 MFMA peak for the implicit-GEMM convs, HBM for everything else);
+      roofline_hbm_convblock   the depth-0/1 ConvBlock convs (north_star's HBM target) against the HBM peak;
+      kernels                  the `top` kernels by total time.
+    `traffic` (HBM bytes per launch from the rocprofv3 PMC passes) is looked up in profiles/pmc_traffic.json, which
+    tools/pmc_summary.py writes from the FETCH_SIZE / WRITE_SIZE passes of this same command."""
+    from audio_diffusion_pytorch_amd import _C
     for p in model.parameters():
         p.grad = None
-    ops.PROFILE = []
-    loss = model(x)
-    loss.backward()
-    torch.cuda.synchronize()
-    recs, ops.PROFILE = ops.PROFILE, None
+    _C.PROFILE = []
+    try:
+        loss = model(x)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        recs, _C.PROFILE = _C.PROFILE, None
     agg = {}
-    for name, flops, nbytes, e0, e1 in recs:
-        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
-        a[0] += 1
-        a[1] += e0.elapsed_time(e1)
-        a[2] += flops
-        a[3] += nbytes
-    dom = max(agg.items(), key=lambda kv: kv[1][1])
-    n, ms, fl, by = dom[1]
-    tf = fl / (ms * 1e-3) / 1e12
-    out = {"bound": "mfma", "kernel": dom[0], "launches": n, "avg_ms": round(ms / n, 4),
-           "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-           "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None}
-    extra = {}
-    for k, (cn, cms, cfl, cby) in agg.items():
-        extra[k] = {"launches": cn, "total_ms": round(cms, 3), "tflops": round(cfl / (cms * 1e-3) / 1e12, 2),
-                    "algo_gbps": round(cby / (cms * 1e-3) / 1e9, 1)}
-    hb = extra.get("conv_kernel<32,128,KT=3>")
+    for call, kern, meta, e0, e1 in recs:
+        a = agg.setdefault(kern or call, {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0})
+        a["launches"] += 1
+        a["ms"] += e0.elapsed_time(e1)
+        a["flops"] += meta.get("flops", 0)
+        a["bytes"] += meta.get("bytes", 0)
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f).get("kernels", {})
+    except (OSError, ValueError):
+        pass
+
+    def entry(name, a):
+        sec = a["ms"] * 1e-3
+        tf, gb = a["flops"] / sec / 1e12, a["bytes"] / sec / 1e9
+        # bound: the roof this kernel would hit first at its algorithmic intensity
+        mfma = a["flops"] > 0 and (a["flops"] / PEAK_F32_MFMA_TFLOPS / 1e12) > (a["bytes"] / PEAK_HBM_GBPS / 1e9)
+        e = {"bound": "mfma" if mfma else "hbm", "kernel": name, "launches": a["launches"],
+             "avg_us": round(a["ms"] / a["launches"] * 1e3, 2),
+             "achieved": round(tf, 2) if mfma else round(gb, 1), "peak": PEAK_F32_MFMA_TFLOPS if mfma else PEAK_HBM_GBPS,
+             "unit": "TFLOP/s" if mfma else "GB/s"}
+        e["frac"] = round(e["achieved"] / e["peak"], 4)
+        t = pmc.get(name)
+        e["traffic"] = t.get("hbm_bytes_per_launch") if t else None
+        if e["traffic"] is not None:
+            e["algorithmic_bytes_per_launch"] = a["bytes"] // a["launches"]
+        return e
+
+    total_ms = sum(a["ms"] for a in agg.values())
+    order = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
+    single = [(k, a) for k, a in order if " + " not in k and (a["flops"] or a["bytes"])]
+    rf = entry(*single[0])
+    rf["share_of_step"] = round(single[0][1]["ms"] / total_ms, 4)
+    # north_star's HBM target: the ConvBlock convs of depths 0-1 (GN+SiLU prologue, k=3, C = 8 / 32)
+    hb = {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0}
+    names = set()
+    for call, kern, meta, e0, e1 in recs:
+        sh = meta.get("shape", "")
+        if call == "adp_conv1d" and " pro1" in sh and " tr0" in sh and (" R8 " in sh or " R32 " in sh):
+            hb["launches"] += 1
+            hb["ms"] += e0.elapsed_time(e1)
+            hb["bytes"] += meta["bytes"]
+            names.add(kern)
     hbm = None
-    if hb:
-        hbm = {"bound": "hbm", "kernel": "conv_kernel<32,128,KT=3> (depth 0-1 ConvBlocks)", "achieved": hb["algo_gbps"],
-               "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(hb["algo_gbps"] / PEAK_HBM_GBPS, 4)}
-    return out, hbm, extra
+    if hb["launches"]:
+        hbm = entry(" | ".join(sorted(names)), hb)
+        hbm["what"] = "forward ConvBlock convs (GroupNorm+SiLU prologue, k=3) of depths 0-1: A_in + A_out (+A_res) bytes"
+    table = {}
+    for k, a in order[:top]:
+        e = entry(k, a)
+        table[k] = {"launches": e["launches"], "avg_us": e["avg_us"], "total_ms": round(a["ms"], 3),
+                    "bound": e["bound"], "achieved": e["achieved"], "unit": e["unit"], "frac": e["frac"]}
+    return rf, hbm, table, round(total_ms, 3)
 
 
 def main():
@@ -205,11 +245,12 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_roofline:
         try:
-            rf, hbm, extra = roofline_leg(model.module if world > 1 else model, x)
+            rf, hbm, extra, eager_ms = roofline_leg(model.module if world > 1 else model, x)
             line["roofline"] = rf
             if hbm:
                 line["roofline_hbm_convblock"] = hbm
             line["kernels"] = extra
+            line["instrumented_eager_step_ms"] = eager_ms
         except Exception as e:
             line["roofline"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -31,6 +31,13 @@ extern "C" {
 
 int adp_version(void);
 
+/* Profiling introspection (host side only, per calling thread): copies the list of kernels launched by this
+ * thread's adp_* calls since the previous adp_launch_trace call into buf (";"-separated
+ * "<kernel expression>@<launcher signature incl. template arguments>", NUL terminated, at most cap bytes), clears
+ * it, and switches recording on (enable != 0) or off.  Returns the number of bytes written.  bench.py uses it to
+ * label each timed launch with the kernel instantiation name rocprofv3 reports. */
+int64_t adp_launch_trace(int64_t enable, char* buf, int64_t cap);
+
 /* ------------------------------------------------------------------------------------------
  * Fused implicit-GEMM Conv1d on the f32 matrix cores (v_mfma_f32_32x32x2_f32).
  *
