@@ -11,7 +11,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libadp_hip.so")
-SOURCES = ["conv1d.hip", "conv_mm.hip", "wgrad_mm.hip", "conv_direct.hip", "wgrad_direct.hip", "norm.hip", "elementwise.hip", "linear.hip", "attention.hip"]
+SOURCES = ["conv1d.hip", "conv_mm.hip", "conv_mm_m64.hip", "conv_mm_m32.hip", "wgrad_mm.hip", "conv_direct.hip", "wgrad_direct.hip", "norm.hip", "elementwise.hip", "linear.hip", "attention.hip"]
 
 
 def _newest_mtime(paths):
@@ -24,7 +24,7 @@ def sources():
 
 def build(force: bool = False, verbose: bool = True) -> str:
     srcs = sources()
-    deps = srcs + [os.path.join(CSRC, "adp_rt.h"), os.path.join(CSRC, "conv_internal.h"), os.path.join(REPO_ROOT, "include", "adp.h")]
+    deps = srcs + [os.path.join(CSRC, "adp_rt.h"), os.path.join(CSRC, "conv_internal.h"), os.path.join(CSRC, "conv_mm_impl.h"), os.path.join(REPO_ROOT, "include", "adp.h")]
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= _newest_mtime(deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1,0 +1,352 @@
+// Implicit-GEMM Conv1d kernel for gfx950: kernel 1 / 3 at stride 1 (plus the kernel = stride = 2 / 4 DownsampleItem
+// and the nearest-upsample UpsampleItem variants), channel counts that are multiples of 32.
+// This is the kernel the MFMA-bound half of the U-Net lives in (ResnetItem ConvBlocks and their data
+// gradients at depths 1-8; /root/reference/audio_diffusion_pytorch/components.py:89).
+//
+// Shape of the machine it is written for:
+//   * v_mfma_f32_32x32x2_f32 retires one 32x32x2 tile per 64 cycles per SIMD, so operand traffic is tiny and the
+//     only thing that matters is that every SIMD always has an MFMA to issue.  Measured on MI355X
+//     (tools/probe/mfma_probe.hip): a loop of "LDS fragment read + MFMA, one barrier per 12-24 MFMAs" sustains
+//     128-138 TF of the 157 TF peak, but the same loop with the operand staging (global load -> GroupNorm+SiLU ->
+//     ds_write) in the SAME waves ran at 80 TF: the staging phase and the MFMA phase of a chunk did not overlap
+//     (staging alone 0.84 us per chunk, MFMAs alone 1.7 us, together 2.3 us).
+//   * so the block is WAVE-SPECIALISED: NLD = 4 loader waves (one per SIMD) own the global -> register ->
+//     (prologue) -> LDS path and never touch the matrix cores; the MMA waves only read fragments and issue MFMAs.
+//     While the MMA waves are inside chunk c, the loaders write chunk c+1 into the other LDS buffer; one
+//     workgroup barrier per chunk hands the buffers over:
+//         loader:  store chunk c -> LDS[c&1] ; issue global loads of chunk c+PD ; barrier B_c
+//         MMA   :  barrier B_c ; MFMAs over LDS[c&1]
+//     (LDS[(c+1)&1] is rewritten by the loaders during iteration c+1, after every MMA wave has passed B_{c+1},
+//     i.e. finished chunk c-1's sibling buffer... see the hazard note at the loops).
+//   * an MMA wave owns a 32 x 64 output tile (two accumulator tiles sharing the A fragment).  Deep layers have few
+//     output tiles (depth 7 at batch 4: 256 tiles of 64x64 for 256 CUs), so the MMA waves of a block split K:
+//     NKG = BKT/8 wave groups each take 8 of the BKT channels of every staged chunk; the partial tiles meet in LDS
+//     at the end and every MMA wave sums + stores a quarter of the rows (fixed order: deterministic).
+//   * weights are copied as they lie in memory:
+//       forward   As[m][r*KT+t]  (row = BKT channels x KT taps, contiguous in w[M][R][KT]); the A fragment
+//                 of lane (m, hi) is 4 channels x KT taps = KT ds_read_b128 (row stride = 4 mod 8 dwords: no
+//                 bank conflicts);
+//       gradient  As[k][m*KT+t]  (row = BM outputs x KT taps, contiguous in w[R][M][KT]); fragment reads are
+//                 stride-KT ds_read_b32 (conflict-free for KT = 1, 3).
+//     The MFMA K pair is (channel c + 4*hi), which both layouts share.
+//   * the GroupNorm+SiLU prologue is applied by the loaders between the global load and the LDS store, from
+//     per-(b,channel) constants kept in LDS; zero padding is applied after the activation, like nn.Conv1d.
+//   * the 1-D grid is decoded XCD-aware: workgroup id -> XCD id%8 (round-robin dispatch), so ids are permuted
+//     to give each XCD a contiguous range of weight row tiles; its 4 MiB L2 then holds 1/8 of the weights.
+#pragma once
+#include "adp_rt.h"
+#include "adp.h"
+#include "conv_internal.h"
+
+namespace {
+
+constexpr int MM_PRO_RMAX = 1024; // channels whose GroupNorm constants fit the LDS table
+constexpr int MM_BN = 64;         // output positions per block
+constexpr int MM_NLD = 4;         // loader waves per block
+
+// four consecutive virtual positions u0..u0+3 (u0 % 4 == 0) of a row upsampled by UP: 4 / 2 / 1 source floats
+template <int UP>
+__device__ __forceinline__ f32x4 load_xquad(const float* p) {
+  f32x4 v;
+  if (UP == 1) {
+    v = *reinterpret_cast<const f32x4*>(p);
+  } else if (UP == 2) {
+    const f32x2 t = *reinterpret_cast<const f32x2*>(p);
+    v[0] = t[0];
+    v[1] = t[0];
+    v[2] = t[1];
+    v[3] = t[1];
+  } else {
+    const float t = *p;
+    v[0] = t;
+    v[1] = t;
+    v[2] = t;
+    v[3] = t;
+  }
+  return v;
+}
+
+template <int A, int B>
+struct cmax {
+  static constexpr int v = A > B ? A : B;
+};
+
+// BM: output channels per block (32 / 64); S: conv stride (1, or kernel = stride = 2 / 4 for DownsampleItem);
+// UP: nearest-upsample factor folded into the X loader (UpsampleItem: the [B, C, L*UP] intermediate is never
+// materialised); BKT: channels per staged chunk; PD: loader prefetch distance in chunks (register stages).
+template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD>
+__global__ __launch_bounds__(((BM / 32) * (BKT / 8) + MM_NLD) * 64) void conv_mm_kernel(adp_conv_desc d) {
+  constexpr int BN = MM_BN, NKG = BKT / 8, NQM = BM / 32;
+  constexpr int NMMA = NQM * NKG;                   // MMA waves
+  constexpr int NLT = MM_NLD * 64;                  // loader threads
+  constexpr int QK = BKT * KT;
+  constexpr int AS = TR ? (BM * KT + 4) : (QK + 4);  // A row stride in floats
+  constexpr int AROWS = TR ? BKT : BM;
+  constexpr int AQ = (TR ? BM * KT : QK) / 4;        // float4 per A row
+  constexpr int XSP = BN * S + 8, XQ = XSP / 4;      // X row: (virtual) positions n0*S-4 .. n0*S+BN*S+3
+  constexpr int A_ELEMS = AROWS * AS, X_ELEMS = BKT * XSP;
+  constexpr int NA4 = (AROWS * AQ + NLT - 1) / NLT, NX4 = (BKT * XQ + NLT - 1) / NLT;
+  constexpr int RED = NMMA * 2048;                   // every MMA wave parks its two accumulator tiles
+  constexpr int SM = cmax<2 * (A_ELEMS + X_ELEMS), RED>::v;
+  static_assert(BKT % 8 == 0 && NKG >= 1 && NKG <= 4, "8 channels per K group");
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  __shared__ float Pa[PRO == 1 ? MM_PRO_RMAX : 1], Pb[PRO == 1 ? MM_PRO_RMAX : 1];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int M = (int)d.M, R = (int)d.R, L = (int)d.Lin, N = (int)d.N;
+  const int dil = (int)d.dil, pad = (int)d.pad;
+  const int Lv = L * UP;  // length of the (virtual) upsampled row
+
+  // ---- XCD-aware decode of the 1-D grid
+  int id = blockIdx.x;
+  const int total = gridDim.x;
+  if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+  const int ntn = (N + BN - 1) / BN, per_m = ntn * (int)d.B;
+  const int mt = id / per_m, rem = id - mt * per_m;
+  const int b = rem / ntn, nt = rem - b * ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int nchunks = R / BKT;
+  const int nrounds = ((nchunks + PD - 1) / PD) * PD;  // ghost iterations (barrier only) pad the loop to PD
+
+  if (PRO == 1) {
+    const int cpg = R / (int)d.groups;
+    for (int r = tid; r < R; r += (NMMA + MM_NLD) * 64) {
+      const int g = r / cpg;
+      const float mean = d.pro_stats[((int64_t)b * d.groups + g) * 2];
+      const float ga = (d.pro_gamma ? d.pro_gamma[r] : 1.0f) * d.pro_stats[((int64_t)b * d.groups + g) * 2 + 1];
+      Pa[r] = ga;
+      Pb[r] = (d.pro_beta ? d.pro_beta[r] : 0.0f) - mean * ga;
+    }
+  }
+
+  if (wave >= NMMA) {
+    // =========================== loader waves ===========================
+    const int lt = tid - NMMA * 64;
+    const float* xb = d.x + (int64_t)b * R * L;
+    const float* wbase = TR ? d.w + (int64_t)m0 * KT : d.w + (int64_t)m0 * R * KT;
+    // per-thread staging slots (chunk independent parts).  Slot indices wrap around instead of being guarded: a
+    // few threads then stage the same 16 bytes twice, and the loop body stays branch-free.
+    int a_src[NA4], a_dst[NA4];
+#pragma unroll
+    for (int i = 0; i < NA4; ++i) {
+      const int e = (lt + i * NLT) % (AROWS * AQ);
+      const int row = e / AQ, qq = e - row * AQ;
+      a_dst[i] = row * AS + 4 * qq;
+      a_src[i] = TR ? row * M * KT + 4 * qq : row * R * KT + 4 * qq;
+    }
+    int x_src[NX4], x_dst[NX4], x_row[NX4];
+    bool x_ok[NX4];
+#pragma unroll
+    for (int i = 0; i < NX4; ++i) {
+      const int e = (lt + i * NLT) % (BKT * XQ);
+      const int rl = e / XQ, pq = e - rl * XQ;
+      const int u = n0 * S - 4 + 4 * pq;
+      x_dst[i] = rl * XSP + 4 * pq;
+      x_ok[i] = (u >= 0 && u < Lv);  // Lv % 4 == 0: a quad is entirely inside or outside the row
+      x_src[i] = rl * L + (x_ok[i] ? u / UP : 0);  // nearest upsample: source index = floor(u / UP), exact
+      x_row[i] = rl;
+    }
+    // Chunk k travels  global -> register stage k % PD -> LDS[k & 1].  Loads are unconditional (the tail re-reads
+    // the last chunk, which is never consumed) so that the number of loads in flight is a compile-time constant
+    // and the compiler waits with vmcnt(loads of the younger stages) instead of vmcnt(0).
+    f32x4 ra[PD][NA4], rx[PD][NX4];
+    auto load_chunk = [&](f32x4 (&a)[NA4], f32x4 (&x)[NX4], int chunk) {
+      const int rn = (chunk < nchunks ? chunk : nchunks - 1) * BKT;
+      const float* wp = TR ? wbase + (int64_t)rn * M * KT : wbase + rn * KT;
+#pragma unroll
+      for (int i = 0; i < NA4; ++i) a[i] = *reinterpret_cast<const f32x4*>(wp + a_src[i]);
+      const float* xp = xb + (int64_t)rn * L;
+#pragma unroll
+      for (int i = 0; i < NX4; ++i) x[i] = load_xquad<UP>(xp + x_src[i]);
+    };
+    auto store_chunk = [&](const f32x4 (&a)[NA4], const f32x4 (&x)[NX4], int chunk) {
+      const int r0 = (chunk < nchunks ? chunk : nchunks - 1) * BKT;
+      float* Ab = smem + (chunk & 1) * (A_ELEMS + X_ELEMS);
+      float* Xb = Ab + A_ELEMS;
+#pragma unroll
+      for (int i = 0; i < NA4; ++i) *reinterpret_cast<f32x4*>(Ab + a_dst[i]) = a[i];
+#pragma unroll
+      for (int i = 0; i < NX4; ++i) {
+        f32x4 v = x[i];
+        if (PRO == 1) {
+          const float pa = Pa[r0 + x_row[i]], pb = Pb[r0 + x_row[i]];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = adp_silu_fast(fmaf(v[j], pa, pb));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = x_ok[i] ? v[j] : 0.0f;  // zero padding is applied after the activation
+        *reinterpret_cast<f32x4*>(Xb + x_dst[i]) = v;
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < PD; ++s) load_chunk(ra[s], rx[s], s);
+    if (PRO == 1) __syncthreads();  // Pa / Pb complete
+    // Hazard note: the store of chunk c goes to LDS[c & 1], last read by the MFMAs of chunk c-2; every MMA wave
+    // finished those before it arrived at barrier B_{c-1}, which this wave passed before starting iteration c.
+    for (int c0 = 0; c0 < nrounds; c0 += PD) {
+#pragma unroll
+      for (int s = 0; s < PD; ++s) {
+        store_chunk(ra[s], rx[s], c0 + s);   // ghost chunks (>= nchunks) restage the last chunk: never consumed
+        load_chunk(ra[s], rx[s], c0 + s + PD);
+        __syncthreads();                     // B_c
+      }
+    }
+    __syncthreads();  // partial tiles parked
+    __syncthreads();  // (pairs with the barrier after the K-group exchange below)
+    return;
+  }
+
+  // =========================== MMA waves ===========================
+  const int mq = wave % NQM, kg = wave / NQM;
+  const int wm0 = mq * 32;
+  f32x16 acc[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ni][r] = 0.0f;
+
+  // lane-constant fragment offsets
+  const int xfrag = 4 * hi * XSP + l31 * S + 4 - pad;                 // + ni*32*S + (ci + c) * XSP + t * dil
+  const int afrag = TR ? 4 * hi * AS + (wm0 + l31) * KT                // + (ci + c) * AS + (KT - 1 - t)
+                       : (wm0 + l31) * AS + 4 * hi * KT;               // + ci * KT + (c * KT + t)
+  const int ci = kg * 8;
+  if (PRO == 1) __syncthreads();
+  for (int c = 0; c < nrounds; ++c) {
+    __syncthreads();  // B_c: chunk c is in LDS[c & 1]
+    if (c < nchunks) {
+      const float* Ab = smem + (c & 1) * (A_ELEMS + X_ELEMS);
+      const float* Xb = Ab + A_ELEMS;
+      if (!TR) {
+        float av[4 * KT];
+        const float* ap = Ab + afrag + ci * KT;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(ap + 4 * j);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) av[4 * j + k] = q[k];
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+          for (int t = 0; t < KT; ++t) {
+            const float x0 = Xb[xfrag + (ci + cc) * XSP + t * dil];
+            const float x1 = Xb[xfrag + 32 * S + (ci + cc) * XSP + t * dil];
+            acc[0] = adp_mfma32(av[cc * KT + t], x0, acc[0]);
+            acc[1] = adp_mfma32(av[cc * KT + t], x1, acc[1]);
+          }
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+          for (int t = 0; t < KT; ++t) {
+            const float a = Ab[afrag + (ci + cc) * AS + (KT - 1 - t)];
+            const float x0 = Xb[xfrag + (ci + cc) * XSP + t * dil];
+            const float x1 = Xb[xfrag + 32 * S + (ci + cc) * XSP + t * dil];
+            acc[0] = adp_mfma32(a, x0, acc[0]);
+            acc[1] = adp_mfma32(a, x1, acc[1]);
+          }
+      }
+    }
+  }
+  __syncthreads();  // the staging buffers are free
+
+  // ---- K-group exchange through LDS: every MMA wave parks both tiles, then sums + stores accumulator rows
+  // [16/NKG * kg, 16/NKG * (kg+1)) of its (mq) tile over the NKG groups in the fixed order 0..NKG-1.
+  constexpr int RPW = 16 / NKG;  // accumulator registers (= output rows per half-wave) finished per wave
+  if (NKG > 1) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      float* rp = smem + ((kg * NQM + mq) * 2 + ni) * 1024 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rp[r * 64] = acc[ni][r];
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue (same contract as adp_conv1d's generic kernel)
+  const int sp = (int)d.sp;
+  const int64_t ebs = d.e_bstride ? d.e_bstride : M;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int n = n0 + ni * 32 + l31;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int r = kg * RPW + rr;
+      float v;
+      if (NKG > 1) {
+        v = 0.0f;
+#pragma unroll
+        for (int g = 0; g < NKG; ++g) v += smem[((g * NQM + mq) * 2 + ni) * 1024 + r * 64 + lane];
+      } else {
+        v = acc[ni][rr];
+      }
+      const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const bool ok = (m < M) && (n < N);
+      if (ok) {
+        if (d.bias) v += d.bias[m];
+        if (d.out_pre) d.out_pre[((int64_t)b * M + m) * N + n] = v;
+        if (d.e_scale) v *= d.e_scale[b * ebs + m];
+      } else {
+        v = 0.0f;
+      }
+      if (d.store == 0) {
+        if (ok) {
+          const int64_t o = ((int64_t)b * M + m) * N + n;
+          if (d.res) v += d.res[o];
+          d.out[o] = v;
+        }
+      } else if (d.store == 1) {
+        if (ok) {
+          const int64_t o = ((int64_t)b * (M / sp) + m / sp) * ((int64_t)N * sp) + (int64_t)n * sp + (m % sp);
+          if (d.res) v += d.res[o];
+          d.out[o] = v;
+        }
+      } else {
+        v += __shfl_xor(v, 1, 64);
+        if (sp == 4) v += __shfl_xor(v, 2, 64);
+        if (ok && (l31 % sp) == 0) {
+          const int64_t o = ((int64_t)b * M + m) * (N / sp) + n / sp;
+          if (d.res) v += d.res[o];
+          d.out[o] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD>
+int launch_mm(const adp_conv_desc& d, void* stream) {
+  const int64_t blocks = (d.M / BM) * adp_cdiv(d.N, MM_BN) * d.B;
+  ADP_LAUNCH((conv_mm_kernel<BM, KT, S, UP, TR, PRO, BKT, PD>), dim3((unsigned)blocks),
+             dim3(((BM / 32) * (BKT / 8) + MM_NLD) * 64), stream, d);
+  return ADP_LAUNCH_OK();
+}
+
+// short K (one or two chunks: the HBM-bound shallow layers) runs without ghost iterations
+template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT>
+int launch_pd(const adp_conv_desc& d, void* stream) {
+  if (d.R / BKT >= 4) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 2>(d, stream);
+  return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1>(d, stream);
+}
+
+// every (kernel, stride, upsample, direction, prologue) variant of one block tile
+template <int BM>
+int run_tile(const adp_conv_desc& d, void* stream) {
+  const bool tr = d.transposed != 0;
+  if (d.stride == 2) return launch_pd<BM, 2, 2, 1, false, 0, 32>(d, stream);
+  if (d.stride == 4) return launch_pd<BM, 4, 4, 1, false, 0, 16>(d, stream);
+  if (d.up == 2) return launch_pd<BM, 3, 1, 2, false, 0, 32>(d, stream);
+  if (d.up == 4) return launch_pd<BM, 3, 1, 4, false, 0, 32>(d, stream);
+  if (d.KT == 3) {
+    if (d.prologue == 1)
+      return tr ? launch_pd<BM, 3, 1, 1, true, 1, 32>(d, stream) : launch_pd<BM, 3, 1, 1, false, 1, 32>(d, stream);
+    return tr ? launch_pd<BM, 3, 1, 1, true, 0, 32>(d, stream) : launch_pd<BM, 3, 1, 1, false, 0, 32>(d, stream);
+  }
+  if (d.prologue == 1)
+    return tr ? launch_pd<BM, 1, 1, 1, true, 1, 32>(d, stream) : launch_pd<BM, 1, 1, 1, false, 1, 32>(d, stream);
+  return tr ? launch_pd<BM, 1, 1, 1, true, 0, 32>(d, stream) : launch_pd<BM, 1, 1, 1, false, 0, 32>(d, stream);
+}
+
+}  // namespace

@@ -121,6 +121,18 @@ def roofline_leg(model, x, top: int = 14):
             e["algorithmic_bytes_per_launch"] = a["bytes"] // a["launches"]
         return e
 
+    detail_path = os.environ.get("ADP_BENCH_DETAIL")
+    if detail_path:  # per (kernel, shape) table for kernel work; not part of the bench line
+        det = {}
+        for call, kern, meta, e0, e1 in recs:
+            a = det.setdefault((kern or call) + " :: " + meta.get("shape", ""), [0, 0.0, 0, 0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1)
+            a[2] += meta.get("flops", 0)
+            a[3] += meta.get("bytes", 0)
+        with open(detail_path, "w") as f:
+            for k, (n, ms, fl, by) in sorted(det.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{ms:8.3f} ms  n={n:3d}  avg {ms / n * 1e3:7.1f} us  {fl / ms / 1e9:6.1f} TF  {by / ms / 1e6:7.1f} GB/s  {k}\n")
     total_ms = sum(a["ms"] for a in agg.values())
     order = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
     single = [(k, a) for k, a in order if " + " not in k and (a["flops"] or a["bytes"])]

@@ -9,12 +9,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(REPO_ROOT, "audio_diffusion_pytorch_amd", "csrc")
 LIB_PATH = os.path.join(HERE, "libadp_emul.so")
-SOURCES = ["conv1d.hip", "conv_mm.hip", "wgrad_mm.hip", "conv_direct.hip", "wgrad_direct.hip", "norm.hip", "elementwise.hip", "linear.hip", "attention.hip"]
+SOURCES = ["conv1d.hip", "conv_mm.hip", "conv_mm_m64.hip", "conv_mm_m32.hip", "wgrad_mm.hip", "conv_direct.hip", "wgrad_direct.hip", "norm.hip", "elementwise.hip", "linear.hip", "attention.hip"]
 
 
 def build(force: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, "adp_rt.h"), os.path.join(CSRC, "conv_internal.h"), os.path.join(HERE, "adp_rt_emul.h"),
+    deps = srcs + [os.path.join(CSRC, "adp_rt.h"), os.path.join(CSRC, "conv_internal.h"), os.path.join(CSRC, "conv_mm_impl.h"), os.path.join(HERE, "adp_rt_emul.h"),
                    os.path.join(REPO_ROOT, "include", "adp.h")]
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
         return LIB_PATH

@@ -122,6 +122,11 @@ MM_CASES = [
     (1, 32, 64, 64 * 768, 1, 0, 1),   # 768 tiles -> 64x64 tile, 1 K group, kernel 1
     (2, 64, 96, 100, 1, 0, 1),        # M % 64 != 0 -> 32-row tile, kernel 1, 2 chunks
     (1, 32, 32, 64, 3, 3, 3),         # dilation 3
+    (1, 32, 64, 64 * 1024, 1, 0, 1),  # 1024 tiles -> 64x128 tile (T2), guarded single-chunk pipeline
+    (2, 96, 64, 64 * 512, 1, 0, 1),   # T2, 3 chunks -> prefetch distance 2 with a remainder iteration
+    (2, 32, 32, 128 * 256, 3, 1, 1),  # M % 64 != 0 with 512 blocks -> 32x128 tile (T3)
+    (1, 128, 64, 64 * 200, 3, 1, 1),  # 64x64 tile (T0), 4 chunks -> unguarded 2-stage pipeline
+    (1, 160, 32, 192, 3, 1, 1),       # 32x64 tile (T1), 5 chunks (odd) -> remainder iteration
 ]
 
 
