@@ -47,17 +47,24 @@ __device__ __forceinline__ f32x4 wg_load_xquad(const float* p) {
   return v;
 }
 
-template <int BM, int BR, int NKG, int KT, int S, int UP, int PRO>
-__global__ __launch_bounds__((BM / 32) * (BR / 32) * NKG * 64) void wgrad_mm_kernel(adp_wgrad_desc d, int CPB, int CPS,
-                                                                                  int nsplit) {
-  constexpr int BKN = WG_BKN, PPW = BKN / NKG;
-  constexpr int NQR = BR / 32, NQ = (BM / 32) * NQR, NW = NQ * NKG, NT = NW * 64;
+constexpr int WG_NLD = 4;  // loader waves per block
+
+// BM = BR: edge of the (m, r) tile (64 / 32); PD: loader prefetch distance in chunks (register stages).
+// Wave-specialised like conv_mm_impl.h: WG_NLD loader waves stage dy / x chunks (global -> registers ->
+// GroupNorm+SiLU -> LDS) one chunk ahead of the MMA waves, which only read fragments and issue MFMAs; one
+// workgroup barrier per chunk hands the double-buffered LDS tiles over.  MMA wave = one 32x32 (m, r) quad x KT taps
+// (KT accumulator tiles sharing the dy fragment); NKG wave groups split every chunk's 64 positions.
+template <int BM, int KT, int S, int UP, int PRO, int PD>
+__global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NLD) * 64) void wgrad_mm_kernel(
+    adp_wgrad_desc d, int CPB, int CPS, int nsplit) {
+  constexpr int BR = BM, BKN = WG_BKN, NKG = (BM == 64 ? 2 : 4), PPW = BKN / NKG;
+  constexpr int NQR = BR / 32, NQ = (BM / 32) * NQR, NMMA = NQ * NKG, NLT = WG_NLD * 64;
   constexpr int PAD = (KT - 1) / 2;
   constexpr int HALO = (S == 1) ? 4 : 0;                       // positions staged on each side of the chunk's x rows
   constexpr int DS = BKN + 4, XS = BKN * S + 2 * HALO + 4;     // row strides (floats), both 4 mod 8
   constexpr int DQ = BKN / 4, XQ = (BKN * S + 2 * HALO) / 4;
   constexpr int D_ELEMS = BM * DS, X_ELEMS = BR * XS;
-  constexpr int ND4 = (BM * DQ + NT - 1) / NT, NX4 = (BR * XQ + NT - 1) / NT;
+  constexpr int ND4 = (BM * DQ + NLT - 1) / NLT, NX4 = (BR * XQ + NLT - 1) / NLT;
   constexpr int RED = NQ * KT * 1024;
   constexpr int STAGE = 2 * (D_ELEMS + X_ELEMS);
   constexpr int SM = STAGE > RED ? STAGE : RED;
@@ -66,8 +73,6 @@ __global__ __launch_bounds__((BM / 32) * (BR / 32) * NKG * 64) void wgrad_mm_ker
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
-  const int quad = wave % NQ, kg = wave / NQ;
-  const int wm0 = (quad / NQR) * 32, wr0 = (quad % NQR) * 32;
 
   const int M = (int)d.M, R = (int)d.R, L = (int)d.Lin, N = (int)d.N, G = (int)d.groups;
   const int Lv = L * UP;
@@ -75,169 +80,213 @@ __global__ __launch_bounds__((BM / 32) * (BR / 32) * NKG * 64) void wgrad_mm_ker
   const int m0 = blockIdx.y * BM, r0 = blockIdx.z * BR;
   const int total = (int)d.B * CPB;
   const int cbeg = split * CPS, cend = (cbeg + CPS < total) ? cbeg + CPS : total;
-  const bool do_bias = (d.dbias != nullptr) && (blockIdx.z == 0);
+  const int nloc = cend - cbeg;                               // chunks of this workgroup (>= 1)
+  const int nrounds = ((nloc + PD - 1) / PD) * PD;            // ghost iterations (barrier only) pad the loop to PD
+  const bool direct = (nsplit == 1);
+  const int64_t cnt = (int64_t)M * R * KT;
 
-  // ---- staging slots (chunk independent parts); slot indices wrap instead of being guarded
-  int d_src[ND4], d_dst[ND4], d_pos[ND4];
+  if (wave >= NMMA) {
+    // =========================== loader waves ===========================
+    const int lt = tid - NMMA * 64;
+    const bool do_bias = (d.dbias != nullptr) && (blockIdx.z == 0);
+    // staging slots (chunk independent parts); slot indices wrap instead of being guarded
+    int d_src[ND4], d_dst[ND4], d_pos[ND4];
 #pragma unroll
-  for (int i = 0; i < ND4; ++i) {
-    const int e = (tid + i * NT) % (BM * DQ);
-    const int row = e / DQ, q = e - row * DQ;
-    d_dst[i] = row * DS + 4 * q;
-    d_src[i] = (m0 + row) * N + 4 * q;
-    d_pos[i] = 4 * q;
-  }
-  int x_src[NX4], x_dst[NX4], x_pos[NX4], x_st[NX4];
-  float x_ga[NX4], x_be[NX4];
-#pragma unroll
-  for (int i = 0; i < NX4; ++i) {
-    const int e = (tid + i * NT) % (BR * XQ);
-    const int row = e / XQ, q = e - row * XQ;
-    x_dst[i] = row * XS + 4 * q;
-    x_src[i] = (r0 + row) * L;
-    x_pos[i] = 4 * q - HALO;
-    if (PRO == 1) {
-      const int r = r0 + row;
-      x_st[i] = (r / (R / G)) * 2;
-      x_ga[i] = d.pro_gamma ? d.pro_gamma[r] : 1.0f;
-      x_be[i] = d.pro_beta ? d.pro_beta[r] : 0.0f;
+    for (int i = 0; i < ND4; ++i) {
+      const int e = (lt + i * NLT) % (BM * DQ);
+      const int row = e / DQ, q = e - row * DQ;
+      d_dst[i] = row * DS + 4 * q;
+      d_src[i] = (m0 + row) * N + 4 * q;
+      d_pos[i] = 4 * q;
     }
+    int x_src[NX4], x_dst[NX4], x_pos[NX4], x_st[NX4];
+    float x_ga[NX4], x_be[NX4];
+#pragma unroll
+    for (int i = 0; i < NX4; ++i) {
+      const int e = (lt + i * NLT) % (BR * XQ);
+      const int row = e / XQ, q = e - row * XQ;
+      x_dst[i] = row * XS + 4 * q;
+      x_src[i] = (r0 + row) * L;
+      x_pos[i] = 4 * q - HALO;
+      if (PRO == 1) {
+        const int r = r0 + row;
+        x_st[i] = (r / (R / G)) * 2;
+        x_ga[i] = d.pro_gamma ? d.pro_gamma[r] : 1.0f;
+        x_be[i] = d.pro_beta ? d.pro_beta[r] : 0.0f;
+      }
+    }
+    float bsum[ND4];
+#pragma unroll
+    for (int i = 0; i < ND4; ++i) bsum[i] = 0.0f;
+
+    f32x4 rd[PD][ND4], rx[PD][NX4];
+    float rmean[PD][NX4], rrstd[PD][NX4];
+    bool d_ok[PD][ND4], x_ok[PD][NX4];
+
+    // local chunk k -> batch element b, first position p0.  Loads are unconditional (ghost chunks re-read the last
+    // one, never consumed) so that the number of loads in flight is a compile-time constant.
+    auto load_chunk = [&](f32x4 (&qd)[ND4], f32x4 (&qx)[NX4], float (&qm)[NX4], float (&qr)[NX4], bool (&okd)[ND4],
+                          bool (&okx)[NX4], int k) {
+      const int c = cbeg + (k < nloc ? k : nloc - 1);
+      const int b = c / CPB, p0 = (c - b * CPB) * BKN;
+      const float* dyb = d.dy + (int64_t)b * M * N + p0;
+#pragma unroll
+      for (int i = 0; i < ND4; ++i) {
+        okd[i] = (p0 + d_pos[i] < N);
+        qd[i] = *reinterpret_cast<const f32x4*>(dyb + (okd[i] ? d_src[i] : d_src[i] - d_pos[i] - p0));
+      }
+      const float* xbp = d.x + (int64_t)b * R * L;
+#pragma unroll
+      for (int i = 0; i < NX4; ++i) {
+        const int u = p0 * S + x_pos[i];
+        okx[i] = (u >= 0 && u < Lv);
+        qx[i] = wg_load_xquad<UP>(xbp + x_src[i] + (okx[i] ? u / UP : 0));
+        if (PRO == 1) {
+          qm[i] = d.pro_stats[(int64_t)b * G * 2 + x_st[i]];
+          qr[i] = d.pro_stats[(int64_t)b * G * 2 + x_st[i] + 1];
+        }
+      }
+    };
+    auto store_chunk = [&](const f32x4 (&qd)[ND4], const f32x4 (&qx)[NX4], const float (&qm)[NX4],
+                           const float (&qr)[NX4], const bool (&okd)[ND4], const bool (&okx)[NX4], int k) {
+      float* Db = smem + (k & 1) * (D_ELEMS + X_ELEMS);
+      float* Xb = Db + D_ELEMS;
+      const bool real = k < nloc;
+#pragma unroll
+      for (int i = 0; i < ND4; ++i) {
+        f32x4 v = qd[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = okd[i] ? v[j] : 0.0f;
+        // dbias: this slot's row is fixed; wrapped duplicate slots (lt + i*NLT >= BM*DQ) and ghost chunks must not
+        // count
+        if (lt + i * NLT < BM * DQ) bsum[i] += real ? (v[0] + v[1]) + (v[2] + v[3]) : 0.0f;
+        *reinterpret_cast<f32x4*>(Db + d_dst[i]) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < NX4; ++i) {
+        f32x4 v = qx[i];
+        if (PRO == 1) {
+          const float pa = x_ga[i] * qr[i], pb = x_be[i] - qm[i] * pa;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = adp_silu_fast(fmaf(v[j], pa, pb));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = okx[i] ? v[j] : 0.0f;
+        *reinterpret_cast<f32x4*>(Xb + x_dst[i]) = v;
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < PD; ++s) load_chunk(rd[s], rx[s], rmean[s], rrstd[s], d_ok[s], x_ok[s], s);
+    // Hazard note: the store of chunk k goes to LDS[k & 1], last read by the MFMAs of chunk k-2; every MMA wave
+    // finished those before it arrived at barrier B_{k-1}, which this wave passed before starting iteration k.
+    for (int k0 = 0; k0 < nrounds; k0 += PD) {
+#pragma unroll
+      for (int s = 0; s < PD; ++s) {
+        store_chunk(rd[s], rx[s], rmean[s], rrstd[s], d_ok[s], x_ok[s], k0 + s);
+        load_chunk(rd[s], rx[s], rmean[s], rrstd[s], d_ok[s], x_ok[s], k0 + s + PD);
+        __syncthreads();  // B_k
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 1; g < NKG; ++g) {
+      __syncthreads();
+      __syncthreads();
+    }
+    if (do_bias) {
+      // a dy row is staged by DQ = 16 consecutive lanes of one slot: sum them in a fixed order
+      float* bb = direct ? d.dbias : d.ws + (int64_t)nsplit * cnt + (int64_t)split * M;
+#pragma unroll
+      for (int i = 0; i < ND4; ++i) {
+        float s = bsum[i];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 8, 64);
+        const int e = lt + i * NLT;
+        if (e < BM * DQ && (e % DQ) == 0) {
+          const int m = m0 + e / DQ;
+          bb[m] = (direct && d.accumulate) ? bb[m] + s : s;
+        }
+      }
+    }
+    return;
   }
 
+  // =========================== MMA waves ===========================
+  const int quad = wave % NQ, kg = wave / NQ;
+  const int wm0 = (quad / NQR) * 32, wr0 = (quad % NQR) * 32;
   f32x16 acc[KT];
 #pragma unroll
   for (int t = 0; t < KT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-  float bsum[ND4];
-#pragma unroll
-  for (int i = 0; i < ND4; ++i) bsum[i] = 0.0f;
 
-  f32x4 rd[ND4], rx[NX4];
-  float rmean[NX4], rrstd[NX4];
-  bool d_ok[ND4], x_ok[NX4];
-
-  // chunk c -> batch element b, first position p0
-  int b = cbeg / CPB, p0 = (cbeg - b * CPB) * BKN;
-
-#define WG_LOAD()                                                                                          \
-  {                                                                                                        \
-    const float* dyb = d.dy + (int64_t)b * M * N + p0;                                                     \
-    _Pragma("unroll") for (int i = 0; i < ND4; ++i) {                                                      \
-      d_ok[i] = (p0 + d_pos[i] < N);                                                                       \
-      rd[i] = *reinterpret_cast<const f32x4*>(dyb + (d_ok[i] ? d_src[i] : d_src[i] - d_pos[i] - p0));      \
-    }                                                                                                      \
-    const float* xbp = d.x + (int64_t)b * R * L;                                                           \
-    _Pragma("unroll") for (int i = 0; i < NX4; ++i) {                                                      \
-      const int u = p0 * S + x_pos[i];                                                                     \
-      x_ok[i] = (u >= 0 && u < Lv);                                                                        \
-      rx[i] = wg_load_xquad<UP>(xbp + x_src[i] + (x_ok[i] ? u / UP : 0));                                  \
-      if (PRO == 1) {                                                                                      \
-        rmean[i] = d.pro_stats[(int64_t)b * G * 2 + x_st[i]];                                              \
-        rrstd[i] = d.pro_stats[(int64_t)b * G * 2 + x_st[i] + 1];                                          \
-      }                                                                                                    \
-    }                                                                                                      \
-  }
-
-  if (cbeg < cend) WG_LOAD();
-
-  for (int c = cbeg; c < cend; ++c) {
-    float* Db = smem + ((c - cbeg) & 1) * (D_ELEMS + X_ELEMS);
-    float* Xb = Db + D_ELEMS;
-    // ---- registers -> LDS
+  for (int k = 0; k < nrounds; ++k) {
+    __syncthreads();  // B_k: chunk k is in LDS[k & 1]
+    if (k < nloc) {
+      const float* Db = smem + (k & 1) * (D_ELEMS + X_ELEMS);
+      const float* Xb = Db + D_ELEMS;
 #pragma unroll
-    for (int i = 0; i < ND4; ++i) {
-      f32x4 v = rd[i];
+      for (int s = 0; s < PPW / 8; ++s) {
+        const int base = kg * PPW + 8 * s + 4 * hi;
+        const f32x4 dq = *reinterpret_cast<const f32x4*>(Db + (wm0 + l31) * DS + base);
+        float xq[S == 1 ? 12 : 4 * S];
+        if (S == 1) {
+          const float* xp = Xb + (wr0 + l31) * XS + base;
+          if (KT == 3) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = d_ok[i] ? v[j] : 0.0f;
-      // dbias: this slot's row is fixed; wrapped duplicate slots (tid + i*NT >= BM*DQ) must not count twice
-      if (tid + i * NT < BM * DQ) bsum[i] += (v[0] + v[1]) + (v[2] + v[3]);
-      *reinterpret_cast<f32x4*>(Db + d_dst[i]) = v;
-    }
+            for (int q = 0; q < 3; ++q) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(xp + 4 * q);
 #pragma unroll
-    for (int i = 0; i < NX4; ++i) {
-      f32x4 v = rx[i];
-      if (PRO == 1) {
-        const float pa = x_ga[i] * rrstd[i], pb = x_be[i] - rmean[i] * pa;
+              for (int j = 0; j < 4; ++j) xq[4 * q + j] = v[j];
+            }
+          } else {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xp + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = adp_silu_fast(fmaf(v[j], pa, pb));
-      }
+            for (int j = 0; j < 4; ++j) xq[4 + j] = v[j];
+          }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = x_ok[i] ? v[j] : 0.0f;
-      *reinterpret_cast<f32x4*>(Xb + x_dst[i]) = v;
-    }
-    __syncthreads();
-    // ---- prefetch the next chunk
-    p0 += BKN;
-    if (p0 >= N) {
-      p0 = 0;
-      ++b;
-    }
-    if (c + 1 < cend) WG_LOAD();
-    // ---- matrix cores over this wave's share of the chunk's positions
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int s = 0; s < PPW / 8; ++s) {
-      const int base = kg * PPW + 8 * s + 4 * hi;
-      const f32x4 dq = *reinterpret_cast<const f32x4*>(Db + (wm0 + l31) * DS + base);
-      float xq[S == 1 ? 12 : 4 * S];
-      if (S == 1) {
-        const float* xp = Xb + (wr0 + l31) * XS + base;
-        if (KT == 3) {
+            for (int t = 0; t < KT; ++t) acc[t] = adp_mfma32(dq[j], xq[j + 4 - PAD + t], acc[t]);
+        } else {
+          const float* xp = Xb + (wr0 + l31) * XS + base * S;
 #pragma unroll
-          for (int q = 0; q < 3; ++q) {
+          for (int q = 0; q < S; ++q) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(xp + 4 * q);
 #pragma unroll
             for (int j = 0; j < 4; ++j) xq[4 * q + j] = v[j];
           }
-        } else {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(xp + 4);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) xq[4 + j] = v[j];
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < KT; ++t) acc[t] = adp_mfma32(dq[j], xq[j * S + t], acc[t]);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int t = 0; t < KT; ++t) acc[t] = adp_mfma32(dq[j], xq[j + 4 - PAD + t], acc[t]);
-      } else {
-        const float* xp = Xb + (wr0 + l31) * XS + base * S;
-#pragma unroll
-        for (int q = 0; q < S; ++q) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(xp + 4 * q);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) xq[4 * q + j] = v[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int t = 0; t < KT; ++t) acc[t] = adp_mfma32(dq[j], xq[j * S + t], acc[t]);
       }
     }
   }
-#undef WG_LOAD
   __syncthreads();
 
   // ---- fixed-order sum of the K groups through LDS, one group per round
-  if (NKG > 1) {
-    for (int g = 1; g < NKG; ++g) {
-      if (kg == g) {
 #pragma unroll
-        for (int t = 0; t < KT; ++t)
+  for (int g = 1; g < NKG; ++g) {
+    if (kg == g) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) smem[((quad * KT + t) * 16 + r) * 64 + lane] = acc[t][r];
-      }
-      __syncthreads();
-      if (kg == 0) {
+      for (int t = 0; t < KT; ++t)
 #pragma unroll
-        for (int t = 0; t < KT; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[t][r] += smem[((quad * KT + t) * 16 + r) * 64 + lane];
-      }
-      __syncthreads();
+        for (int r = 0; r < 16; ++r) smem[((quad * KT + t) * 16 + r) * 64 + lane] = acc[t][r];
     }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] += smem[((quad * KT + t) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
   }
 
-  const bool direct = (nsplit == 1);
-  const int64_t cnt = (int64_t)M * R * KT;
   if (kg == 0) {
     float* base = direct ? d.dw : d.ws + (int64_t)split * cnt;
 #pragma unroll
@@ -248,23 +297,6 @@ __global__ __launch_bounds__((BM / 32) * (BR / 32) * NKG * 64) void wgrad_mm_ker
         float* o = base + ((int64_t)m * R + rr) * KT + t;
         *o = (direct && d.accumulate) ? *o + acc[t][r] : acc[t][r];
       }
-  }
-  if (do_bias) {
-    // a dy row is staged by DQ = 16 consecutive lanes of one slot: sum them in a fixed order
-    float* bb = direct ? d.dbias : d.ws + (int64_t)nsplit * cnt + (int64_t)split * M;
-#pragma unroll
-    for (int i = 0; i < ND4; ++i) {
-      float s = bsum[i];
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      s += __shfl_xor(s, 8, 64);
-      const int e = tid + i * NT;
-      if (e < BM * DQ && (e % DQ) == 0) {
-        const int m = m0 + e / DQ;
-        bb[m] = (direct && d.accumulate) ? bb[m] + s : s;
-      }
-    }
   }
 }
 
@@ -280,8 +312,8 @@ WgPlan wg_plan(const adp_wgrad_desc& d) {
   const int64_t tiles = (d.M / p.bm) * (d.R / p.bm);
   p.cpb = adp_cdiv(d.N, WG_BKN);
   const int64_t total = d.B * p.cpb;
-  // 16-wave workgroups (64x64): one per CU fills the SIMDs; 4-wave workgroups (32x32): four per CU
-  const int64_t target = (p.bm == 64) ? 256 : 1024;
+  // 12-wave workgroups (64x64): one per CU fills the SIMDs; 8-wave workgroups (32x32): about three per CU
+  const int64_t target = (p.bm == 64) ? 256 : 768;
   int64_t ns = adp_cdiv(target, tiles);
   if (ns > total / 8) ns = total / 8;  // a workgroup should amortise its start-up over >= 8 chunks
   if (ns > total) ns = total;
@@ -357,8 +389,10 @@ namespace {
 template <int BM, int KT, int S, int UP, int PRO>
 int launch_wg(const adp_wgrad_desc& d, const WgPlan& p, void* stream) {
   dim3 grid((unsigned)p.nsplit, (unsigned)(d.M / BM), (unsigned)(d.R / BM));
-  ADP_LAUNCH((wgrad_mm_kernel<BM, BM, 4, KT, S, UP, PRO>), grid, dim3((BM / 32) * (BM / 32) * 4 * 64), stream, d,
-             (int)p.cpb, (int)p.cps, (int)p.nsplit);
+  constexpr int NTH = ((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NLD) * 64;
+  constexpr int PD = BM == 64 ? 1 : 2;  // a 64x64 chunk is 2.6 us of MFMAs, a 32x32 chunk 0.64 us
+  ADP_LAUNCH((wgrad_mm_kernel<BM, KT, S, UP, PRO, PD>), grid, dim3(NTH), stream, d, (int)p.cpb, (int)p.cps,
+             (int)p.nsplit);
   if (p.nsplit > 1) {
     return adp_wgrad_reduce(d.ws, p.nsplit, d.M * d.R * KT, d.M, d.dw, d.dbias, (int)d.accumulate, stream);
   }
