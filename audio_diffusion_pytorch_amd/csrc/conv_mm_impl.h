@@ -42,7 +42,10 @@ namespace {
 
 constexpr int MM_PRO_RMAX = 1024; // channels whose GroupNorm constants fit the LDS table
 constexpr int MM_BN = 64;         // output positions per block
-constexpr int MM_NLD = 4;         // loader waves per block
+// loader waves per block: the GroupNorm+SiLU prologue is VALU work (two transcendentals per element) on the
+// loaders' critical path, so those variants get twice the loaders -- except the one-chunk 32-row blocks of the
+// HBM-bound shallow layers, where more resident blocks per CU matter more (measured: depth 1, 54 vs 63 us)
+constexpr int mm_nld(int PRO, int BM, int PD) { return (PRO == 1 && !(BM == 32 && PD == 1)) ? 8 : 4; }
 
 // four consecutive virtual positions u0..u0+3 (u0 % 4 == 0) of a row upsampled by UP: 4 / 2 / 1 source floats
 template <int UP>
@@ -75,7 +78,8 @@ struct cmax {
 // UP: nearest-upsample factor folded into the X loader (UpsampleItem: the [B, C, L*UP] intermediate is never
 // materialised); BKT: channels per staged chunk; PD: loader prefetch distance in chunks (register stages).
 template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD>
-__global__ __launch_bounds__(((BM / 32) * (BKT / 8) + MM_NLD) * 64) void conv_mm_kernel(adp_conv_desc d) {
+__global__ __launch_bounds__(((BM / 32) * (BKT / 8) + mm_nld(PRO, BM, PD)) * 64) void conv_mm_kernel(adp_conv_desc d) {
+  constexpr int MM_NLD = mm_nld(PRO, BM, PD);
   constexpr int BN = MM_BN, NKG = BKT / 8, NQM = BM / 32;
   constexpr int NMMA = NQM * NKG;                   // MMA waves
   constexpr int NLT = MM_NLD * 64;                  // loader threads
@@ -320,7 +324,7 @@ template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD>
 int launch_mm(const adp_conv_desc& d, void* stream) {
   const int64_t blocks = (d.M / BM) * adp_cdiv(d.N, MM_BN) * d.B;
   ADP_LAUNCH((conv_mm_kernel<BM, KT, S, UP, TR, PRO, BKT, PD>), dim3((unsigned)blocks),
-             dim3(((BM / 32) * (BKT / 8) + MM_NLD) * 64), stream, d);
+             dim3(((BM / 32) * (BKT / 8) + mm_nld(PRO, BM, PD)) * 64), stream, d);
   return ADP_LAUNCH_OK();
 }
 
