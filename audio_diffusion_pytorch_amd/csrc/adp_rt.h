@@ -36,6 +36,7 @@ __device__ __forceinline__ float adp_rcp(float x) { return __builtin_amdgcn_rcpf
     hipLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__);      \
   } while (0)
 #define ADP_LAUNCH_OK() (hipGetLastError() == hipSuccess ? ADP_OK : ADP_ERR_LAUNCH)
+
 #endif
 
 // Launch trace (introspection only, see adp_launch_trace in adp.h): when tracing is on, every ADP_LAUNCH appends

@@ -41,6 +41,9 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* x, int64_t
   }
 }
 
+// (A "last workgroup combines the partials" ticket was measured here: the agent-scope release/acquire it needs
+// per workgroup -- L2 write-back + invalidate, the per-XCD L2s are not coherent -- made the 8192-workgroup depth-1
+// launch 4x slower than this second tiny launch.)
 __global__ __launch_bounds__(64) void gn_final_kernel(const float* ws, int64_t NG, int64_t nchunks, float eps,
                                                       float* stats) {
   const int64_t bg = blockIdx.x;
@@ -96,10 +99,26 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* x, cons
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* x, const float* dact, const float* stats,
                                                            const float* gamma, const float* beta, const float* ab,
                                                            const float* dres, int64_t C, int64_t L, int64_t G,
-                                                           int64_t NS, int64_t CL, float* dx) {
+                                                           int64_t NS, int64_t CL, float* dx, int64_t B,
+                                                           float* dgamma, float* dbeta, int accumulate) {
   __shared__ float sh[4];
   const int64_t row = blockIdx.y, split = blockIdx.x;
   const int64_t b = row / C, c = row % C, Cg = C / G, g = c / Cg;
+  if (dgamma && b == 0 && split == 0) {
+    // parameter gradients of this channel (what adp_gn_param_grad computes): dgamma = sum_{b,s} A, dbeta = sum B
+    float pa = 0.0f, pb = 0.0f;
+    for (int64_t e = threadIdx.x; e < B * NS; e += 256) {
+      const int64_t bb = e / NS, spx = e % NS;
+      pa += ab[((bb * C + c) * NS + spx) * 2];
+      pb += ab[((bb * C + c) * NS + spx) * 2 + 1];
+    }
+    pa = adp_block_sum<4>(pa, sh);
+    pb = adp_block_sum<4>(pb, sh);
+    if (threadIdx.x == 0) {
+      dgamma[c] = accumulate ? dgamma[c] + pa : pa;
+      dbeta[c] = accumulate ? dbeta[c] + pb : pb;
+    }
+  }
   const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
   float sa = 0.0f, sb = 0.0f;
   for (int64_t e = threadIdx.x; e < Cg * NS; e += 256) {
@@ -416,12 +435,13 @@ extern "C" int adp_gn_silu_bwd_reduce(const float* x, const float* dact, const f
 
 extern "C" int adp_gn_silu_bwd_apply(const float* x, const float* dact, const float* stats, const float* gamma,
                                      const float* beta, const float* ab, const float* dres, int64_t B, int64_t C,
-                                     int64_t L, int64_t G, int64_t NS, float* dx, void* stream) {
-  if (!x || !dact || !stats || !gamma || !beta || !ab || !dx) return ADP_ERR_NULL;
+                                     int64_t L, int64_t G, int64_t NS, float* dx, float* dgamma, float* dbeta,
+                                     int64_t accumulate, void* stream) {
+  if (!x || !dact || !stats || !gamma || !beta || !ab || !dx || (!dgamma != !dbeta)) return ADP_ERR_NULL;
   if (B <= 0 || C <= 0 || L <= 0 || G <= 0 || C % G || NS < 1 || NS > 65535 || B * C > 65535) return ADP_ERR_SHAPE;
   const int64_t CL = adp_cdiv(L, NS);
   ADP_LAUNCH(gn_bwd_apply_kernel, dim3((unsigned)NS, (unsigned)(B * C)), dim3(256), stream, x, dact, stats, gamma,
-             beta, ab, dres, C, L, G, NS, CL, dx);
+             beta, ab, dres, C, L, G, NS, CL, dx, B, dgamma, dbeta, (int)accumulate);
   return ADP_LAUNCH_OK();
 }
 

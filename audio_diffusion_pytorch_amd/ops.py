@@ -107,14 +107,13 @@ def gn_silu_bwd(x: Tensor, dact: Tensor, stats: Tensor, gamma: Tensor, beta: Ten
             ptr(ab), s)
     if dx is None:
         dx = torch.empty_like(x)
-    _C.tag(bytes=(12 + (4 if dres is not None else 0)) * x.numel(), shape=f"B{B} C{C} L{L}")
-    _C.call("adp_gn_silu_bwd_apply", ptr(x), ptr(dact), ptr(stats), ptr(gamma), ptr(beta), ptr(ab), ptr(dres), B, C,
-            L, groups, NS, ptr(dx), s)
     if dgamma is None:
         dgamma = torch.empty_like(gamma)
     if dbeta is None:
         dbeta = torch.empty_like(beta)
-    _C.call("adp_gn_param_grad", ptr(ab), B, C, NS, ptr(dgamma), ptr(dbeta), int(accumulate), s)
+    _C.tag(bytes=(12 + (4 if dres is not None else 0)) * x.numel(), shape=f"B{B} C{C} L{L}")
+    _C.call("adp_gn_silu_bwd_apply", ptr(x), ptr(dact), ptr(stats), ptr(gamma), ptr(beta), ptr(ab), ptr(dres), B, C,
+            L, groups, NS, ptr(dx), ptr(dgamma), ptr(dbeta), int(accumulate), s)
     return dx, dgamma, dbeta
 
 

@@ -119,7 +119,8 @@ int64_t adp_row_nsplit(int64_t rows, int64_t L);
 
 /* Backward of y = SiLU(GroupNorm(x)) given dact = dL/dy (the conv data gradient), NS = adp_row_nsplit(B*C, L):
  *   adp_gn_silu_bwd_reduce: ab[b,c,s,0] = sum_l ds*xhat, ab[b,c,s,1] = sum_l ds over slice s of L, ds = dact*silu'(h)
- *   adp_gn_silu_bwd_apply : dx = rstd*(gamma*ds - m1 - xhat*m2) (+ dres)
+ *   adp_gn_silu_bwd_apply : dx = rstd*(gamma*ds - m1 - xhat*m2) (+ dres); with dgamma/dbeta != NULL it also writes
+ *                           the parameter gradients (same arithmetic as adp_gn_param_grad, no third launch)
  *   adp_gn_param_grad     : dgamma[c] = sum_{b,s} ab[..0], dbeta[c] = sum_{b,s} ab[..1]
  * ab holds B*C*NS*2 floats. */
 int adp_gn_silu_bwd_reduce(const float* x, const float* dact, const float* stats, const float* gamma,
@@ -127,7 +128,8 @@ int adp_gn_silu_bwd_reduce(const float* x, const float* dact, const float* stats
                            void* stream);
 int adp_gn_silu_bwd_apply(const float* x, const float* dact, const float* stats, const float* gamma,
                           const float* beta, const float* ab, const float* dres, int64_t B, int64_t C, int64_t L,
-                          int64_t G, int64_t NS, float* dx, void* stream);
+                          int64_t G, int64_t NS, float* dx, float* dgamma, float* dbeta, int64_t accumulate,
+                          void* stream);
 int adp_gn_param_grad(const float* ab, int64_t B, int64_t C, int64_t NS, float* dgamma, float* dbeta,
                       int64_t accumulate, void* stream);
 
