@@ -851,6 +851,7 @@ extern "C" int adp_conv1d(const adp_conv_desc* dp, void* stream) {
   if (d.store == 1 && (d.sp < 1 || d.M % d.sp != 0)) return ADP_ERR_SHAPE;
   if (d.store == 2 && ((d.sp != 2 && d.sp != 4) || d.N % d.sp != 0 || d.bias)) return ADP_ERR_UNSUPPORTED;
   if (d.B > 65535 || adp_cdiv(d.M, 32) > 65535) return ADP_ERR_SHAPE;
+  if (adp_conv_stream_eligible(d)) return adp_conv_stream(d, stream);
   if (adp_conv_mm_eligible(d)) return adp_conv_mm(d, stream);
   if (adp_conv_direct_eligible(d)) return adp_conv_direct(d, stream);
   if (d.KT == 1) return dispatch_conv<1, 1>(d, stream);
@@ -862,6 +863,7 @@ extern "C" int adp_conv1d(const adp_conv_desc* dp, void* stream) {
 // which tile the dispatcher picks for this problem: BM * 1000 + BN (introspection for profiling / roofline reports)
 extern "C" int64_t adp_conv1d_tile(const adp_conv_desc* dp) {
   if (!dp) return ADP_ERR_NULL;
+  if (adp_conv_stream_eligible(*dp)) return 32 * 1000 + 256;  // streaming 32-channel kernel: 32 outputs x 256 positions
   if (adp_conv_mm_eligible(*dp)) return adp_conv_mm_tile(*dp);
   if (adp_conv_direct_eligible(*dp)) return 8 * 1000 + 999;  // direct VALU kernel: 8 output channels x 1024 positions
   return pick_tile(*dp);

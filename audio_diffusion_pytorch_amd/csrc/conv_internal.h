@@ -14,6 +14,10 @@ int adp_wgrad_mm(const adp_wgrad_desc& d, void* stream);
 int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, float* dw, float* dbias, int accumulate,
                      void* stream);
 
+// conv_stream.hip: persistent streaming kernel for the HBM-bound 32 -> 32 channel kernel-3 ConvBlock convs (depth 1)
+bool adp_conv_stream_eligible(const adp_conv_desc& d);
+int adp_conv_stream(const adp_conv_desc& d, void* stream);
+
 // conv_direct.hip: VALU direct convolution for the narrow (2-8 channel) ends of the U-Net
 bool adp_conv_direct_eligible(const adp_conv_desc& d);
 int adp_conv_direct(const adp_conv_desc& d, void* stream);

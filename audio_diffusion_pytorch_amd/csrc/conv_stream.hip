@@ -1,0 +1,201 @@
+// Streaming ConvBlock convolution for the HBM-bound depth-1 layers: 32 -> 32 channels, kernel 3, stride 1, 'same'
+// (ResnetItem ConvBlocks at channels = 32 and their data gradients; /root/reference/audio_diffusion_pytorch/
+// components.py:89, SURVEY.md 8a row a13, 8d "HBM-bound" rows).
+//
+// At [4, 32, 65536] a ConvBlock conv moves 67-100 MB (A_in + A_out (+A_res)) for 1.6 GFLOP: arithmetic intensity
+// ~20 flop/B, right at the MI355X ridge, so the kernel is built like a stream with the matrix cores fed from it:
+//   * the whole 32 x 96 weight matrix lives in REGISTERS as MFMA A-operands (48 VGPRs per lane) for the lifetime of
+//     a persistent workgroup -- there is no K loop, no K-group exchange, no weight traffic after start-up;
+//   * one workgroup per CU walks a contiguous range of 256-position tiles.  Four loader waves stage the next tile
+//     (32 channels x (256 + 8 halo) positions: 16-byte global loads, GroupNorm+SiLU in registers, 16-byte LDS
+//     stores) while four MMA waves -- one per SIMD, 64 positions each, two accumulator tiles -- run 96 MFMAs over
+//     the current one; one workgroup barrier per tile hands the double-buffered LDS tile over (same protocol as
+//     conv_mm_impl.h);
+//   * an MMA wave issues the residual loads of its tile BEFORE its MFMAs and stores the finished tile straight
+//     from the accumulators afterwards (fire and forget), so the epilogue's HBM latency hides behind the MFMAs.
+// Algorithmic bytes per launch: 4 * B * 32 * L * (2 + has_res) + 12 KB of weights.
+#include "adp_rt.h"
+#include "adp.h"
+#include "conv_internal.h"
+
+namespace {
+
+constexpr int ST_C = 32;           // channels in = channels out
+constexpr int ST_KT = 3;
+constexpr int ST_TN = 256;         // positions per workgroup iteration (4 MMA waves x 64)
+constexpr int ST_XS = ST_TN + 8;   // LDS row stride: positions n0-4 .. n0+TN+3
+constexpr int ST_XQ = ST_XS / 4;
+constexpr int ST_NX4 = (ST_C * ST_XQ + 255) / 256;  // staging quads per loader thread
+
+template <bool TR, int PRO>
+__global__ __launch_bounds__(512) void conv_stream32_kernel(adp_conv_desc d, int tiles_per_b, int total_tiles) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * ST_C * ST_XS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int L = (int)d.Lin;
+  // contiguous tile range of this workgroup
+  const int t_beg = (int)(((int64_t)blockIdx.x * total_tiles) / gridDim.x);
+  const int t_end = (int)(((int64_t)(blockIdx.x + 1) * total_tiles) / gridDim.x);
+  const int niter = t_end - t_beg;
+
+  if (wave >= 4) {
+    // =========================== loader waves ===========================
+    const int lt = tid - 256;
+    int x_dst[ST_NX4], x_off[ST_NX4], x_pos[ST_NX4];
+    float x_ga[ST_NX4], x_be[ST_NX4];
+    int x_st[ST_NX4];
+#pragma unroll
+    for (int i = 0; i < ST_NX4; ++i) {
+      const int e = (lt + i * 256) % (ST_C * ST_XQ);
+      const int row = e / ST_XQ, pq = e - row * ST_XQ;
+      x_dst[i] = row * ST_XS + 4 * pq;
+      x_off[i] = row * L;
+      x_pos[i] = 4 * pq - 4;
+      if (PRO == 1) {
+        x_st[i] = (row / (ST_C / (int)d.groups)) * 2;
+        x_ga[i] = d.pro_gamma ? d.pro_gamma[row] : 1.0f;
+        x_be[i] = d.pro_beta ? d.pro_beta[row] : 0.0f;
+      }
+    }
+    f32x4 rx[ST_NX4];
+    float rm[ST_NX4], rr[ST_NX4];
+    bool ok[ST_NX4];
+    auto load_tile = [&](int it) {
+      const int t = t_beg + (it < niter ? it : niter - 1);
+      const int b = t / tiles_per_b, n0 = (t - b * tiles_per_b) * ST_TN;
+      const float* xb = d.x + (int64_t)b * ST_C * L;
+#pragma unroll
+      for (int i = 0; i < ST_NX4; ++i) {
+        const int u = n0 + x_pos[i];
+        ok[i] = (u >= 0 && u < L);  // L % 4 == 0: a quad is entirely inside or outside the row
+        rx[i] = *reinterpret_cast<const f32x4*>(xb + x_off[i] + (ok[i] ? u : 0));
+        if (PRO == 1) {
+          rm[i] = d.pro_stats[(int64_t)b * d.groups * 2 + x_st[i]];
+          rr[i] = d.pro_stats[(int64_t)b * d.groups * 2 + x_st[i] + 1];
+        }
+      }
+    };
+    auto store_tile = [&](int it) {
+      float* Xb = smem + (it & 1) * (ST_C * ST_XS);
+#pragma unroll
+      for (int i = 0; i < ST_NX4; ++i) {
+        f32x4 v = rx[i];
+        if (PRO == 1) {
+          const float pa = x_ga[i] * rr[i], pb = x_be[i] - rm[i] * pa;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = adp_silu_fast(fmaf(v[j], pa, pb));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ok[i] ? v[j] : 0.0f;  // zero padding is applied after the activation
+        *reinterpret_cast<f32x4*>(Xb + x_dst[i]) = v;
+      }
+    };
+    // the store of tile it goes to LDS[it & 1], last read by the MFMAs of tile it-2; every MMA wave finished those
+    // before it arrived at barrier B_{it-1}, which this wave passed before starting iteration it
+    load_tile(0);
+    for (int it = 0; it < niter; ++it) {
+      store_tile(it);
+      load_tile(it + 1);  // unconditional: the tail re-reads the last tile (never consumed)
+      __syncthreads();    // B_it
+    }
+    return;
+  }
+
+  // =========================== MMA waves ===========================
+  // A operands: av[g][c*KT + t] = A(m = l31, channel 8g + c + 4hi, tap t)
+  float av[4][4 * ST_KT];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < ST_KT; ++t) {
+        const int r = 8 * g + c + 4 * hi;
+        av[g][c * ST_KT + t] = TR ? d.w[((int64_t)r * ST_C + l31) * ST_KT + (ST_KT - 1 - t)]
+                                  : d.w[((int64_t)l31 * ST_C + r) * ST_KT + t];
+      }
+  float bias[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bias[r] = d.bias ? d.bias[(r & 3) + 8 * (r >> 2) + 4 * hi] : 0.0f;
+  const int xfrag = 4 * hi * ST_XS + 64 * wave + l31 + 4 - 1;  // + ni*32 + (8g + c) * XS + t
+  const bool has_res = d.res != nullptr;
+
+  for (int it = 0; it < niter; ++it) {
+    const int t = t_beg + it;
+    const int b = t / tiles_per_b, n0 = (t - b * tiles_per_b) * ST_TN;
+    const int64_t obase = (int64_t)b * ST_C * L + n0 + 64 * wave + l31;
+    // residual values of this wave's tile: issued before the MFMAs, consumed after them
+    float rv[2][16];
+    if (has_res) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
+          rv[ni][r] = d.res[obase + (int64_t)m * L + 32 * ni];
+        }
+    }
+    __syncthreads();  // B_it: tile it is in LDS[it & 1]
+    const float* Xb = smem + (it & 1) * (ST_C * ST_XS);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[r] = bias[r];
+      acc1[r] = bias[r];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int tt = 0; tt < ST_KT; ++tt) {
+          const float x0 = Xb[xfrag + (8 * g + c) * ST_XS + tt];
+          const float x1 = Xb[xfrag + 32 + (8 * g + c) * ST_XS + tt];
+          acc0 = adp_mfma32(av[g][c * ST_KT + tt], x0, acc0);
+          acc1 = adp_mfma32(av[g][c * ST_KT + tt], x1, acc1);
+        }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float v0 = acc0[r], v1 = acc1[r];
+      if (has_res) {
+        v0 += rv[0][r];
+        v1 += rv[1][r];
+      }
+      d.out[obase + (int64_t)m * L] = v0;
+      d.out[obase + (int64_t)m * L + 32] = v1;
+    }
+  }
+}
+
+}  // namespace
+
+bool adp_conv_stream_eligible(const adp_conv_desc& d) {
+  if (d.R != ST_C || d.R1 != d.R || d.M != ST_C || d.KT != ST_KT) return false;
+  if (d.stride != 1 || d.dil != 1 || d.pad != 1 || d.up != 1 || d.store != 0) return false;
+  if (d.out_pre || d.e_scale || d.x2) return false;
+  if (d.prologue != 0 && d.prologue != 1) return false;
+  if (d.prologue == 1 && (d.groups < 1 || ST_C % d.groups != 0)) return false;
+  if (d.N != d.Lin || d.N % ST_TN != 0) return false;
+  if (reinterpret_cast<uintptr_t>(d.x) & 15) return false;
+  if (d.B * (d.N / ST_TN) >= (int64_t)1 << 30 || d.B * ST_C * d.Lin >= (int64_t)1 << 40) return false;
+  return true;
+}
+
+int adp_conv_stream(const adp_conv_desc& d, void* stream) {
+  const int tiles_per_b = (int)(d.N / ST_TN);
+  const int total = (int)d.B * tiles_per_b;
+  const int grid = total < 256 ? total : 256;  // one persistent workgroup per CU
+  if (d.transposed) {
+    if (d.prologue == 1)
+      ADP_LAUNCH((conv_stream32_kernel<true, 1>), dim3((unsigned)grid), dim3(512), stream, d, tiles_per_b, total);
+    else
+      ADP_LAUNCH((conv_stream32_kernel<true, 0>), dim3((unsigned)grid), dim3(512), stream, d, tiles_per_b, total);
+  } else {
+    if (d.prologue == 1)
+      ADP_LAUNCH((conv_stream32_kernel<false, 1>), dim3((unsigned)grid), dim3(512), stream, d, tiles_per_b, total);
+    else
+      ADP_LAUNCH((conv_stream32_kernel<false, 0>), dim3((unsigned)grid), dim3(512), stream, d, tiles_per_b, total);
+  }
+  return ADP_LAUNCH_OK();
+}

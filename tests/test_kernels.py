@@ -124,7 +124,7 @@ MM_CASES = [
     (1, 32, 32, 64, 3, 3, 3),         # dilation 3
     (1, 32, 64, 64 * 1024, 1, 0, 1),  # 1024 tiles -> 64x128 tile (T2), guarded single-chunk pipeline
     (2, 96, 64, 64 * 512, 1, 0, 1),   # T2, 3 chunks -> prefetch distance 2 with a remainder iteration
-    (2, 32, 32, 128 * 256, 3, 1, 1),  # M % 64 != 0 with 512 blocks -> 32x128 tile (T3)
+    (2, 32, 32, 128 * 256 + 64, 3, 1, 1),  # 32 -> 32 channels, length not a multiple of 256: stays on conv_mm
     (1, 128, 64, 64 * 200, 3, 1, 1),  # 64x64 tile (T0), 4 chunks -> unguarded 2-stage pipeline
     (1, 160, 32, 192, 3, 1, 1),       # 32x64 tile (T1), 5 chunks (odd) -> remainder iteration
 ]
@@ -158,6 +158,40 @@ def test_conv_mm_family(dev, B, R, M, L, KT, pad, dil):
     out = ops.conv1d(xd, wd, b.to(dev), pad=pad, dil=dil, prologue=1, pro_stats=stats, pro_gamma=gamma.to(dev),
                      pro_beta=beta.to(dev), groups=G, res=res.to(dev))
     assert rel_err(out, ref) < TOL
+
+
+@pytest.mark.parametrize("B,L,pro,res", [(1, 256, 0, 0), (2, 1024, 1, 1), (3, 768, 1, 0), (1, 256 * 300, 1, 1)])
+def test_conv_stream32(dev, B, L, pro, res):
+    """conv_stream.hip: persistent 32 -> 32 channel kernel-3 conv (depth-1 ConvBlocks), forward and data gradient,
+    with / without the GroupNorm+SiLU prologue and the residual; the last case gives every workgroup > 1 tile."""
+    from audio_diffusion_pytorch_amd import _C
+    if dev.type != "cuda" and L > 4096:
+        pytest.skip("emulator: large case runs on the GPU only")
+    C, G = 32, 8
+    x = (rnd(B, C, L, seed=1) * 1.3 + 0.2).requires_grad_()
+    w, b = rnd(C, C, 3, seed=2, scale=0.2), rnd(C, seed=3)
+    gamma, beta = rnd(C, seed=4) * 0.5 + 1, rnd(C, seed=5) * 0.1
+    xd, wd = x.detach().to(dev), w.to(dev)
+    d = _C.ConvDesc(_C.ptr(xd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(xd), None, B, C, C, L, C, L,
+                    3, 1, 1, 1, 1, 0, 0, 1, 0, 1, 0)
+    assert _C.query("adp_conv1d_tile", d) == 32256, "case must dispatch to the streaming kernel"
+    r = rnd(B, C, L, seed=6) if res else None
+    if pro:
+        ref = F.conv1d(ref_gn_silu(x.detach(), G, gamma, beta), w, b, padding=1)
+        stats = ops.gn_stats(xd, G)
+        out = ops.conv1d(xd, wd, b.to(dev), pad=1, prologue=1, pro_stats=stats, pro_gamma=gamma.to(dev),
+                         pro_beta=beta.to(dev), groups=G, res=r.to(dev) if res else None)
+    else:
+        ref = F.conv1d(x.detach(), w, b, padding=1)
+        out = ops.conv1d(xd, wd, b.to(dev), pad=1, res=r.to(dev) if res else None)
+    if res:
+        ref = ref + r
+    assert rel_err(out, ref) < TOL
+    y = F.conv1d(x, w, None, padding=1)
+    dy = rnd(*y.shape, seed=9)
+    (dx_ref,) = torch.autograd.grad(y, x, dy)
+    dx = ops.conv1d(dy.to(dev), wd, None, pad=1, transposed=True, res=r.to(dev) if res else None)
+    assert rel_err(dx, dx_ref + (r if res else 0)) < TOL
 
 
 MM_RESAMPLE_CASES = [
