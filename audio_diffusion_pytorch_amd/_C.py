@@ -73,6 +73,10 @@ SIGNATURES = {
     "adp_mse_bwd": (c_int, [P, P, P, I, P, P]),
     "adp_v_step": (c_int, [P, P, P, I, P, P]),
     "adp_add": (c_int, [P, P, I, P, P]),
+    "adp_v_inpaint_step": (c_int, [P, P, P, P, P, P, I, P, P]),
+    "adp_cfg_mix": (c_int, [P, I, F, P, P]),
+    "adp_select_rows": (c_int, [P, P, P, I, I, P, P]),
+    "adp_resample": (c_int, [P, P, I, I, I, I, I, I, I, P, P]),
     "adp_attn_fwd": (c_int, [P, P, P, I, I, I, I, I, I, I, P, P, P]),
     "adp_attn_bwd_ws_bytes": (I, [I, I, I, I, I]),
     "adp_attn_bwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P, P]),
@@ -114,12 +118,12 @@ def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def ptr(t):
-    """Device pointer of a contiguous fp32 tensor (None -> NULL)."""
+def ptr(t, dtype=torch.float32):
+    """Device pointer of a contiguous fp32 (or `dtype`) tensor (None -> NULL)."""
     if t is None:
         return None
-    if t.dtype != torch.float32:
-        raise TypeError(f"adp kernels are fp32; got {t.dtype}")
+    if t.dtype != dtype:
+        raise TypeError(f"adp kernel argument must be {dtype}; got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError("adp kernels need contiguous tensors")
     if not t.is_cuda and not _allow_cpu:

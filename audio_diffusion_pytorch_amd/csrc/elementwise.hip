@@ -62,6 +62,42 @@ __global__ __launch_bounds__(256) void v_step_kernel(const float* x, const float
   }
 }
 
+// one VInpainter resample step (diffusion.py:339-350): rotate (x, v) from noise level i to level j, re-noise the
+// source to level j with the caller's draw, keep the source where mask is set
+__global__ __launch_bounds__(256) void v_inpaint_kernel(const float* x, const float* v, const float* src,
+                                                        const float* noise, const uint8_t* mask, const float* ab4,
+                                                        int64_t n, float* xo) {
+  const float a0 = ab4[0], b0 = ab4[1], a1 = ab4[2], b1 = ab4[3];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float xv = x[i], vv = v[i];
+    const float x_pred = a0 * xv - b0 * vv;
+    const float n_pred = b0 * xv + a0 * vv;
+    const float xn = a1 * x_pred + b1 * n_pred;
+    const float sn = a1 * src[i] + b1 * noise[i];
+    xo[i] = mask[i] ? sn : xn;
+  }
+}
+
+// classifier-free guidance mix of the two halves of a batched [2B, ...] evaluation:
+// out = o_masked + (o - o_masked) * scale,  o = y[:half], o_masked = y[half:]
+__global__ __launch_bounds__(256) void cfg_mix_kernel(const float* y, int64_t half, float scale, float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < half; i += (int64_t)gridDim.x * 256) {
+    const float o = y[i], om = y[half + i];
+    out[i] = om + (o - om) * scale;
+  }
+}
+
+// out[b, :] = pick[b] ? a[b, :] : bsrc[b, :]   (per-row select; CFG's training-time embedding mask and its batch
+// doubling write through it)
+__global__ __launch_bounds__(256) void select_rows_kernel(const float* a, const float* bsrc, const uint8_t* pick,
+                                                          int64_t rows, int64_t per, float* out) {
+  const int64_t n = rows * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / per;
+    out[i] = pick[r] ? a[i] : bsrc[i];
+  }
+}
+
 __global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, int64_t n, float* y) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = a[i] + b[i];
 }
@@ -188,6 +224,29 @@ extern "C" int adp_v_step(const float* x, const float* v, const float* ab4, int6
   if (!x || !v || !ab4 || !x_out) return ADP_ERR_NULL;
   if (n <= 0) return ADP_ERR_SHAPE;
   ADP_LAUNCH(v_step_kernel, dim3(stream_grid(n)), dim3(256), stream, x, v, ab4, n, x_out);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_v_inpaint_step(const float* x, const float* v, const float* source, const float* noise,
+                                  const uint8_t* mask, const float* ab4, int64_t n, float* x_out, void* stream) {
+  if (!x || !v || !source || !noise || !mask || !ab4 || !x_out) return ADP_ERR_NULL;
+  if (n <= 0) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(v_inpaint_kernel, dim3(stream_grid(n)), dim3(256), stream, x, v, source, noise, mask, ab4, n, x_out);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_cfg_mix(const float* y, int64_t half, float scale, float* out, void* stream) {
+  if (!y || !out) return ADP_ERR_NULL;
+  if (half <= 0) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(cfg_mix_kernel, dim3(stream_grid(half)), dim3(256), stream, y, half, scale, out);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_select_rows(const float* a, const float* b, const uint8_t* pick, int64_t rows, int64_t per,
+                               float* out, void* stream) {
+  if (!a || !b || !pick || !out) return ADP_ERR_NULL;
+  if (rows <= 0 || per <= 0) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(select_rows_kernel, dim3(stream_grid(rows * per)), dim3(256), stream, a, b, pick, rows, per, out);
   return ADP_LAUNCH_OK();
 }
 

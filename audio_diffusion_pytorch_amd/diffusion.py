@@ -1,6 +1,6 @@
 """v-objective diffusion on the gfx950 kernels: `VDiffusion` (training loss) and `VSampler`
-(DDIM-style loop), API-compatible with /root/reference/audio_diffusion_pytorch/diffusion.py:15-30,
-:62-95, :133-190.
+(DDIM-style loop) and `VInpainter` (RePaint-style resampling loop), API-compatible with
+/root/reference/audio_diffusion_pytorch/diffusion.py:15-30, :62-95, :133-190, :300-354.
 
 Differences from the reference are structural, not numerical:
   * noising (x_noisy, v_target) is one fused kernel (2 reads, 2 writes) instead of ~6 elementwise ops;
@@ -204,3 +204,53 @@ class VSampler(Sampler):
             sab.copy_(ab[i])
             graph.replay()
         return sx.clone()
+
+
+""" Inpainters """
+
+
+class Inpainter(nn.Module):
+    pass
+
+
+class VInpainter(Inpainter):
+    """diffusion.py:306-354.  Per resample the reference runs ~10 elementwise ops; here the rotation to the next
+    noise level, the re-noising of the source and the masked blend are ONE kernel (adp_v_inpaint_step).  The noise
+    draws stay on torch's generator (`torch.randn_like(source)`, same call order as the reference) so seeding
+    behaves identically; the (alpha, beta) table lives on the device and the loop never syncs with the host."""
+
+    diffusion_types = [VDiffusion]
+
+    def __init__(self, net: nn.Module, schedule: Schedule = LinearSchedule()):
+        super().__init__()
+        self.net = net
+        self.schedule = schedule
+
+    def get_alpha_beta(self, sigmas: Tensor) -> Tuple[Tensor, Tensor]:
+        angle = sigmas * pi / 2
+        return torch.cos(angle), torch.sin(angle)
+
+    @torch.no_grad()
+    def forward(self, source: Tensor, mask: Tensor, num_steps: int, num_resamples: int, show_progress: bool = False,
+                x_noisy: Optional[Tensor] = None, **kwargs) -> Tensor:
+        x = (x_noisy if x_noisy is not None else torch.randn_like(source)).contiguous()
+        b = x.shape[0]
+        sigmas = self.schedule(num_steps + 1, device=x.device).to(torch.float32)
+        alphas, betas = self.get_alpha_beta(sigmas)
+        sig = sigmas[:, None].expand(num_steps + 1, b).contiguous()
+        # rows (a_i, b_i, a_j, b_j) for j = i (re-noise at the same level) and j = i + 1 (move on)
+        ab_stay = torch.stack([alphas[:-1], betas[:-1], alphas[:-1], betas[:-1]], dim=1).contiguous()
+        ab_next = torch.stack([alphas[:-1], betas[:-1], alphas[1:], betas[1:]], dim=1).contiguous()
+        src = source.to(torch.float32).contiguous()
+        mask_u8 = mask.expand_as(src).to(torch.uint8).contiguous()
+        host_sigmas = self.schedule(num_steps + 1, device="cpu").tolist() if show_progress else None
+        bar = tqdm(range(num_steps), disable=not show_progress)
+        for i in bar:
+            for r in range(num_resamples):
+                v = self.net(x, sig[i], **kwargs)
+                last = r == num_resamples - 1
+                x = ops.v_inpaint_step(x, v.contiguous(), src, torch.randn_like(src), mask_u8,
+                                       (ab_next if last else ab_stay)[i])
+            if host_sigmas is not None:
+                bar.set_description(f"Inpainting (noise={host_sigmas[i + 1]:.2f})")
+        return x

@@ -268,6 +268,43 @@ def v_step(x: Tensor, v: Tensor, ab4: Tensor, out: Optional[Tensor] = None) -> T
     return out
 
 
+def v_inpaint_step(x: Tensor, v: Tensor, source: Tensor, noise: Tensor, mask_u8: Tensor, ab4: Tensor,
+                   out: Optional[Tensor] = None) -> Tensor:
+    if out is None:
+        out = torch.empty_like(x)
+    _C.call("adp_v_inpaint_step", ptr(x), ptr(v), ptr(source), ptr(noise), ptr(mask_u8, torch.uint8), ptr(ab4),
+            x.numel(), ptr(out), _C.stream())
+    return out
+
+
+def cfg_mix(y2: Tensor, scale: float) -> Tensor:
+    """y2 [2B, ...] -> y2[B:] + (y2[:B] - y2[B:]) * scale."""
+    half = y2.numel() // 2
+    out = torch.empty((y2.shape[0] // 2,) + tuple(y2.shape[1:]), dtype=torch.float32, device=y2.device)
+    _C.call("adp_cfg_mix", ptr(y2), half, float(scale), ptr(out), _C.stream())
+    return out
+
+
+def select_rows(a: Tensor, b: Tensor, pick_u8: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """out[r] = pick[r] ? a[r] : b[r] for the leading dimension r."""
+    rows = a.shape[0]
+    per = a.numel() // rows
+    if out is None:
+        out = torch.empty_like(a)
+    _C.call("adp_select_rows", ptr(a), ptr(b), ptr(pick_u8, torch.uint8), rows, per, ptr(out), _C.stream())
+    return out
+
+
+def resample(x: Tensor, kern: Tensor, fi: int, fo: int, width: int, out_len: int) -> Tensor:
+    """x [B, C, length], kern [fo, J] -> [B, C, out_len] (adp_resample)."""
+    B, C, length = x.shape
+    J = kern.shape[-1]
+    out = torch.empty((B, C, out_len), dtype=torch.float32, device=x.device)
+    _C.tag(bytes=4 * (x.numel() + out.numel()), shape=f"rows{B * C} len{length} {fi}->{fo}")
+    _C.call("adp_resample", ptr(x), ptr(kern), B * C, length, fi, fo, J, width, out_len, ptr(out), _C.stream())
+    return out
+
+
 def add(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
     if out is None:
         out = torch.empty_like(a)

@@ -345,8 +345,10 @@ class _Run:
                 # data gradient w.r.t. x only uses the first C input channels of the 1x1 weight
                 dx = ops.conv1d(gy, w[:, :C, :].contiguous(), None, transposed=True, res=gy)
                 if self.ctx_grads is not None and self.ctx_needs[ctx_index]:
-                    dctx = ops.conv1d(gy, w[:, C:, :].contiguous(), None, transposed=True)
-                    self.ctx_grads[ctx_index] = dctx
+                    # the down- and the up-branch InjectChannelsItem of a depth read the same context tensor:
+                    # the second one to run accumulates through the conv's residual epilogue
+                    prev = self.ctx_grads[ctx_index]
+                    self.ctx_grads[ctx_index] = ops.conv1d(gy, w[:, C:, :].contiguous(), None, transposed=True, res=prev)
                 return dx
             self.tape.append((bwd, None))
         return y

@@ -1,6 +1,6 @@
 """Host helpers with the reference's semantics (/root/reference/audio_diffusion_pytorch/utils.py:15-70, :123-125).
 Pure host-side glue: kwargs routing for DiffusionModel and small predicates.  The windowed-sinc
-`resample` family (utils.py:82-117; SURVEY 8f-1 "next" row) runs as one strided conv on the device."""
+`resample` family (utils.py:82-117) runs on the polyphase HIP kernel adp_resample."""
 from functools import reduce
 from inspect import isfunction
 from math import ceil, floor, log2, pi
@@ -68,26 +68,47 @@ def prefix_dict(prefix: str, d: Dict) -> Dict:
     return {prefix + str(k): v for k, v in d.items()}
 
 
-def resample(waveforms: Tensor, factor_in: int, factor_out: int, rolloff: float = 0.99,
-             lowpass_filter_width: int = 6) -> Tensor:
-    """Windowed-sinc resampler as ONE strided conv (utils.py:82-109 semantics).
-    TODO(next row f-1): polyphase HIP kernel fusing the (l k) interleave; today this single conv runs on
-    PyTorch-ROCm (MIOpen) and is outside the measured denoising step."""
-    b, c, length = waveforms.shape
-    target = int(factor_out * length / factor_in)
-    kw = dict(device=waveforms.device, dtype=waveforms.dtype)
+_KERNEL_BANKS: Dict = {}
+
+
+def resample_kernels(factor_in: int, factor_out: int, rolloff: float, lowpass_filter_width: int):
+    """The reference's [factor_out, J] windowed-sinc kernel bank and its `width` (utils.py:91-102), evaluated with
+    the reference's own fp32 torch expressions on the CPU (the reference CPU path's bits), cached per configuration."""
+    key = (factor_in, factor_out, rolloff, lowpass_filter_width)
+    hit = _KERNEL_BANKS.get(key)
+    if hit is not None:
+        return hit
+    kw = dict(device="cpu", dtype=torch.float32)
     base = min(factor_in, factor_out) * rolloff
     width = ceil(lowpass_filter_width * factor_in / base)
     idx = torch.arange(-width, width + factor_in, **kw)[None, None] / factor_in
     t = torch.arange(0, -factor_out, step=-1, **kw)[:, None, None] / factor_out + idx
     t = (t * base).clamp(-lowpass_filter_width, lowpass_filter_width) * pi
     window = torch.cos(t / lowpass_filter_width / 2) ** 2
-    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t)
-    kernels = kernels * (window * (base / factor_in))
-    w = F.pad(waveforms.reshape(b * c, length), (width, width + factor_in))
-    out = F.conv1d(w[:, None], kernels, stride=factor_in)
-    out = out.reshape(b, c, factor_out, -1).permute(0, 1, 3, 2).reshape(b, c, -1)
-    return out[..., :target]
+    scale = base / factor_in
+    kernels = torch.where(t == 0, torch.tensor(1.0).to(t), t.sin() / t)
+    kernels *= window * scale
+    hit = (kernels.reshape(factor_out, -1).contiguous(), width)
+    _KERNEL_BANKS[key] = hit
+    return hit
+
+
+def resample(waveforms: Tensor, factor_in: int, factor_out: int, rolloff: float = 0.99,
+             lowpass_filter_width: int = 6) -> Tensor:
+    """Windowed-sinc resampler (utils.py:82-109 semantics) on the polyphase HIP kernel `adp_resample`: the padding,
+    the phase interleave "(b c) k l -> b c (l k)" and the crop are index arithmetic inside the kernel."""
+    from . import ops
+    b, c, length = waveforms.shape
+    target = int(factor_out * length / factor_in)
+    kernels, width = resample_kernels(factor_in, factor_out, rolloff, lowpass_filter_width)
+    x = waveforms.to(torch.float32).contiguous()
+    dkey = (factor_in, factor_out, rolloff, lowpass_filter_width, str(x.device))
+    bank = _KERNEL_BANKS.get(dkey)
+    if bank is None:  # device copy of the coefficient bank, made once per device
+        bank = kernels.to(x.device)
+        _KERNEL_BANKS[dkey] = bank
+    out = ops.resample(x, bank, factor_in, factor_out, width, target)
+    return out.to(waveforms.dtype)
 
 
 def downsample(waveforms: Tensor, factor: int, **kwargs) -> Tensor:

@@ -214,6 +214,28 @@ int adp_attn_bwd(const float* q, const float* k, const float* v, const float* o,
                  int64_t kv_bstride, float* dq, float* dk, float* dv, float* ws, void* stream);
 int64_t adp_attn_bwd_ws_bytes(int64_t B, int64_t H, int64_t D, int64_t n, int64_t m);
 
+/* one VInpainter resample step (diffusion.py:339-350): x_new = mask ? a1*source + b1*noise
+ *                                                                  : a1*(a0 x - b0 v) + b1*(b0 x + a0 v);
+ * ab4 = device [a_i, b_i, a_j, b_j] (j = i + 1 on the last resample of a step, else i); mask is 1 byte / element */
+int adp_v_inpaint_step(const float* x, const float* v, const float* source, const float* noise, const uint8_t* mask,
+                       const float* ab4, int64_t n, float* x_out, void* stream);
+
+/* ClassifierFreeGuidancePlugin (components.py:66-69): the guided and the masked evaluation run as ONE [2B, ...]
+ * U-Net call; out = y[half:] + (y[:half] - y[half:]) * scale.  adp_select_rows: out[r,:] = pick[r] ? a[r,:] : b[r,:]
+ * (training-time embedding mask). */
+int adp_cfg_mix(const float* y, int64_t half, float scale, float* out, void* stream);
+int adp_select_rows(const float* a, const float* b, const uint8_t* pick, int64_t rows, int64_t per, float* out,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Windowed-sinc polyphase resampler (utils.py:82-109: F.pad + strided conv1d + "(b c) k l -> b c (l k)" + crop):
+ *   out[row, l*fo + k] = sum_{j<J} kern[k*J + j] * xpad[row, l*fi + j],  xpad = x with `width` zeros on the left
+ *   and width + fi on the right.  rows = B*C, kern = the reference's [fo, 1, J] kernel bank (built by the host with
+ *   the reference's own formula), out_len = int(fo * length / fi) (the crop), out is [rows, out_len].
+ * ------------------------------------------------------------------------------------------ */
+int adp_resample(const float* x, const float* kern, int64_t rows, int64_t length, int64_t fi, int64_t fo, int64_t J,
+                 int64_t width, int64_t out_len, float* out, void* stream);
+
 /* y = a + b (n elements); used where two gradient streams meet */
 int adp_add(const float* a, const float* b, int64_t n, float* y, void* stream);
 

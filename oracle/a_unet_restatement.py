@@ -305,6 +305,45 @@ class UNetV0Oracle(nn.Module):
         return self.run_block(0, x, features, embedding, channels)
 
 
+def rand_bool(shape, proba: float) -> Tensor:
+    """a_unet rand_bool [recalled]: Bernoulli(proba) draw as a bool tensor (constant for proba 0 / 1)."""
+    if proba == 1:
+        return torch.ones(shape, dtype=torch.bool)
+    if proba == 0:
+        return torch.zeros(shape, dtype=torch.bool)
+    return torch.bernoulli(torch.full(shape, float(proba))).to(torch.bool)
+
+
+class ClassifierFreeGuidanceOracle(nn.Module):
+    """Restatement of a_unet ClassifierFreeGuidancePlugin around a UNetV0Oracle (components.py:66-69; SURVEY
+    Appendix A [recalled]): a learned positional FixedEmbedding stands in for the masked embedding; training masks
+    whole batch elements with probability `embedding_mask_proba`; `embedding_scale != 1` evaluates the net twice and
+    extrapolates  out_masked + (out - out_masked) * scale."""
+
+    def __init__(self, net: nn.Module, embedding_max_length: int, embedding_features: int):
+        super().__init__()
+        self.net = net
+        self.max_length = embedding_max_length
+        self.fixed_embedding = nn.Embedding(embedding_max_length, embedding_features)
+
+    def forward(self, x: Tensor, time: Optional[Tensor] = None, *, embedding: Optional[Tensor] = None,
+                embedding_scale: float = 1.0, embedding_mask_proba: float = 0.0, batch_mask: Optional[Tensor] = None,
+                **kwargs) -> Tensor:
+        assert embedding is not None, "ClassiferFreeGuidancePlugin requires embedding"
+        b, length = embedding.shape[0], embedding.shape[1]
+        assert length <= self.max_length
+        fixed = self.fixed_embedding(torch.arange(length))[None].expand(b, -1, -1)
+        if embedding_mask_proba > 0.0:
+            if batch_mask is None:  # `batch_mask` lets a test inject the draw
+                batch_mask = rand_bool((b, 1, 1), embedding_mask_proba)
+            embedding = torch.where(batch_mask.reshape(b, 1, 1), fixed, embedding)
+        if embedding_scale != 1.0:
+            out = self.net(x, time, embedding=embedding, **kwargs)
+            out_masked = self.net(x, time, embedding=fixed, **kwargs)
+            return out_masked + (out - out_masked) * embedding_scale
+        return self.net(x, time, embedding=embedding, **kwargs)
+
+
 def AppendChannelsOracle(net_t, channels: int):
     """Restatement of AppendChannelsPlugin (components.py:162-180)."""
 

@@ -7,6 +7,8 @@ Follows /root/reference/audio_diffusion_pytorch/diffusion.py:
   * LinearSchedule.forward :147-148 linspace(start, end, num_steps)
   * VSampler.forward       :172-190 per step: x_pred = a_i x - b_i v ; n_pred = b_i x + a_i v ;
                                     x = a_{i+1} x_pred + b_{i+1} n_pred
+  * VInpainter.forward     :321-354 per (step i, resample r): rotate to level j = i + (r == last); re-noise the
+                                    source to level j (torch.randn_like(source)); x = s_noisy*mask + x*~mask
 and /root/reference/audio_diffusion_pytorch/utils.py:82-117 (windowed-sinc `resample`).
 
 PINNED: tests/test_oracle.py checks this restatement against the live reference module
@@ -54,6 +56,27 @@ def v_sample(net: Callable, x_noisy: Tensor, num_steps: int, sigmas: Optional[Te
         x_pred = a[i] * x_noisy - bt[i] * v
         n_pred = bt[i] * x_noisy + a[i] * v
         x_noisy = a[i + 1] * x_pred + bt[i + 1] * n_pred
+    return x_noisy
+
+
+@torch.no_grad()
+def v_inpaint(net: Callable, source: Tensor, mask: Tensor, num_steps: int, num_resamples: int,
+              x_noisy: Optional[Tensor] = None, **kw) -> Tensor:
+    """VInpainter.forward (diffusion.py:321-354) with the same torch.randn_like call order."""
+    x_noisy = x_noisy if x_noisy is not None else torch.randn_like(source)
+    b = x_noisy.shape[0]
+    sigmas = linear_schedule(num_steps + 1, device=x_noisy.device)
+    sig = sigmas[:, None].expand(num_steps + 1, b)
+    a, bt = alpha_beta(sig.reshape(num_steps + 1, b, *([1] * (x_noisy.ndim - 1))))
+    for i in range(num_steps):
+        for r in range(num_resamples):
+            v = net(x_noisy, sig[i], **kw)
+            x_pred = a[i] * x_noisy - bt[i] * v
+            n_pred = bt[i] * x_noisy + a[i] * v
+            j = int(r == num_resamples - 1)
+            x_noisy = a[i + j] * x_pred + bt[i + j] * n_pred
+            s_noisy = a[i + j] * source + bt[i + j] * torch.randn_like(source)
+            x_noisy = s_noisy * mask + x_noisy * ~mask
     return x_noisy
 
 

@@ -55,6 +55,16 @@ def main():
     out["vs_noise"] = n0
     for steps in (1, 5, 50):
         out[f"vs_out_{steps}"] = samp(n0, num_steps=steps)
+    # VInpainter (diffusion.py:306-354): seeded global generator -> the x_noisy draw and the per-resample draws
+    src = torch.randn(2, 2, 64, generator=g)
+    mask = torch.zeros(2, 2, 64, dtype=torch.bool)
+    mask[..., :24] = True
+    out["vi_source"], out["vi_mask"] = src, mask
+    inp = D.VInpainter(StubNet())
+    torch.manual_seed(77)
+    out["vi_out_4_3"] = inp(src, mask, num_steps=4, num_resamples=3)
+    torch.manual_seed(77)
+    out["vi_out_6_1"] = inp(src, mask, num_steps=6, num_resamples=1)
     # resampler
     w = torch.randn(2, 2, 512, generator=g)
     out["rs_in"] = w

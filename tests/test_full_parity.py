@@ -60,3 +60,74 @@ def test_config3_sampler_full(hip, pair):
         assert rel_err(out, ref) < 1e-3, use_graph
         out2 = model.sample(noise.to(hip), num_steps=steps)   # replays the cached graph
         assert torch.equal(out, out2)
+
+
+ATTN_README = dict(attentions=[0, 0, 0, 0, 0, 1, 1, 1, 1], attention_heads=8, attention_features=64)
+CROSS_CFG4 = dict(cross_attentions=[0, 0, 0, 1, 1, 1, 1, 1, 1], embedding_features=768, attention_heads=8,
+                  attention_features=64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra,use_emb", [(ATTN_README, False), (CROSS_CFG4, True)], ids=["readme-self-attn", "config4"])
+def test_config4_attention_full_fwd_bwd(hip, extra, use_emb):
+    """BASELINE config 4 (text-conditional UNetV0: cross attention at depths 3-8 over embedding [B, 64, 768]) and the
+    README self-attention layout, at full size with one sample (the per-rank share of global batch 8 on 8 GPUs):
+    loss, every parameter gradient and the embedding gradient against the CPU oracle at 1e-3."""
+    cfg = dict(FULL, **extra)
+    torch.manual_seed(0)
+    oracle = UNetV0Oracle(**cfg)
+    model = adp.DiffusionModel(net_t=adp.UNetV0, diffusion_sigma_distribution=FixedSigmas([0.45]), **cfg)
+    model.net.load_oracle_state_dict(oracle.state_dict())
+    model = model.to(hip)
+    g = torch.Generator().manual_seed(0)
+    x, noise = torch.randn(1, 2, 2 ** 18, generator=g), torch.randn(1, 2, 2 ** 18, generator=g)
+    kw_ref, kw = {}, {}
+    if use_emb:
+        emb = torch.randn(1, 64, 768, generator=g).requires_grad_()
+        emb_d = emb.detach().to(hip).requires_grad_()
+        kw_ref, kw = dict(embedding=emb), dict(embedding=emb_d)
+    loss_ref = ovd.v_loss(oracle, x, noise, torch.tensor([0.45]), **kw_ref)
+    loss_ref.backward()
+    loss = model(x.to(hip), noise=noise.to(hip), **kw)
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-3 * abs(loss_ref.item())
+    compare_grads(model.net, oracle)
+    if use_emb:
+        assert rel_err(emb_d.grad, emb.grad) < 1e-3
+
+
+@pytest.mark.gpu
+def test_config5_upsampler_full(hip):
+    """BASELINE config 5: DiffusionUpsampler(upsample_factor=16) on the full UNetV0 (in=4 via AppendChannels, out=2):
+    training loss + gradients on [1, 2, 2**18] (reupsample = polyphase HIP resampler down x16 then up x16) and a
+    2-step sample from [1, 2, 2**14] -> [1, 2, 2**18], against the CPU oracle."""
+    from oracle.a_unet_restatement import AppendChannelsOracle
+    torch.manual_seed(0)
+    cfg = dict(FULL)
+    cfg.pop("in_channels")
+    up = adp.DiffusionUpsampler(net_t=adp.UNetV0, in_channels=2, upsample_factor=16, sampler_use_graph=False,
+                                diffusion_sigma_distribution=FixedSigmas([0.6]), **cfg)
+    oracle = AppendChannelsOracle(lambda **kw: UNetV0Oracle(**kw), channels=2)(in_channels=2, **cfg)
+    up.net.net.load_oracle_state_dict(oracle.net.state_dict())
+    up = up.to(hip)
+    g = torch.Generator().manual_seed(1)
+    x, noise = torch.randn(1, 2, 2 ** 18, generator=g), torch.randn(1, 2, 2 ** 18, generator=g)
+    re_ref = ovd.upsample(ovd.downsample(x.clone(), 16), 16)
+    assert rel_err(up.reupsample(x.to(hip)), re_ref) < 1e-4
+    loss_ref = ovd.v_loss(oracle, x, noise, torch.tensor([0.6]), append_channels=re_ref)
+    loss_ref.backward()
+    loss = up(x.to(hip), noise=noise.to(hip))
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-3 * abs(loss_ref.item())
+    compare_grads(up.net.net, oracle.net)
+    low = torch.randn(1, 2, 2 ** 14, generator=g)
+    start = torch.randn(1, 2, 2 ** 18, generator=g)
+    re_low = ovd.upsample(low, 16)
+    ref = ovd.v_sample(oracle, start, 2, append_channels=re_low)
+    out = up.sampler(start.to(hip), num_steps=2, append_channels=up_sample_input(up, low.to(hip)))
+    assert out.shape == (1, 2, 2 ** 18) and rel_err(out, ref) < 1e-3
+
+
+def up_sample_input(up, low):
+    from audio_diffusion_pytorch_amd.utils import upsample
+    return upsample(low, factor=up.upsample_factor)

@@ -45,8 +45,24 @@ def test_oracle_resample_matches_golden():
     for f in (2, 4, 16):
         assert torch.equal(ovd.downsample(w, f), GOLD[f"rs_down_{f}"])
         assert torch.equal(ovd.upsample(w[..., :64], f), GOLD[f"rs_up_{f}"])
-        assert torch.equal(putils.downsample(w, f), GOLD[f"rs_down_{f}"])
-        assert torch.equal(putils.upsample(w[..., :64], f), GOLD[f"rs_up_{f}"])
+
+
+def test_product_resample_matches_golden(dev):
+    """utils.resample on the polyphase HIP kernel (adp_resample) against the live reference's outputs (fixtures):
+    same taps, same padding / interleave / crop index math; only the fp32 summation order differs from conv1d."""
+    w = GOLD["rs_in"]
+    for f in (2, 4, 16):
+        down = putils.downsample(w.to(dev), f)
+        assert down.shape == GOLD[f"rs_down_{f}"].shape
+        assert rel_err(down, GOLD[f"rs_down_{f}"]) < 1e-5, f
+        up = putils.upsample(w[..., :64].contiguous().to(dev), f)
+        assert up.shape == GOLD[f"rs_up_{f}"].shape
+        assert rel_err(up, GOLD[f"rs_up_{f}"]) < 1e-5, f
+    # a length that is not a multiple of the factor, several rows, and the kernel bank equals the reference's bits
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 1000, generator=g)
+    assert rel_err(putils.resample(x.to(dev), 3, 2), ovd.resample(x, 3, 2)) < 1e-5
+    assert rel_err(putils.downsample(x.to(dev), 16), ovd.downsample(x, 16)) < 1e-5
 
 
 def test_host_helpers_match_golden():
@@ -74,6 +90,24 @@ def test_oracle_matches_live_reference():
     assert torch.equal(D.VDiffusion(net, sigma_distribution=Fixed())(x), ovd.v_loss(net, x, noise, sig))
     w = torch.randn(1, 2, 300, generator=g)
     assert torch.equal(U.downsample(w, 3), ovd.downsample(w, 3)) and torch.equal(U.upsample(w, 3), ovd.upsample(w, 3))
+    mask = torch.rand(2, 2, 96, generator=g) > 0.5
+    torch.manual_seed(11)
+    ref = D.VInpainter(net)(x, mask, num_steps=5, num_resamples=2)
+    torch.manual_seed(11)
+    assert torch.equal(ref, ovd.v_inpaint(net, x, mask, 5, 2))
+
+
+def test_oracle_and_product_inpainter_match_golden(emul):
+    """VInpainter: the oracle restatement is bit-equal to the live reference's fixtures; the product (one fused
+    kernel per resample, torch's generator for the draws in the reference's call order) matches within fp32
+    reassociation."""
+    net = StubNet()
+    for steps, res in ((4, 3), (6, 1)):
+        torch.manual_seed(77)
+        assert torch.equal(ovd.v_inpaint(net, GOLD["vi_source"], GOLD["vi_mask"], steps, res), GOLD[f"vi_out_{steps}_{res}"])
+        torch.manual_seed(77)
+        out = adp.VInpainter(net)(GOLD["vi_source"], GOLD["vi_mask"], num_steps=steps, num_resamples=res)
+        assert rel_err(out, GOLD[f"vi_out_{steps}_{res}"]) < 1e-5
 
 
 def test_product_vdiffusion_and_sampler_match_golden(emul):

@@ -90,14 +90,16 @@ def test_unet_inject_channels(dev):
     g = torch.Generator().manual_seed(2)
     x = torch.randn(2, 2, 64, generator=g)
     t = torch.tensor([0.2, 0.9])
-    ctx = torch.randn(2, 3, 16, generator=g)
+    ctx = torch.randn(2, 3, 16, generator=g).requires_grad_()
+    ctx_d = ctx.detach().to(dev).requires_grad_()
     y_ref = oracle(x, t, channels=[None, ctx])
-    y = net(x.to(dev), t.to(dev), channels=[None, ctx.to(dev)])
+    y = net(x.to(dev), t.to(dev), channels=[None, ctx_d])
     assert rel_err(y, y_ref) < TOL
     gy = torch.randn(y_ref.shape, generator=g)
     y_ref.backward(gy)
     y.backward(gy.to(dev))
     compare_grads(net, oracle)
+    assert rel_err(ctx_d.grad, ctx.grad) < TOL  # both InjectChannelsItems of the depth feed the context gradient
 
 
 def test_vdiffusion_loss_and_grads(dev):
@@ -173,3 +175,88 @@ def test_unet_attention_self_and_cross(dev):
     y.backward(gy.to(dev))
     compare_grads(net, oracle)
     assert rel_err(emb_d.grad, emb.grad) < TOL
+
+
+def test_classifier_free_guidance(dev):
+    """UNetV0(use_embedding_cfg=True): training-time batch masking (gradients of the U-Net, of the incoming embedding
+    and of the fixed positional table) and guided sampling (batched [x|x] evaluation + fused mix) against the
+    ClassifierFreeGuidanceOracle restatement (components.py:66-69)."""
+    from oracle.a_unet_restatement import ClassifierFreeGuidanceOracle
+    torch.manual_seed(0)
+    inner = UNetV0Oracle(**ATTN)
+    oracle = ClassifierFreeGuidanceOracle(inner, embedding_max_length=7, embedding_features=12)
+    net = adp.UNetV0(dim=1, use_embedding_cfg=True, embedding_max_length=7, **ATTN)
+    assert isinstance(net, adp.ClassifierFreeGuidanceNet)
+    net.net.load_oracle_state_dict(inner.state_dict())
+    with torch.no_grad():
+        net.fixed_embedding.weight.copy_(oracle.fixed_embedding.weight)
+    net = net.to(dev)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 2, 96, generator=g)
+    t = torch.tensor([0.15, 0.65, 0.4])
+    emb = torch.randn(3, 5, 12, generator=g).requires_grad_()
+    bm = torch.tensor([True, False, True])
+    # training path: masked batch elements see the fixed embedding
+    y_ref = oracle(x, t, embedding=emb, embedding_mask_proba=0.5, batch_mask=bm)
+    emb_d = emb.detach().to(dev).requires_grad_()
+    y = net(x.to(dev), t.to(dev), embedding=emb_d, embedding_mask_proba=0.5, batch_mask=bm.to(dev))
+    assert rel_err(y, y_ref) < TOL
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    y.backward(gy.to(dev))
+    compare_grads(net.net, inner)
+    assert rel_err(emb_d.grad, emb.grad) < TOL
+    assert rel_err(net.fixed_embedding.weight.grad, oracle.fixed_embedding.weight.grad) < TOL
+    # guided sampling path: one batched evaluation, out_masked + (out - out_masked) * scale
+    with torch.no_grad():
+        s_ref = oracle(x, t, embedding=emb.detach(), embedding_scale=5.0)
+        s = net(x.to(dev), t.to(dev), embedding=emb.detach().to(dev), embedding_scale=5.0)
+    assert rel_err(s, s_ref) < TOL
+    # through the model API (README.md:62-76): kwargs reach the plugin via DiffusionModel.sample
+    model = adp.DiffusionModel(net_t=adp.UNetV0, use_embedding_cfg=True, embedding_max_length=7,
+                               sampler_use_graph=False, **ATTN)
+    model.net.net.load_oracle_state_dict(inner.state_dict())
+    with torch.no_grad():
+        model.net.fixed_embedding.weight.copy_(oracle.fixed_embedding.weight)
+    model = model.to(dev)
+    out = model.sample(x.to(dev), num_steps=2, embedding=emb.detach().to(dev), embedding_scale=3.0)
+    ref = ovd.v_sample(lambda xx, tt, **kw: oracle(xx, tt, embedding=emb.detach(), embedding_scale=3.0), x, 2)
+    assert rel_err(out, ref) < TOL
+
+
+def test_diffusion_autoencoder(dev):
+    """DiffusionAE (models.py:70-131): encoder latent injected at inject_depth, loss + encoder gradient through the
+    inject conv's data gradient, decode() with the closest_power_2 noise length rule."""
+    class Enc(adp.EncoderBase):
+        def __init__(self):
+            super().__init__()
+            self.out_channels, self.downsample_factor = 3, 4
+            self.conv = torch.nn.Conv1d(2, 3, kernel_size=4, stride=4)
+
+        def forward(self, x, with_info=False):
+            z = torch.tanh(self.conv(x))
+            return (z, {"z": z}) if with_info else z
+
+    torch.manual_seed(0)
+    cfg = dict(channels=[8, 16], factors=[2, 2], items=[1, 1], modulation_features=32)
+    enc = Enc()
+    ae = adp.DiffusionAE(net_t=adp.UNetV0, in_channels=2, encoder=enc, inject_depth=1,
+                         diffusion_sigma_distribution=FixedSigmas([0.3, 0.7]), sampler_use_graph=False, **cfg)
+    oracle = UNetV0Oracle(in_channels=2, context_channels=[0, 3], **cfg)
+    ae.net.load_oracle_state_dict(oracle.state_dict())
+    ae = ae.to(dev)
+    import copy
+    enc_ref = copy.deepcopy(enc).cpu()
+    g = torch.Generator().manual_seed(2)
+    x, noise = torch.randn(2, 2, 64, generator=g), torch.randn(2, 2, 64, generator=g)
+    z_ref = enc_ref(x)
+    loss_ref = ovd.v_loss(oracle, x, noise, torch.tensor([0.3, 0.7]), channels=[None, z_ref])
+    loss_ref.backward()
+    loss, info = ae(x.to(dev), with_info=True, noise=noise.to(dev))
+    loss.backward()
+    assert "z" in info and abs(loss.item() - loss_ref.item()) < TOL * abs(loss_ref.item())
+    compare_grads(ae.net, oracle)
+    assert rel_err(ae.encoder.conv.weight.grad, enc_ref.conv.weight.grad) < TOL
+    z = enc_ref(x).detach()
+    out = ae.decode(z.to(dev), num_steps=2, generator=None)
+    assert out.shape == (2, 2, 64)  # closest_power_2(16 * 4)
