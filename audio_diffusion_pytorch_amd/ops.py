@@ -185,15 +185,22 @@ def linear_bwd_data(dy: Tensor, w: Tensor, dxa: Optional[Tensor] = None, accumul
 
 
 def linear_bwd_weight(dy: Tensor, x: Tensor, act: int = 0, dw: Optional[Tensor] = None,
-                      dbias: Optional[Tensor] = None, want_bias: bool = True, accumulate: bool = False):
-    B, N = dy.shape
+                      dbias: Optional[Tensor] = None, want_bias: bool = True, accumulate: bool = False,
+                      rows: Optional[int] = None, dy_bstride: Optional[int] = None):
+    """dy [B, N]; or, with `rows`, a 1-D view whose element [b*dy_bstride + n] is dy[b, n] for n < rows (a column
+    slice of a wider table, e.g. one depth's rows of the conditioning bank)."""
+    if rows is None:
+        B, N = dy.shape
+        dy_bstride = N
+    else:
+        B, N = x.shape[0], rows
     K = x.shape[1]
     if dw is None:
         dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
     if dbias is None and want_bias:
         dbias = torch.empty((N,), dtype=torch.float32, device=dy.device)
     _C.tag(bytes=4 * (dw.numel() + B * N + x.numel()), shape=f"B{B} K{K} N{N}")
-    _C.call("adp_linear_bwd_weight", ptr(dy), N, ptr(x), B, K, N, act, int(accumulate), ptr(dw), ptr(dbias),
+    _C.call("adp_linear_bwd_weight", ptr(dy), dy_bstride, ptr(x), B, K, N, act, int(accumulate), ptr(dw), ptr(dbias),
             _C.stream())
     return dw, dbias
 

@@ -46,7 +46,7 @@ class DataParallel(nn.Module):
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.min_bucket = min_bucket_bytes // 4
         self._works: List = []
-        self._pending = None  # (start, end) of a contiguous region not yet sent
+        self._pending: List = []  # contiguous (start, end) regions not yet sent
         self.unet = self._find_unet(module)
         if self.world > 1:
             with torch.no_grad():
@@ -79,26 +79,31 @@ class DataParallel(nn.Module):
 
     def _on_ready(self, flat: torch.Tensor, start, end):
         if start is None:  # end of backward: flush and make the compute stream wait for the collectives
-            if self._pending is not None:
-                self._send(flat, *self._pending)
-                self._pending = None
+            for reg in self._pending:
+                self._send(flat, *reg)
+            self._pending = []
             for w, buf in self._works:
                 w.wait()
                 if buf is not None:
                     buf.mul_(1.0 / self.world)
             self._works = []
             return
-        # merge adjacent regions until a bucket is big enough for the links (blocks arrive deepest-first,
-        # i.e. in DEcreasing address order, so a new region normally ends where the pending one starts)
-        if self._pending is None:
-            self._pending = (start, end)
-        elif end == self._pending[0]:
-            self._pending = (start, self._pending[1])
-        elif start == self._pending[1]:
-            self._pending = (self._pending[0], end)
+        # Regions arrive as several interleaved address-descending streams (the blocks deepest-first, and each
+        # depth's rows of the conditioning bank): merge a new region into the pending region it touches, and send a
+        # pending region once it is big enough for the links.
+        for i, (a, b) in enumerate(self._pending):
+            if end == a:
+                self._pending[i] = (start, b)
+                break
+            if start == b:
+                self._pending[i] = (a, end)
+                break
         else:
-            self._send(flat, *self._pending)
-            self._pending = (start, end)
-        if self._pending[1] - self._pending[0] >= self.min_bucket:
-            self._send(flat, *self._pending)
-            self._pending = None
+            self._pending.append((start, end))
+        keep = []
+        for a, b in self._pending:
+            if b - a >= self.min_bucket:
+                self._send(flat, a, b)
+            else:
+                keep.append((a, b))
+        self._pending = keep

@@ -141,6 +141,11 @@ class UNetV0Net(nn.Module):
             blocks.append(blk)
         self.blocks = nn.ModuleList(blocks)
         self.bank_total = off
+        # rows of the bank owned by each depth (contiguous: the bank is filled depth by depth)
+        self.bank_depth_rows = []
+        for d in range(n):
+            offs = [(o, o + c) for k, (o, c) in self.bank_slices.items() if k[0] == d]
+            self.bank_depth_rows.append((min(a for a, _ in offs), max(b for _, b in offs)) if offs else (0, 0))
         self.bank_weight = nn.Parameter(torch.cat(bank_w, 0).contiguous())
         self.bank_bias = nn.Parameter(torch.cat(bank_b, 0).contiguous())
 
@@ -220,10 +225,11 @@ class UNetV0Net(nn.Module):
         return min(a for a, _ in spans), max(b for _, b in spans)
 
     def nonblock_param_ranges(self):
-        """Maximal contiguous ranges of the parameters outside the blocks (time MLP + conditioning bank); their
-        gradients are final only after conditioning_backward."""
+        """Maximal contiguous ranges of the parameters outside the blocks and the conditioning bank's weight (time
+        MLP + bank bias); their gradients are final only after conditioning_backward.  (The bank weight is handed
+        out per depth.)"""
         t = self._param_offsets()
-        spans = sorted(v for k, v in t.items() if not k.startswith("blocks."))
+        spans = sorted(v for k, v in t.items() if not k.startswith("blocks.") and k != "bank_weight")
         out = []
         for a, b in spans:
             if out and out[-1][1] == a:
@@ -282,9 +288,7 @@ class _Run:
     def conditioning_backward(self) -> Tensor:
         """Back-propagates dss_all through the bank and the time MLP; returns d(features)."""
         n = self.net
-        dfa = ops.linear_bwd_data(self.dss_all, n.bank_weight)
-        ops.linear_bwd_weight(self.dss_all, self.feats, act=ACT_SILU, dw=self.g(n.bank_weight),
-                              dbias=self.g(n.bank_bias))
+        dfa = ops.linear_bwd_data(self.dss_all, n.bank_weight)  # the bank's own gradient: bank_grad_for_depth
         dfeat = ops.act_bwd(self.feats, dfa, ACT_SILU)
         dcur = dfeat
         lins = [n.time_linear] + list(n.time_mlp)
@@ -295,6 +299,20 @@ class _Run:
             dcur = ops.linear_bwd_data(dp, lins[i].weight)
         ops.time_fourier_bwd(self.t, n.time_weights, dcur, dw=self.g(n.time_weights))
         return dfeat
+
+    def bank_grad_for_depth(self, d: int):
+        """Weight / bias gradient of depth d's rows of the conditioning bank.  Every Modulation / SkipModulate of
+        block d has run its backward when block d's tape entries are done, so these rows are final long before the
+        end of the backward pass -- their all-reduce overlaps the shallower blocks instead of trailing the step.
+        Returns the (start, end) row range."""
+        n = self.net
+        a, b = n.bank_depth_rows[d]
+        if b > a:
+            K = n.mf
+            ops.linear_bwd_weight(self.dss_all.view(-1)[a:], self.feats, act=ACT_SILU,
+                                  dw=self.g(n.bank_weight)[a:b], dbias=self.g(n.bank_bias)[a:b], rows=b - a,
+                                  dy_bstride=n.bank_total)
+        return a, b
 
     def ss(self, key):
         off, nout = self.net.bank_slices[key]
@@ -482,10 +500,16 @@ class _UNetFn(torch.autograd.Function):
         # gradient buffer is final (deepest blocks first), and with (flat, None, None) at the very end
         hook = getattr(net, "_grad_ready_hook", None)
         g = gy.contiguous()
+        offs = net._param_offsets()
         for fn, tag in reversed(run.tape):
             g = fn(g)
-            if tag is not None and hook is not None:
-                hook(flat, *net.block_param_range(tag))
+            if tag is not None:
+                ra, rb = run.bank_grad_for_depth(tag)
+                if hook is not None:
+                    hook(flat, *net.block_param_range(tag))
+                    if rb > ra:  # this depth's weight rows of the conditioning bank (the small bias goes out at the end)
+                        w0 = offs["bank_weight"][0]
+                        hook(flat, w0 + ra * net.mf, w0 + rb * net.mf)
         dfeat = run.conditioning_backward()
         if hook is not None:
             for a, b in net.nonblock_param_ranges():
