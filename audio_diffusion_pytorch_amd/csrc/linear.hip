@@ -5,6 +5,7 @@
 // matrix is read exactly once with 16-byte lane loads, the few activation rows sit in LDS.
 #include "adp_rt.h"
 #include "adp.h"
+#include "conv_internal.h"
 
 namespace {
 
@@ -75,12 +76,19 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* x, const f
   }
 }
 
-// partial[p][b][k] = sum_{n in block p's 256-row range} dy[b,n] w[n,k]; thread owns 4 consecutive k
+// partial[p][b][k] = sum_{n in block p's LIN_NR-row range} dy[b,n] w[n,k].  grid = (row ranges, 256-column
+// slabs): a workgroup streams LIN_NR rows x 1 KB; its four waves take a quarter of the rows each (16 independent
+// 16-byte loads in flight per lane) and meet in LDS.  [With 256 rows per workgroup and one workgroup per row range
+// the 1024x1024 time-MLP layers ran on FOUR workgroups (132 us each) and the 184 MB bank at 0.96 TB/s.]
+constexpr int LIN_NR = 64;
+
 template <int BT>
 __global__ __launch_bounds__(256) void linear_bwd_data_kernel(const float* dy, int64_t dybstride, const float* w,
                                                               int64_t B, int64_t K, int64_t N, float* ws) {
-  constexpr int NR = 256;
+  constexpr int NR = LIN_NR, RPW = NR / 4;
   __shared__ float dys[BT * NR];
+  __shared__ __attribute__((aligned(16))) float part[3][BT][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t n0 = (int64_t)blockIdx.x * NR;
   const int nr = (int)((N - n0) < NR ? (N - n0) : NR);
   for (int e = threadIdx.x; e < BT * NR; e += 256) {
@@ -89,50 +97,58 @@ __global__ __launch_bounds__(256) void linear_bwd_data_kernel(const float* dy, i
   }
   __syncthreads();
   const bool vec = (K % 4 == 0);
-  for (int64_t k = (int64_t)threadIdx.x * 4; k < K; k += 1024) {
-    float acc[BT][4];
+  const int64_t k = (int64_t)blockIdx.y * 256 + lane * 4;
+  float acc[BT][4];
 #pragma unroll
-    for (int b = 0; b < BT; ++b) acc[b][0] = acc[b][1] = acc[b][2] = acc[b][3] = 0.0f;
-    for (int j = 0; j < nr; ++j) {
-      const float* wr = w + (n0 + j) * K + k;
-      float w0, w1, w2, w3;
-      if (vec) {
-        const float4 wv = *reinterpret_cast<const float4*>(wr);
-        w0 = wv.x; w1 = wv.y; w2 = wv.z; w3 = wv.w;
-      } else {
-        w0 = wr[0];
-        w1 = (k + 1 < K) ? wr[1] : 0.0f;
-        w2 = (k + 2 < K) ? wr[2] : 0.0f;
-        w3 = (k + 3 < K) ? wr[3] : 0.0f;
-      }
+  for (int b = 0; b < BT; ++b) acc[b][0] = acc[b][1] = acc[b][2] = acc[b][3] = 0.0f;
+  if (k < K) {
+#pragma unroll 8
+    for (int jj = 0; jj < RPW; ++jj) {
+      const int j = wave * RPW + jj;
+      if (j < nr) {
+        const float* wr = w + (n0 + j) * K + k;
+        float w0, w1, w2, w3;
+        if (vec) {
+          const float4 wv = *reinterpret_cast<const float4*>(wr);
+          w0 = wv.x; w1 = wv.y; w2 = wv.z; w3 = wv.w;
+        } else {
+          w0 = wr[0];
+          w1 = (k + 1 < K) ? wr[1] : 0.0f;
+          w2 = (k + 2 < K) ? wr[2] : 0.0f;
+          w3 = (k + 3 < K) ? wr[3] : 0.0f;
+        }
 #pragma unroll
-      for (int b = 0; b < BT; ++b) {
-        const float d = dys[b * NR + j];
-        acc[b][0] = fmaf(d, w0, acc[b][0]);
-        acc[b][1] = fmaf(d, w1, acc[b][1]);
-        acc[b][2] = fmaf(d, w2, acc[b][2]);
-        acc[b][3] = fmaf(d, w3, acc[b][3]);
+        for (int b = 0; b < BT; ++b) {
+          const float d = dys[b * NR + j];
+          acc[b][0] = fmaf(d, w0, acc[b][0]);
+          acc[b][1] = fmaf(d, w1, acc[b][1]);
+          acc[b][2] = fmaf(d, w2, acc[b][2]);
+          acc[b][3] = fmaf(d, w3, acc[b][3]);
+        }
       }
     }
+  }
+  // fixed-order sum of the four waves (deterministic)
+  if (wave > 0) {
+#pragma unroll
+    for (int b = 0; b < BT; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part[wave - 1][b][lane * 4 + q] = acc[b][q];
+  }
+  __syncthreads();
+  if (wave == 0 && k < K) {
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
       if (b < B) {
         float* o = ws + ((int64_t)blockIdx.x * B + b) * K + k;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (k + q < K) o[q] = acc[b][q];
+        for (int q = 0; q < 4; ++q) {
+          const float v = ((acc[b][q] + part[0][b][lane * 4 + q]) + part[1][b][lane * 4 + q]) + part[2][b][lane * 4 + q];
+          if (k + q < K) o[q] = v;
+        }
       }
     }
   }
-}
-
-__global__ __launch_bounds__(256) void linear_bwd_data_reduce_kernel(const float* ws, int64_t P, int64_t BK,
-                                                                     int accumulate, float* dxa) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= BK) return;
-  float s = 0.0f;
-  for (int64_t p = 0; p < P; ++p) s += ws[p * BK + i];
-  dxa[i] = accumulate ? dxa[i] + s : s;
 }
 
 // dw[n,k] = sum_b dy[b,n] act(x[b,k]) ; dbias[n] = sum_b dy[b,n]; one wave per row n
@@ -193,7 +209,7 @@ extern "C" int adp_linear_fwd(const float* x, const float* w, const float* bias,
 
 extern "C" int64_t adp_linear_bwd_data_ws_bytes(int64_t B, int64_t K, int64_t N) {
   if (B <= 0 || K <= 0 || N <= 0) return ADP_ERR_SHAPE;
-  return adp_cdiv(N, 256) * B * K * (int64_t)sizeof(float);
+  return adp_cdiv(N, LIN_NR) * B * K * (int64_t)sizeof(float);
 }
 
 extern "C" int adp_linear_bwd_data(const float* dy, int64_t dy_bstride, const float* w, int64_t B, int64_t K,
@@ -201,12 +217,12 @@ extern "C" int adp_linear_bwd_data(const float* dy, int64_t dy_bstride, const fl
   if (!dy || !w || !dxa || !ws) return ADP_ERR_NULL;
   if (B <= 0 || B > LIN_BMAX || K <= 0 || N <= 0) return ADP_ERR_SHAPE;
   if (dy_bstride == 0) dy_bstride = N;
-  const int64_t P = adp_cdiv(N, 256);
-  LIN_DISPATCH(B, ADP_LAUNCH((linear_bwd_data_kernel<BT>), dim3((unsigned)P), dim3(256), stream, dy, dy_bstride, w,
-                             B, K, N, ws));
-  ADP_LAUNCH(linear_bwd_data_reduce_kernel, dim3((unsigned)adp_cdiv(B * K, 256)), dim3(256), stream,
-             (const float*)ws, P, B * K, (int)accumulate, dxa);
-  return ADP_LAUNCH_OK();
+  const int64_t P = adp_cdiv(N, LIN_NR);
+  if (P > 2147483647 || adp_cdiv(K, 256) > 65535) return ADP_ERR_SHAPE;
+  LIN_DISPATCH(B, ADP_LAUNCH((linear_bwd_data_kernel<BT>), dim3((unsigned)P, (unsigned)adp_cdiv(K, 256)), dim3(256),
+                             stream, dy, dy_bstride, w, B, K, N, ws));
+  // second stage: the split-lane row reduction shared with the conv weight gradients (16 lanes per output)
+  return adp_wgrad_reduce(ws, P, B * K, 0, dxa, nullptr, (int)accumulate, stream);
 }
 
 extern "C" int adp_linear_bwd_weight(const float* dy, int64_t dy_bstride, const float* x, int64_t B, int64_t K,

@@ -295,19 +295,27 @@ __global__ __launch_bounds__(NT) void chan_ln_bwd_kernel(const float* x, const f
 struct LnCfg {
   int tl, nt;
 };
-LnCfg ln_cfg(int64_t C) {
+LnCfg ln_cfg(int64_t C, int64_t B, int64_t L) {
   if (C <= 64) return {64, 256};     // CG 4,  VPT 2 / 8 / 16
   if (C <= 128) return {32, 256};    // CG 8,  VPT 16
   if (C <= 256) return {32, 1024};   // CG 32, VPT 8
-  return {16, 1024};                 // CG 64, VPT 16 (C <= 1024)
+  // C <= 1024, 1024-thread workgroups: the deep layers have few positions (depth 8 at batch 4: 512), so the tile
+  // narrows until the grid covers the chip -- 16 positions (CG 64, VPT 16), 8 (CG 128, VPT 8) or 4 (CG 256, VPT 4)
+  if (B * adp_cdiv(L, 16) >= 192) return {16, 1024};
+  if (B * adp_cdiv(L, 8) >= 192) return {8, 1024};
+  return {4, 1024};
 }
 constexpr int64_t LN_CMAX = 1024;
 
 int launch_ln_fwd(const float* x, const float* ss, int64_t bstride, int64_t B, int64_t C, int64_t L, float eps, float* y,
                   float* stats, void* stream) {
-  const LnCfg k = ln_cfg(C);
+  const LnCfg k = ln_cfg(C, B, L);
   dim3 grid((unsigned)adp_cdiv(L, k.tl), (unsigned)B);
-  if (k.tl == 64 && C <= 8)
+  if (k.tl == 8)
+    ADP_LAUNCH((chan_ln_fwd_kernel<8, 1024, 8>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats);
+  else if (k.tl == 4)
+    ADP_LAUNCH((chan_ln_fwd_kernel<4, 1024, 4>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats);
+  else if (k.tl == 64 && C <= 8)
     ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 2>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats);
   else if (k.tl == 64 && C <= 32)
     ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 8>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats);
@@ -327,10 +335,16 @@ int launch_ln_fwd(const float* x, const float* ss, int64_t bstride, int64_t B, i
 int launch_ln_bwd(const float* x, const float* dy, const float* ss, int64_t bstride, const float* gamma,
                   const float* stats, const float* dres, int64_t B, int64_t C, int64_t L, float* dx, float* ws,
                   void* stream) {
-  const LnCfg k = ln_cfg(C);
+  const LnCfg k = ln_cfg(C, B, L);
   const int NTL = (int)adp_cdiv(L, k.tl);
   dim3 grid((unsigned)NTL, (unsigned)B);
-  if (k.tl == 64 && C <= 8)
+  if (k.tl == 8)
+    ADP_LAUNCH((chan_ln_bwd_kernel<8, 1024, 8>), grid, dim3(1024), stream, x, dy, ss, bstride, gamma, stats, dres,
+               (int)C, (int)L, NTL, dx, ws);
+  else if (k.tl == 4)
+    ADP_LAUNCH((chan_ln_bwd_kernel<4, 1024, 4>), grid, dim3(1024), stream, x, dy, ss, bstride, gamma, stats, dres,
+               (int)C, (int)L, NTL, dx, ws);
+  else if (k.tl == 64 && C <= 8)
     ADP_LAUNCH((chan_ln_bwd_kernel<64, 256, 2>), grid, dim3(256), stream, x, dy, ss, bstride, gamma, stats, dres,
                (int)C, (int)L, NTL, dx, ws);
   else if (k.tl == 64 && C <= 32)
@@ -471,7 +485,7 @@ extern "C" int adp_ln_stats(const float* x, int64_t B, int64_t C, int64_t L, flo
 
 extern "C" int64_t adp_chan_ln_bwd_ws_bytes(int64_t B, int64_t C, int64_t L) {
   if (B <= 0 || C <= 0 || L <= 0) return ADP_ERR_SHAPE;
-  return B * 2 * C * adp_cdiv(L, ln_cfg(C).tl) * (int64_t)sizeof(float);
+  return B * 2 * C * adp_cdiv(L, ln_cfg(C, B, L).tl) * (int64_t)sizeof(float);
 }
 
 extern "C" int adp_modulation_bwd(const float* x, const float* dy, const float* ss, int64_t ss_bstride,
@@ -480,7 +494,7 @@ extern "C" int adp_modulation_bwd(const float* x, const float* dy, const float* 
   if (!x || !dy || !ss || !stats || !dx || !dss || !ws) return ADP_ERR_NULL;
   if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
   if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
-  const int64_t NT = adp_cdiv(L, ln_cfg(C).tl);
+  const int64_t NT = adp_cdiv(L, ln_cfg(C, B, L).tl);
   launch_ln_bwd(x, dy, ss, ss_bstride, (const float*)nullptr, stats, (const float*)nullptr, B, C, L, dx, ws, stream);
   ADP_LAUNCH(reduce_rows_kernel, dim3((unsigned)adp_cdiv(B * 2 * C, 4)), dim3(256), stream, (const float*)ws, B,
              2 * C, NT, dss_bstride, 0, 0, dss);
@@ -493,7 +507,7 @@ extern "C" int adp_ln_bwd(const float* x, const float* dxn, const float* stats, 
   if (!x || !dxn || !stats || !gamma || !dx || !dgamma_dbeta || !ws) return ADP_ERR_NULL;
   if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
   if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
-  const int64_t NT = adp_cdiv(L, ln_cfg(C).tl);
+  const int64_t NT = adp_cdiv(L, ln_cfg(C, B, L).tl);
   launch_ln_bwd(x, dxn, (const float*)nullptr, (int64_t)0, gamma, stats, dres, B, C, L, dx, ws, stream);
   // dgamma_dbeta = [dgamma (C) | dbeta (C)]
   ADP_LAUNCH(reduce_rows_kernel, dim3((unsigned)adp_cdiv(2 * C, 4)), dim3(256), stream, (const float*)ws, B, 2 * C,

@@ -435,7 +435,8 @@ def test_gn_silu_bwd(dev, B, C, L, G):
 
 
 # ------------------------------------------------------------------ Modulation / LayerNorm over channels
-@pytest.mark.parametrize("B,C,L", [(2, 8, 300), (2, 32, 70), (1, 130, 64), (2, 100, 50), (2, 300, 40), (1, 1024, 24)])
+@pytest.mark.parametrize("B,C,L", [(2, 8, 300), (2, 32, 70), (1, 130, 64), (2, 100, 50), (2, 300, 40), (1, 1024, 24),
+                                   (4, 512, 1024), (4, 512, 300), (2, 1024, 128)])  # 16 / 8 / 4-position tiles
 def test_modulation_fwd_bwd(dev, B, C, L):
     x = (rnd(B, C, L, seed=1) * 1.5 + 0.4).requires_grad_()
     NT = 2 * C + 7
