@@ -42,6 +42,7 @@ class WgradDesc(Structure):
 SIGNATURES = {
     "adp_version": (c_int, []),
     "adp_launch_trace": (I, [I, ctypes.c_char_p, I]),
+    "adp_launch_times": (I, [P, I]),
     "adp_conv1d": (c_int, [POINTER(ConvDesc), P]),
     "adp_conv1d_tile": (I, [POINTER(ConvDesc)]),
     "adp_conv1d_wgrad_ws_bytes": (I, [POINTER(WgradDesc)]),
@@ -181,15 +182,29 @@ def call(name: str, *args):
         check(getattr(lib(), name)(*args), name)
         return
     l = lib()
-    l.adp_launch_trace(1, None, 0)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()  # torch's current stream == the stream passed to the kernel (see stream())
+    l.adp_launch_trace(1, None, 0)      # recording on: names + a HIP event pair per launch, on the launch stream
     check(getattr(l, name)(*args), name)
-    e1.record()
     buf = ctypes.create_string_buffer(4096)
     l.adp_launch_trace(0, buf, 4096)
-    PROFILE.append((name, _decode_trace(buf.value.decode()), _TAG or {}, e0, e1))
+    kernels = [k for k in _decode_trace(buf.value.decode()).split(" + ") if k]
+    PROFILE.append([name, kernels, _TAG or {}, None])   # the last slot receives the per-kernel times
     _TAG = None
+
+
+def profile_collect():
+    """Ends a profiled region: waits for the recorded events and returns [(call, kernel, meta, ms), ...] with one
+    entry per kernel launch (meta -- algorithmic flops / bytes / shape -- is attached to a call's first kernel)."""
+    global PROFILE
+    recs, PROFILE = PROFILE or [], None
+    n = sum(len(r[1]) for r in recs)
+    arr = (c_float * max(n, 1))()
+    got = lib().adp_launch_times(arr, n)
+    out, i = [], 0
+    for name, kernels, meta, _ in recs:
+        for j, k in enumerate(kernels):
+            out.append((name, k, meta if j == 0 else {}, arr[i] if i < got else float("nan")))
+            i += 1
+    return out
 
 
 def query(name: str, *args) -> int:

@@ -32,17 +32,19 @@ __device__ __forceinline__ float adp_rcp(float x) { return __builtin_amdgcn_rcpf
 
 #define ADP_LAUNCH(kern, grid, block, stream, ...)                                     \
   do {                                                                                 \
-    adp_rt_note_launch(#kern, __PRETTY_FUNCTION__);                                    \
+    adp_rt_note_launch(#kern, __PRETTY_FUNCTION__, (void*)(stream));                   \
     hipLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__);      \
+    adp_rt_launch_done((void*)(stream));                                               \
   } while (0)
 #define ADP_LAUNCH_OK() (hipGetLastError() == hipSuccess ? ADP_OK : ADP_ERR_LAUNCH)
 
 #endif
 
-// Launch trace (introspection only, see adp_launch_trace in adp.h): when tracing is on, every ADP_LAUNCH appends
-// "<kernel expression>@<launcher signature with its template arguments>" to a per-thread buffer.  Defined in
-// elementwise.hip.
-void adp_rt_note_launch(const char* kern, const char* site);
+// Launch trace (introspection only, see adp_launch_trace / adp_launch_times in adp.h): when tracing is on, every
+// ADP_LAUNCH appends "<kernel expression>@<launcher signature with its template arguments>" to a per-thread buffer
+// and brackets the launch with a pair of HIP events recorded on the launch stream.  Defined in elementwise.hip.
+void adp_rt_note_launch(const char* kern, const char* site, void* stream);
+void adp_rt_launch_done(void* stream);
 
 #include <stdint.h>
 

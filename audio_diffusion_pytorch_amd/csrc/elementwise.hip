@@ -4,6 +4,9 @@
 //   adp_v_step   : diffusion.py:185-187 one VSampler update, 2 reads 1 write
 //   adp_time_fourier_* : a_unet NumberEmbedder under TimeConditioningPlugin (components.py:74-76)
 #include "adp_rt.h"
+#ifndef ADP_EMULATE
+#include <mutex>
+#endif
 #include "adp.h"
 
 namespace {
@@ -165,14 +168,51 @@ namespace {
 thread_local bool g_trace_on = false;
 thread_local char g_trace[4096];
 thread_local size_t g_trace_len = 0;
+#ifndef ADP_EMULATE
+// The event list is process-wide (autograd runs the backward's launches on its own thread; the host code is
+// serialised by the interpreter lock, so launches are appended in launch order).
+constexpr int TRACE_EV_MAX = 8192;          // launches timed between two adp_launch_times calls
+hipEvent_t g_ev[2 * TRACE_EV_MAX];
+int g_ev_n = 0;                             // events recorded (two per launch)
+std::mutex g_ev_mu;
+#endif
 }  // namespace
 
-void adp_rt_note_launch(const char* kern, const char* site) {
+void adp_rt_note_launch(const char* kern, const char* site, void* stream) {
   if (!g_trace_on) return;
   const char* parts[4] = {g_trace_len ? "\n" : "", kern, "@", site};
   for (const char* p : parts)
     for (; *p && g_trace_len + 1 < sizeof(g_trace); ++p) g_trace[g_trace_len++] = *p;
   g_trace[g_trace_len] = 0;
+#ifndef ADP_EMULATE
+  std::lock_guard<std::mutex> lock(g_ev_mu);
+  if (g_ev_n + 2 <= 2 * TRACE_EV_MAX) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) == hipSuccess) {
+      (void)hipEventRecord(e, (hipStream_t)stream);   // on the stream the kernel is launched on
+      g_ev[g_ev_n++] = e;
+    }
+  }
+#else
+  (void)stream;
+#endif
+}
+
+void adp_rt_launch_done(void* stream) {
+#ifndef ADP_EMULATE
+  if (!g_trace_on) return;
+  std::lock_guard<std::mutex> lock(g_ev_mu);
+  if ((g_ev_n & 1) == 0) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) == hipSuccess) {
+    (void)hipEventRecord(e, (hipStream_t)stream);
+    g_ev[g_ev_n++] = e;
+  } else {  // keep the pairs aligned
+    (void)hipEventDestroy(g_ev[--g_ev_n]);
+  }
+#else
+  (void)stream;
+#endif
 }
 
 extern "C" int64_t adp_launch_trace(int64_t enable, char* buf, int64_t cap) {
@@ -185,6 +225,28 @@ extern "C" int64_t adp_launch_trace(int64_t enable, char* buf, int64_t cap) {
   g_trace[0] = 0;
   g_trace_on = enable != 0;
   return n;
+}
+
+extern "C" int64_t adp_launch_times(float* ms, int64_t cap) {
+#ifndef ADP_EMULATE
+  std::lock_guard<std::mutex> lock(g_ev_mu);
+  const int pairs = g_ev_n / 2;
+  int64_t n = 0;
+  for (int i = 0; i < pairs; ++i) {
+    float t = -1.0f;
+    if (hipEventSynchronize(g_ev[2 * i + 1]) == hipSuccess) (void)hipEventElapsedTime(&t, g_ev[2 * i], g_ev[2 * i + 1]);
+    if (ms && n < cap) ms[n++] = t;
+    (void)hipEventDestroy(g_ev[2 * i]);
+    (void)hipEventDestroy(g_ev[2 * i + 1]);
+  }
+  if (g_ev_n & 1) (void)hipEventDestroy(g_ev[g_ev_n - 1]);
+  g_ev_n = 0;
+  return n;
+#else
+  (void)ms;
+  (void)cap;
+  return 0;
+#endif
 }
 
 extern "C" int adp_v_noise(const float* x, const float* noise, const float* sigma, int64_t B, int64_t per,

@@ -386,11 +386,11 @@ int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, fl
 
 namespace {
 
-template <int BM, int KT, int S, int UP, int PRO>
+// PD: a 64x64 chunk is 2.6 us of MFMAs (one register stage), a 32x32 chunk 0.64 us (two)
+template <int BM, int KT, int S, int UP, int PRO, int PD = (BM == 64 ? 1 : 2)>
 int launch_wg(const adp_wgrad_desc& d, const WgPlan& p, void* stream) {
   dim3 grid((unsigned)p.nsplit, (unsigned)(d.M / BM), (unsigned)(d.R / BM));
   constexpr int NTH = ((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NLD) * 64;
-  constexpr int PD = BM == 64 ? 1 : 2;  // a 64x64 chunk is 2.6 us of MFMAs, a 32x32 chunk 0.64 us
   ADP_LAUNCH((wgrad_mm_kernel<BM, KT, S, UP, PRO, PD>), grid, dim3(NTH), stream, d, (int)p.cpb, (int)p.cps,
              (int)p.nsplit);
   if (p.nsplit > 1) {

@@ -72,9 +72,10 @@ def cpu_baseline(batch: int, threads: int = 16, budget_s: float = 25.0):
 
 
 def roofline_leg(model, x, top: int = 14):
-    """One instrumented eager step: every C-ABI call is bracketed by HIP events on the stream it launches on
-    (`_C.call`), labelled with the kernel instantiation it dispatched (the spelling rocprofv3 prints) and with its
-    ALGORITHMIC flops / bytes.  Reports
+    """One instrumented eager step: while recording is on, libadp_hip.so brackets EVERY kernel launch with a pair of
+    HIP events recorded on the stream the kernel is launched on (`adp_launch_trace` / `adp_launch_times`) and names
+    the kernel instantiation (the spelling rocprofv3 prints); the host layer attaches the ALGORITHMIC flops / bytes of
+    the call.  Reports
       roofline                 the single kernel with the largest total time, against the bound that limits it
                                (f32 MFMA peak for the implicit-GEMM convs, HBM for everything else);
       roofline_hbm_convblock   the depth-0/1 ConvBlock convs (north_star's HBM target) against the HBM peak;
@@ -88,14 +89,13 @@ def roofline_leg(model, x, top: int = 14):
     try:
         loss = model(x)
         loss.backward()
-        torch.cuda.synchronize()
     finally:
-        recs, _C.PROFILE = _C.PROFILE, None
+        recs = _C.profile_collect()   # waits for the events
     agg = {}
-    for call, kern, meta, e0, e1 in recs:
-        a = agg.setdefault(kern or call, {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0})
+    for call, kern, meta, ms in recs:
+        a = agg.setdefault(kern, {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0})
         a["launches"] += 1
-        a["ms"] += e0.elapsed_time(e1)
+        a["ms"] += ms
         a["flops"] += meta.get("flops", 0)
         a["bytes"] += meta.get("bytes", 0)
     pmc = {}
@@ -115,19 +115,18 @@ def roofline_leg(model, x, top: int = 14):
              "achieved": round(tf, 2) if mfma else round(gb, 1), "peak": PEAK_F32_MFMA_TFLOPS if mfma else PEAK_HBM_GBPS,
              "unit": "TFLOP/s" if mfma else "GB/s"}
         e["frac"] = round(e["achieved"] / e["peak"], 4)
-        t = pmc.get(name)
+        t = pmc.get(name.split(" | ")[0])
         e["traffic"] = t.get("hbm_bytes_per_launch") if t else None
-        if e["traffic"] is not None:
-            e["algorithmic_bytes_per_launch"] = a["bytes"] // a["launches"]
+        e["algorithmic_bytes_per_launch"] = a["bytes"] // a["launches"]
         return e
 
     detail_path = os.environ.get("ADP_BENCH_DETAIL")
     if detail_path:  # per (kernel, shape) table for kernel work; not part of the bench line
         det = {}
-        for call, kern, meta, e0, e1 in recs:
-            a = det.setdefault((kern or call) + " :: " + meta.get("shape", ""), [0, 0.0, 0, 0])
+        for call, kern, meta, ms in recs:
+            a = det.setdefault(kern + " :: " + meta.get("shape", ""), [0, 0.0, 0, 0])
             a[0] += 1
-            a[1] += e0.elapsed_time(e1)
+            a[1] += ms
             a[2] += meta.get("flops", 0)
             a[3] += meta.get("bytes", 0)
         with open(detail_path, "w") as f:
@@ -135,22 +134,24 @@ def roofline_leg(model, x, top: int = 14):
                 f.write(f"{ms:8.3f} ms  n={n:3d}  avg {ms / n * 1e3:7.1f} us  {fl / ms / 1e9:6.1f} TF  {by / ms / 1e6:7.1f} GB/s  {k}\n")
     total_ms = sum(a["ms"] for a in agg.values())
     order = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
-    single = [(k, a) for k, a in order if " + " not in k and (a["flops"] or a["bytes"])]
-    rf = entry(*single[0])
-    rf["share_of_step"] = round(single[0][1]["ms"] / total_ms, 4)
+    rated = [(k, a) for k, a in order if (a["flops"] or a["bytes"])]
+    rf = entry(*rated[0])
+    rf["share_of_step"] = round(rated[0][1]["ms"] / total_ms, 4)
     # north_star's HBM target: the ConvBlock convs of depths 0-1 (GN+SiLU prologue, k=3, C = 8 / 32)
     hb = {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0}
-    names = set()
-    for call, kern, meta, e0, e1 in recs:
+    names = []
+    for call, kern, meta, ms in recs:
         sh = meta.get("shape", "")
         if call == "adp_conv1d" and " pro1" in sh and " tr0" in sh and (" R8 " in sh or " R32 " in sh):
             hb["launches"] += 1
-            hb["ms"] += e0.elapsed_time(e1)
+            hb["ms"] += ms
             hb["bytes"] += meta["bytes"]
-            names.add(kern)
+            if kern not in names:
+                names.append(kern)
     hbm = None
     if hb["launches"]:
         hbm = entry(" | ".join(sorted(names)), hb)
+        hbm["traffic"] = None
         hbm["what"] = "forward ConvBlock convs (GroupNorm+SiLU prologue, k=3) of depths 0-1: A_in + A_out (+A_res) bytes"
     table = {}
     for k, a in order[:top]:
@@ -262,7 +263,7 @@ def main():
             if hbm:
                 line["roofline_hbm_convblock"] = hbm
             line["kernels"] = extra
-            line["instrumented_eager_step_ms"] = eager_ms
+            line["instrumented_kernel_ms_per_step"] = eager_ms
         except Exception as e:
             line["roofline"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -37,6 +37,10 @@ int adp_version(void);
  * it, and switches recording on (enable != 0) or off.  Returns the number of bytes written.  bench.py uses it to
  * label each timed launch with the kernel instantiation name rocprofv3 reports. */
 int64_t adp_launch_trace(int64_t enable, char* buf, int64_t cap);
+/* While recording is on, every kernel launch is bracketed by two HIP events recorded on the stream it is launched
+ * on.  adp_launch_times waits for them, writes the elapsed milliseconds of each launch since the previous call
+ * (launch order, the order adp_launch_trace lists the kernels) into ms[0..cap) and returns how many it wrote. */
+int64_t adp_launch_times(float* ms, int64_t cap);
 
 /* ------------------------------------------------------------------------------------------
  * Fused implicit-GEMM Conv1d on the f32 matrix cores (v_mfma_f32_32x32x2_f32).

@@ -289,7 +289,7 @@ static inline float __fdividef(float a, float b) { return a / b; }
 #define ADP_LAUNCH(kern, grid, block, stream, ...) \
   do {                                             \
     (void)(stream);                                \
-    adp_rt_note_launch(#kern, __PRETTY_FUNCTION__); \
+    adp_rt_note_launch(#kern, __PRETTY_FUNCTION__, nullptr); \
     adp_emul::launch(grid, block, [=]() { kern(__VA_ARGS__); }); \
   } while (0)
 #define ADP_LAUNCH_OK() 0
