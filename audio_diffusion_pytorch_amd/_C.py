@@ -49,6 +49,7 @@ SIGNATURES = {
     "adp_conv1d_wgrad": (c_int, [POINTER(WgradDesc), P]),
     "adp_gn_stats_ws_bytes": (I, [I, I, I, I]),
     "adp_gn_stats": (c_int, [P, I, I, I, I, F, P, P, P]),
+    "adp_gn_stats_act": (c_int, [P, I, I, I, I, F, P, P, P, P, P, P]),
     "adp_row_nsplit": (I, [I, I]),
     "adp_gn_silu_bwd_reduce": (c_int, [P, P, P, P, P, I, I, I, I, I, P, P]),
     "adp_gn_silu_bwd_apply": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, I, P]),

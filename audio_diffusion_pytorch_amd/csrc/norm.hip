@@ -67,6 +67,60 @@ __global__ __launch_bounds__(64) void gn_final_kernel(const float* ws, int64_t N
   }
 }
 
+// Second stage of the statistics fused with the activation: a = SiLU(GroupNorm(x)) materialised.  Used by the WIDE
+// layers only (C >= 512): there an activation is staged by 8-16 workgroups of the implicit-GEMM conv / weight-gradient
+// kernels, so recomputing exp + rcp in every one of their loaders costs more MFMA issue time (measured: 0.7 us of a
+// 4.5 us weight-gradient chunk at depth 7) than writing the 2-8 MB tensor once.  One workgroup = 1024 elements of one
+// (b, c) row; every workgroup re-derives its group's (mean, rstd) from the partials (a handful at these sizes) and
+// the first workgroup of each group also publishes them for the backward pass.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, const float* ws, const float* gamma,
+                                                       const float* beta, int64_t C, int64_t L, int64_t G,
+                                                       int64_t nchunks, float eps, float* stats, float* a) {
+  const int64_t row = blockIdx.y, b = row / C, c = row % C, Cg = C / G, g = c / Cg, bg = b * G + g;
+  const int64_t NG = Cg * L;
+  // Chan's combination of the group's partials, in gn_final_kernel's order of operations (wave 0's lanes; every
+  // thread then reads the result from LDS)
+  __shared__ float st[2];
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    float s = 0.0f;
+    for (int64_t k = lane; k < nchunks; k += 64) {
+      const int64_t n = (NG - k * GN_CHUNK) < GN_CHUNK ? (NG - k * GN_CHUNK) : GN_CHUNK;
+      s += ws[(bg * nchunks + k) * 2] * (float)n;
+    }
+    const float mean = adp_wave_sum(s) / (float)NG;
+    float q = 0.0f;
+    for (int64_t k = lane; k < nchunks; k += 64) {
+      const int64_t n = (NG - k * GN_CHUNK) < GN_CHUNK ? (NG - k * GN_CHUNK) : GN_CHUNK;
+      const float dm = ws[(bg * nchunks + k) * 2] - mean;
+      q += ws[(bg * nchunks + k) * 2 + 1] + (float)n * dm * dm;
+    }
+    q = adp_wave_sum(q);
+    if (lane == 0) {
+      const float rstd = 1.0f / sqrtf(q / (float)NG + eps);
+      st[0] = mean;
+      st[1] = rstd;
+      if (c == g * Cg && blockIdx.x == 0) {
+        stats[bg * 2] = mean;
+        stats[bg * 2 + 1] = rstd;
+      }
+    }
+  }
+  __syncthreads();
+  const float pa = gamma[c] * st[1], pb = beta[c] - st[0] * pa;
+  const int64_t l0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const float* xr = x + row * L;
+  float* ar = a + row * L;
+  if (l0 + 3 < L && (L & 3) == 0) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(xr + l0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = adp_silu_fast(fmaf(v[j], pa, pb));
+    *reinterpret_cast<f32x4*>(ar + l0) = v;
+  } else {
+    for (int64_t l = l0; l < L && l < l0 + 4; ++l) ar[l] = adp_silu_fast(fmaf(xr[l], pa, pb));
+  }
+}
+
 // ---- backward of y = SiLU(GN(x)) ------------------------------------------------------------------------
 // ab[b, c, split, {A,B}] : A = sum ds*xhat, B = sum ds over the split's slice of L, ds = dact * silu'(h)
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* x, const float* dact, const float* stats,
@@ -431,6 +485,19 @@ extern "C" int adp_gn_stats(const float* x, int64_t B, int64_t C, int64_t L, int
   if (B * G > 65535) return ADP_ERR_SHAPE;
   ADP_LAUNCH(gn_partial_kernel, dim3((unsigned)nchunks, (unsigned)(B * G)), dim3(256), stream, x, NG, nchunks, ws);
   ADP_LAUNCH(gn_final_kernel, dim3((unsigned)(B * G)), dim3(64), stream, (const float*)ws, NG, nchunks, eps, stats);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_gn_stats_act(const float* x, int64_t B, int64_t C, int64_t L, int64_t G, float eps,
+                                const float* gamma, const float* beta, float* stats, float* act, float* ws,
+                                void* stream) {
+  if (!x || !gamma || !beta || !stats || !act || !ws) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || L <= 0 || G <= 0 || C % G) return ADP_ERR_SHAPE;
+  const int64_t NG = (C / G) * L, nchunks = adp_cdiv(NG, GN_CHUNK);
+  if (B * G > 65535 || B * C > 65535) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(gn_partial_kernel, dim3((unsigned)nchunks, (unsigned)(B * G)), dim3(256), stream, x, NG, nchunks, ws);
+  ADP_LAUNCH(gn_apply_kernel, dim3((unsigned)adp_cdiv(L, 1024), (unsigned)(B * C)), dim3(256), stream, x,
+             (const float*)ws, gamma, beta, C, L, G, nchunks, eps, stats, act);
   return ADP_LAUNCH_OK();
 }
 

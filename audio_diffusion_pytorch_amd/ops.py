@@ -94,6 +94,18 @@ def gn_stats(x: Tensor, groups: int, eps: float = GN_EPS, out: Optional[Tensor] 
     return stats
 
 
+def gn_stats_act(x: Tensor, groups: int, gamma: Tensor, beta: Tensor, eps: float = GN_EPS):
+    """(stats [B, G, 2], act = SiLU(GroupNorm(x)) materialised) in two launches (adp_gn_stats_act)."""
+    B, C, L = x.shape
+    stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+    act = torch.empty_like(x)
+    ws = _ws(_C.query("adp_gn_stats_ws_bytes", B, C, L, groups), x)
+    _C.tag(bytes=12 * x.numel(), shape=f"B{B} C{C} L{L}")
+    _C.call("adp_gn_stats_act", ptr(x), B, C, L, groups, eps, ptr(gamma), ptr(beta), ptr(stats), ptr(act), ptr(ws),
+            _C.stream())
+    return stats, act
+
+
 def gn_silu_bwd(x: Tensor, dact: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor, groups: int,
                 dres: Optional[Tensor] = None, dx: Optional[Tensor] = None, dgamma: Optional[Tensor] = None,
                 dbeta: Optional[Tensor] = None, accumulate: bool = False):

@@ -22,6 +22,8 @@ MI355X-first structure (not a module-per-op translation):
 """
 from typing import Dict, List, Optional, Sequence
 
+import os
+
 import torch
 import torch.nn as nn
 from torch import Tensor
@@ -249,6 +251,10 @@ class UNetV0Net(nn.Module):
                              *params)
 
 
+# channel count from which SiLU(GroupNorm(x)) is materialised instead of recomputed in the conv loaders
+ACT_MATERIALIZE_MIN_C = int(os.environ.get("ADP_ACT_MATERIALIZE_MIN_C", "512"))
+
+
 class _Run:
     """One forward execution: issues kernels, and (when grad is needed) records the tape."""
 
@@ -321,6 +327,8 @@ class _Run:
     # -- items ----------------------------------------------------------------------------
     def resnet(self, p, x: Tensor) -> Tensor:
         G = self.net.groups
+        if x.shape[1] >= ACT_MATERIALIZE_MIN_C:
+            return self.resnet_wide(p, x)
         st1 = ops.gn_stats(x, G)
         h1 = ops.conv1d(x, p.conv1.weight, p.conv1.bias, pad=1, prologue=1, pro_stats=st1, pro_gamma=p.gn1.weight,
                         pro_beta=p.gn1.bias, groups=G)
@@ -336,6 +344,29 @@ class _Run:
                                             dbeta=self.g(p.gn2.bias))
                 ops.conv1d_wgrad(x, dh1, 3, pad=1, prologue=1, pro_stats=st1, pro_gamma=p.gn1.weight,
                                  pro_beta=p.gn1.bias, groups=G, dw=self.g(p.conv1.weight), dbias=self.g(p.conv1.bias))
+                dact1 = ops.conv1d(dh1, p.conv1.weight, None, pad=1, transposed=True)
+                dx, _, _ = ops.gn_silu_bwd(x, dact1, st1, p.gn1.weight, p.gn1.bias, G, dres=gy,
+                                           dgamma=self.g(p.gn1.weight), dbeta=self.g(p.gn1.bias))
+                return dx
+            self.tape.append((bwd, None))
+        return y
+
+    def resnet_wide(self, p, x: Tensor) -> Tensor:
+        """ResnetBlock of the wide layers (C >= 512): same arithmetic, but SiLU(GroupNorm(.)) is materialised once by
+        the statistics' second stage instead of being recomputed by each of the 8-16 conv / weight-gradient
+        workgroups that stage a tile of it (the tensors are 2-8 MB here; see gn_apply_kernel in csrc/norm.hip)."""
+        G = self.net.groups
+        st1, a1 = ops.gn_stats_act(x, G, p.gn1.weight, p.gn1.bias)
+        h1 = ops.conv1d(a1, p.conv1.weight, p.conv1.bias, pad=1)
+        st2, a2 = ops.gn_stats_act(h1, G, p.gn2.weight, p.gn2.bias)
+        y = ops.conv1d(a2, p.conv2.weight, p.conv2.bias, pad=1, res=x)
+        if self.need_grad:
+            def bwd(gy):
+                ops.conv1d_wgrad(a2, gy, 3, pad=1, dw=self.g(p.conv2.weight), dbias=self.g(p.conv2.bias))
+                dact2 = ops.conv1d(gy, p.conv2.weight, None, pad=1, transposed=True)
+                dh1, _, _ = ops.gn_silu_bwd(h1, dact2, st2, p.gn2.weight, p.gn2.bias, G, dgamma=self.g(p.gn2.weight),
+                                            dbeta=self.g(p.gn2.bias))
+                ops.conv1d_wgrad(a1, dh1, 3, pad=1, dw=self.g(p.conv1.weight), dbias=self.g(p.conv1.bias))
                 dact1 = ops.conv1d(dh1, p.conv1.weight, None, pad=1, transposed=True)
                 dx, _, _ = ops.gn_silu_bwd(x, dact1, st1, p.gn1.weight, p.gn1.bias, G, dres=gy,
                                            dgamma=self.g(p.gn1.weight), dbeta=self.g(p.gn1.bias))

@@ -118,6 +118,13 @@ int64_t adp_gn_stats_ws_bytes(int64_t B, int64_t C, int64_t L, int64_t G);
 int adp_gn_stats(const float* x, int64_t B, int64_t C, int64_t L, int64_t G, float eps, float* stats, float* ws,
                  void* stream);
 
+/* Statistics + materialised activation in the same two launches: stats as adp_gn_stats, and
+ * act[b,c,l] = SiLU((x - mean) * rstd * gamma[c] + beta[c]).  For the wide layers (C >= 512), where 8-16 workgroups of
+ * the conv kernels would each recompute the activation of the tile they stage; the narrow layers keep the activation
+ * fused into the conv loaders (adp_conv_desc.prologue = 1).  ws: adp_gn_stats_ws_bytes. */
+int adp_gn_stats_act(const float* x, int64_t B, int64_t C, int64_t L, int64_t G, float eps, const float* gamma,
+                     const float* beta, float* stats, float* act, float* ws, void* stream);
+
 /* Split count used by the row-wise two-stage reductions below (rows = B*C rows of length L). */
 int64_t adp_row_nsplit(int64_t rows, int64_t L);
 

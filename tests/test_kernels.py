@@ -569,3 +569,14 @@ def test_attention_fwd_bwd(dev, B, H, D, n, m):
     dq, dkv = ops.attn_bwd(q.detach().to(dev), kv.detach().to(dev), o, do.to(dev), lse, H, D)
     assert rel_err(dq, dq_ref) < TOL
     assert rel_err(dkv, dkv_ref) < TOL
+
+
+@pytest.mark.parametrize("B,C,L,G", [(2, 16, 300, 8), (1, 64, 1030, 8), (2, 512, 24, 8)])
+def test_gn_stats_act(dev, B, C, L, G):
+    """adp_gn_stats_act: statistics + materialised SiLU(GroupNorm(x)) (the wide-layer path)."""
+    x = rnd(B, C, L, seed=1) * 1.7 + 0.3
+    gamma, beta = rnd(C, seed=2) * 0.5 + 1, rnd(C, seed=3) * 0.1
+    stats, act = ops.gn_stats_act(x.to(dev), G, gamma.to(dev), beta.to(dev))
+    assert rel_err(act, ref_gn_silu(x, G, gamma, beta)) < TOL
+    ref_stats = ops.gn_stats(x.to(dev), G)
+    assert rel_err(stats, ref_stats) < 1e-6
