@@ -38,6 +38,18 @@ __device__ __forceinline__ float adp_rcp(float x) { return __builtin_amdgcn_rcpf
   } while (0)
 #define ADP_LAUNCH_OK() (hipGetLastError() == hipSuccess ? ADP_OK : ADP_ERR_LAUNCH)
 
+// Workgroup barrier for a wave that only CONSUMES LDS data after it and has global stores in flight.
+// __syncthreads() carries a workgroup-scope release fence, which on gfx9-family hardware waits (vmcnt) for every
+// outstanding global STORE of the wave to be acknowledged by L2 -- microseconds of HBM write latency per loop
+// iteration in a streaming kernel whose epilogue stores precede the next tile's barrier (measured in
+// conv_stream.hip: 10 of 26 us).  The waves that PRODUCE the LDS data use __syncthreads() (their ds_writes are
+// complete before they arrive); this variant is the bare s_barrier plus a compiler-level ordering point.
+__device__ __forceinline__ void adp_barrier_consume() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 #endif
 
 // Launch trace (introspection only, see adp_launch_trace / adp_launch_times in adp.h): when tracing is on, every

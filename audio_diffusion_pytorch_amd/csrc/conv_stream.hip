@@ -119,6 +119,19 @@ __global__ __launch_bounds__(512) void conv_stream32_kernel(adp_conv_desc d, int
   for (int r = 0; r < 16; ++r) bias[r] = d.bias ? d.bias[(r & 3) + 8 * (r >> 2) + 4 * hi] : 0.0f;
   const int xfrag = 4 * hi * ST_XS + 64 * wave + l31 + 4 - 1;  // + ni*32 + (8g + c) * XS + t
   const bool has_res = d.res != nullptr;
+#ifndef ADP_EMULATE
+  // Make the weight / bias loads complete HERE.  Otherwise the first MFMA of the loop body is the first use of
+  // registers that are pending on the loop-entry path only, and the compiler covers it with s_waitcnt vmcnt(0) on
+  // EVERY iteration -- which also waits for the residual loads just issued and the previous tile's stores, i.e.
+  // serialises HBM latency with the matrix cores.
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    asm volatile("" ::"v"(av[g][0]), "v"(av[g][1]), "v"(av[g][2]), "v"(av[g][3]), "v"(av[g][4]), "v"(av[g][5]),
+                 "v"(av[g][6]), "v"(av[g][7]), "v"(av[g][8]), "v"(av[g][9]), "v"(av[g][10]), "v"(av[g][11]));
+  asm volatile("" ::"v"(bias[0]), "v"(bias[1]), "v"(bias[2]), "v"(bias[3]), "v"(bias[4]), "v"(bias[5]), "v"(bias[6]),
+               "v"(bias[7]), "v"(bias[8]), "v"(bias[9]), "v"(bias[10]), "v"(bias[11]), "v"(bias[12]), "v"(bias[13]),
+               "v"(bias[14]), "v"(bias[15]));
+#endif
 
   for (int it = 0; it < niter; ++it) {
     const int t = t_beg + it;
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(512) void conv_stream32_kernel(adp_conv_desc d, int
           rv[ni][r] = d.res[obase + (int64_t)m * L + 32 * ni];
         }
     }
-    __syncthreads();  // B_it: tile it is in LDS[it & 1]
+    adp_barrier_consume();  // B_it: tile it is in LDS[it & 1] (no wait for the previous tile's stores: adp_rt.h)
     const float* Xb = smem + (it & 1) * (ST_C * ST_XS);
     f32x16 acc0, acc1;
 #pragma unroll

@@ -286,6 +286,8 @@ static inline float adp_rcp(float x) { return 1.0f / x; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
 
+static inline void adp_barrier_consume() { adp_emul::sync_block(); }
+
 #define ADP_LAUNCH(kern, grid, block, stream, ...) \
   do {                                             \
     (void)(stream);                                \

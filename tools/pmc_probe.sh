@@ -20,7 +20,7 @@ import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
-    if "conv_mm" in k or "wgrad_mm" in k:
+    if "conv_mm" in k or "wgrad_mm" in k or "conv_stream" in k:
         acc[k[:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print(k)
