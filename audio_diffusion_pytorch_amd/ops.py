@@ -174,6 +174,9 @@ def ln_bwd(x: Tensor, dxn: Tensor, stats: Tensor, gamma: Tensor, dres: Optional[
     return dx, dgb
 
 
+LIN_ROWS = 16  # activation rows one adp_linear_* launch holds in LDS (LIN_BMAX in csrc/linear.hip)
+
+
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], act: int = 0, post: int = 0,
                y: Optional[Tensor] = None) -> Tensor:
     B, K = x.shape
@@ -181,7 +184,10 @@ def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], act: int = 0, post:
     if y is None:
         y = torch.empty((B, N), dtype=torch.float32, device=x.device)
     _C.tag(bytes=4 * (w.numel() + x.numel() + y.numel()), shape=f"B{B} K{K} N{N}")
-    _C.call("adp_linear_fwd", ptr(x), ptr(w), ptr(bias), B, K, N, act, post, ptr(y), N, _C.stream())
+    for b0 in range(0, B, LIN_ROWS):  # batches beyond 16 rows: the weight matrix is streamed once per 16 rows
+        nb = min(LIN_ROWS, B - b0)
+        _C.call("adp_linear_fwd", ptr(x[b0:b0 + nb]), ptr(w), ptr(bias), nb, K, N, act, post, ptr(y[b0:b0 + nb]), N,
+                _C.stream())
     return y
 
 
@@ -190,9 +196,12 @@ def linear_bwd_data(dy: Tensor, w: Tensor, dxa: Optional[Tensor] = None, accumul
     K = w.shape[1]
     if dxa is None:
         dxa = torch.empty((B, K), dtype=torch.float32, device=dy.device)
-    ws = _ws(_C.query("adp_linear_bwd_data_ws_bytes", B, K, N), dy)
+    ws = _ws(_C.query("adp_linear_bwd_data_ws_bytes", min(B, LIN_ROWS), K, N), dy)
     _C.tag(bytes=4 * (w.numel() + B * N + dxa.numel()), shape=f"B{B} K{K} N{N}")
-    _C.call("adp_linear_bwd_data", ptr(dy), N, ptr(w), B, K, N, int(accumulate), ptr(dxa), ptr(ws), _C.stream())
+    for b0 in range(0, B, LIN_ROWS):
+        nb = min(LIN_ROWS, B - b0)
+        _C.call("adp_linear_bwd_data", ptr(dy[b0:b0 + nb]), N, ptr(w), nb, K, N, int(accumulate),
+                ptr(dxa[b0:b0 + nb]), ptr(ws), _C.stream())
     return dxa
 
 
@@ -204,6 +213,7 @@ def linear_bwd_weight(dy: Tensor, x: Tensor, act: int = 0, dw: Optional[Tensor] 
     if rows is None:
         B, N = dy.shape
         dy_bstride = N
+        dy = dy.reshape(-1)
     else:
         B, N = x.shape[0], rows
     K = x.shape[1]
@@ -212,8 +222,10 @@ def linear_bwd_weight(dy: Tensor, x: Tensor, act: int = 0, dw: Optional[Tensor] 
     if dbias is None and want_bias:
         dbias = torch.empty((N,), dtype=torch.float32, device=dy.device)
     _C.tag(bytes=4 * (dw.numel() + B * N + x.numel()), shape=f"B{B} K{K} N{N}")
-    _C.call("adp_linear_bwd_weight", ptr(dy), dy_bstride, ptr(x), B, K, N, act, int(accumulate), ptr(dw), ptr(dbias),
-            _C.stream())
+    for b0 in range(0, B, LIN_ROWS):  # the second and later groups of 16 rows accumulate into dw / dbias
+        nb = min(LIN_ROWS, B - b0)
+        _C.call("adp_linear_bwd_weight", ptr(dy[b0 * dy_bstride:]), dy_bstride, ptr(x[b0:b0 + nb]), nb, K, N, act,
+                int(accumulate or b0 > 0), ptr(dw), ptr(dbias), _C.stream())
     return dw, dbias
 
 

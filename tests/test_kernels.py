@@ -487,7 +487,7 @@ def test_skipmod_bwd(dev):
 
 
 # ------------------------------------------------------------------ conditioning path (small-batch Linear)
-@pytest.mark.parametrize("B,K,N,act,post", [(1, 257, 64, 0, 2), (4, 1024, 37, 1, 0), (8, 1500, 20, 2, 0),
+@pytest.mark.parametrize("B,K,N,act,post", [(1, 257, 64, 0, 2), (4, 1024, 37, 1, 0), (8, 1500, 20, 2, 0), (37, 96, 50, 1, 0),
                                             (16, 64, 9, 1, 2)])
 def test_linear_fwd_bwd(dev, B, K, N, act, post):
     x = rnd(B, K, seed=1).requires_grad_()

@@ -57,12 +57,12 @@ def compare_grads(net, oracle, tol=TOL):
     assert worst[1] < tol, worst
 
 
-@pytest.mark.parametrize("B,L", [(2, 256)])
+@pytest.mark.parametrize("B,L", [(2, 256), (18, 64)])  # 18 > the 16 rows one conditioning-Linear launch holds
 def test_unet_forward_backward_tiny(dev, B, L):
     oracle, net = build_pair(TINY, dev)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, 2, L, generator=g)
-    t = torch.tensor([0.3, 0.8])[:B]
+    t = torch.linspace(0.3, 0.8, B)
     feats = 0.1 * torch.randn(B, TINY["modulation_features"], generator=g)
     y_ref = oracle(x, t, features=feats)
     y = net(x.to(dev), t.to(dev), features=feats.to(dev))
