@@ -2,12 +2,13 @@
 #pragma once
 #include "adp.h"
 
-// conv_mm.hip: pipelined split-K-in-block implicit GEMM (stride 1, kernel 1/3, channels % 32 == 0)
+// conv_mm.hip (+ conv_mm_impl.h, conv_mm_m64/m32.hip): wave-specialised implicit-GEMM conv (stride 1 kernel 1/3,
+// kernel = stride 2/4, nearest-upsample loader; channels % 32 == 0)
 bool adp_conv_mm_eligible(const adp_conv_desc& d);
 int adp_conv_mm(const adp_conv_desc& d, void* stream);
 int64_t adp_conv_mm_tile(const adp_conv_desc& d);  // NKG * 1000000 + BM * 1000 + BN
 
-// wgrad_mm.hip: pipelined weight gradient of the stride-1 'same' convolutions (kernel 3 / 1, channels % 32 == 0)
+// wgrad_mm.hip: wave-specialised weight gradient of the same convolutions (channels % 32 == 0)
 bool adp_wgrad_mm_eligible(const adp_wgrad_desc& d);
 int64_t adp_wgrad_mm_ws_floats(const adp_wgrad_desc& d);
 int adp_wgrad_mm(const adp_wgrad_desc& d, void* stream);
