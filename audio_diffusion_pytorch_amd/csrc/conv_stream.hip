@@ -37,6 +37,7 @@ __global__ __launch_bounds__(512) void conv_stream32_kernel(adp_conv_desc d, int
   const int t_beg = (int)(((int64_t)blockIdx.x * total_tiles) / gridDim.x);
   const int t_end = (int)(((int64_t)(blockIdx.x + 1) * total_tiles) / gridDim.x);
   const int niter = t_end - t_beg;
+  const int nrounds = (niter + 1) & ~1;  // the loaders run two tiles per loop trip; a ghost iteration pads odd counts
 
   if (wave >= 4) {
     // =========================== loader waves ===========================
@@ -57,10 +58,12 @@ __global__ __launch_bounds__(512) void conv_stream32_kernel(adp_conv_desc d, int
         x_be[i] = d.pro_beta ? d.pro_beta[row] : 0.0f;
       }
     }
-    f32x4 rx[ST_NX4];
-    float rm[ST_NX4], rr[ST_NX4];
-    bool ok[ST_NX4];
-    auto load_tile = [&](int it) {
+    // two register stages: tile it+2 is requested while tile it+1 is being staged, so a tile's loads have a full
+    // MFMA phase + a staging phase (~4 us) to arrive instead of one phase
+    f32x4 rxs[2][ST_NX4];
+    float rms[2][ST_NX4], rrs[2][ST_NX4];
+    bool oks[2][ST_NX4];
+    auto load_tile = [&](f32x4 (&rx)[ST_NX4], float (&rm)[ST_NX4], float (&rr)[ST_NX4], bool (&ok)[ST_NX4], int it) {
       const int t = t_beg + (it < niter ? it : niter - 1);
       const int b = t / tiles_per_b, n0 = (t - b * tiles_per_b) * ST_TN;
       const float* xb = d.x + (int64_t)b * ST_C * L;
@@ -75,7 +78,8 @@ __global__ __launch_bounds__(512) void conv_stream32_kernel(adp_conv_desc d, int
         }
       }
     };
-    auto store_tile = [&](int it) {
+    auto store_tile = [&](const f32x4 (&rx)[ST_NX4], const float (&rm)[ST_NX4], const float (&rr)[ST_NX4],
+                          const bool (&ok)[ST_NX4], int it) {
       float* Xb = smem + (it & 1) * (ST_C * ST_XS);
 #pragma unroll
       for (int i = 0; i < ST_NX4; ++i) {
@@ -92,11 +96,15 @@ __global__ __launch_bounds__(512) void conv_stream32_kernel(adp_conv_desc d, int
     };
     // the store of tile it goes to LDS[it & 1], last read by the MFMAs of tile it-2; every MMA wave finished those
     // before it arrived at barrier B_{it-1}, which this wave passed before starting iteration it
-    load_tile(0);
-    for (int it = 0; it < niter; ++it) {
-      store_tile(it);
-      load_tile(it + 1);  // unconditional: the tail re-reads the last tile (never consumed)
-      __syncthreads();    // B_it
+    load_tile(rxs[0], rms[0], rrs[0], oks[0], 0);
+    load_tile(rxs[1], rms[1], rrs[1], oks[1], 1);
+    for (int it0 = 0; it0 < nrounds; it0 += 2) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        store_tile(rxs[s], rms[s], rrs[s], oks[s], it0 + s);  // ghost tile (odd niter): restages the last one
+        load_tile(rxs[s], rms[s], rrs[s], oks[s], it0 + s + 2);  // unconditional, clamped: never consumed
+        __syncthreads();                                         // B_it
+      }
     }
     return;
   }
@@ -133,7 +141,11 @@ __global__ __launch_bounds__(512) void conv_stream32_kernel(adp_conv_desc d, int
                "v"(bias[14]), "v"(bias[15]));
 #endif
 
-  for (int it = 0; it < niter; ++it) {
+  for (int it = 0; it < nrounds; ++it) {
+    if (it >= niter) {  // ghost iteration: only the barrier
+      adp_barrier_consume();
+      break;
+    }
     const int t = t_beg + it;
     const int b = t / tiles_per_b, n0 = (t - b * tiles_per_b) * ST_TN;
     const int64_t obase = (int64_t)b * ST_C * L + n0 + 64 * wave + l31;
