@@ -260,3 +260,39 @@ def test_diffusion_autoencoder(dev):
     z = enc_ref(x).detach()
     out = ae.decode(z.to(dev), num_steps=2, generator=None)
     assert out.shape == (2, 2, 64)  # closest_power_2(16 * 4)
+
+
+@pytest.mark.parametrize("L", [100, 36])
+def test_unet_ragged_lengths(dev, L):
+    """Lengths that are not multiples of the 4-position vector width (25 / 9 positions at the deepest level): the
+    dispatcher leaves the 16-byte-load kernel families for the generic ones; results and gradients still match."""
+    cfg = dict(in_channels=2, channels=[8, 32, 64], factors=[1, 2, 2], items=[1, 1, 1], modulation_features=32)
+    oracle, net = build_pair(cfg, dev)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 2, L, generator=g)
+    t = torch.tensor([0.1, 0.5, 0.9])
+    y_ref = oracle(x, t)
+    y = net(x.to(dev), t.to(dev))
+    assert rel_err(y, y_ref) < TOL
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    y.backward(gy.to(dev))
+    compare_grads(net, oracle)
+
+
+def test_unet_odd_channel_counts(dev):
+    """Channel counts that are multiples of resnet_groups but not of the 32-channel MFMA chunk (24, 40): generic
+    conv / weight-gradient kernels; factor 4 down/upsampling; out_channels != in_channels (skip adapter)."""
+    cfg = dict(in_channels=3, out_channels=2, channels=[8, 24, 40], factors=[1, 4, 2], items=[1, 1, 2],
+               modulation_features=48)
+    oracle, net = build_pair(cfg, dev)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 64, generator=g)
+    t = torch.tensor([0.25, 0.75])
+    y_ref = oracle(x, t)
+    y = net(x.to(dev), t.to(dev))
+    assert y.shape == (2, 2, 64) and rel_err(y, y_ref) < TOL
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    y.backward(gy.to(dev))
+    compare_grads(net, oracle)
