@@ -133,6 +133,8 @@ MM_CASES = [
 @pytest.mark.parametrize("B,R,M,L,KT,pad,dil", MM_CASES)
 def test_conv_mm_family(dev, B, R, M, L, KT, pad, dil):
     from audio_diffusion_pytorch_amd import _C
+    if dev.type != "cuda" and B * R * M * L * KT > 80e6:
+        pytest.skip("emulator: the large-grid cases run on the GPU only")
     G = 8
     x = (rnd(B, R, L, seed=1) * 1.3 + 0.2).requires_grad_()
     w, b = rnd(M, R, KT, seed=2, scale=0.2), rnd(M, seed=3)
@@ -436,7 +438,7 @@ def test_gn_silu_bwd(dev, B, C, L, G):
 
 # ------------------------------------------------------------------ Modulation / LayerNorm over channels
 @pytest.mark.parametrize("B,C,L", [(2, 8, 300), (2, 32, 70), (1, 130, 64), (2, 100, 50), (2, 300, 40), (1, 1024, 24),
-                                   (4, 512, 1024), (4, 512, 300), (2, 1024, 128)])  # 16 / 8 / 4-position tiles
+                                   (4, 512, 784), (4, 512, 400), (2, 1024, 128)])  # 16 / 8 / 4-position tiles
 def test_modulation_fwd_bwd(dev, B, C, L):
     x = (rnd(B, C, L, seed=1) * 1.5 + 0.4).requires_grad_()
     NT = 2 * C + 7
