@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* x, const f
     __syncthreads();
     if (n < N) {
       const float* wr = w + n * K + k0;
-      for (int k = lane * 4; k < kc; k += 256) {
+#pragma unroll 4
+      for (int k = lane * 4; k < kc; k += 256) {  // a 1024-wide row is four independent 16-byte loads per lane
         float w0, w1, w2, w3;
         if (vec) {
           const float4 wv = *reinterpret_cast<const float4*>(wr + k);

@@ -336,11 +336,27 @@ __global__ __launch_bounds__(1024) void adp_wgrad_reduce_kernel(const float* ws,
   const int64_t i = (int64_t)blockIdx.x * 64 + il;
   const int64_t tot = cnt + (dbias ? M : 0);
   float s = 0.0f;
+  // the partial rows of one output are independent loads: issue them eight at a time (a plain loop waits for each
+  // row's latency in turn), and keep the summation order fixed
+  const float* col = nullptr;
+  int64_t step = 0;
   if (i < cnt) {
-    for (int64_t k = ks; k < nsplit; k += 16) s += ws[k * cnt + i];
+    col = ws + i;
+    step = cnt;
   } else if (i < tot) {
-    const float* wsb = ws + nsplit * cnt + (i - cnt);
-    for (int64_t k = ks; k < nsplit; k += 16) s += wsb[k * M];
+    col = ws + nsplit * cnt + (i - cnt);
+    step = M;
+  }
+  if (col) {
+    int64_t k = ks;
+    for (; k + 7 * 16 < nsplit; k += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = col[(k + 16 * u) * step];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nsplit; k += 16) s += col[k * step];
   }
   part[ks][il] = s;
   __syncthreads();
@@ -360,12 +376,14 @@ __global__ __launch_bounds__(256) void adp_wgrad_reduce_small_kernel(const float
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < cnt) {
     float s = 0.0f;
+#pragma unroll 8
     for (int64_t k = 0; k < nsplit; ++k) s += ws[k * cnt + i];
     dw[i] = accumulate ? dw[i] + s : s;
   } else if (dbias && i < cnt + M) {
     const int64_t m = i - cnt;
     const float* wsb = ws + nsplit * cnt;
     float s = 0.0f;
+#pragma unroll 8
     for (int64_t k = 0; k < nsplit; ++k) s += wsb[k * M + m];
     dbias[m] = accumulate ? dbias[m] + s : s;
   }
