@@ -1,5 +1,5 @@
 """Runs one conv / wgrad shape repeatedly (for rocprofv3 --pmc passes on a single kernel).
-usage: python tools/mm_probe.py <fwd|dgrad|wgrad> B C L [iters]"""
+usage: python tools/mm_probe.py <fwd|dgrad|wgrad|wgrad0> B C L [iters]"""
 import os
 import sys
 
@@ -30,6 +30,8 @@ def run():
         ops.conv1d(x, w, b, pad=1, prologue=1, pro_stats=stats, pro_gamma=g, pro_beta=be, groups=8, res=x, out=out)
     elif kind == "dgrad":
         ops.conv1d(dy, w, None, pad=1, transposed=True, out=out)
+    elif kind == "wgrad0":  # weight gradient of a materialised (already activated) input
+        ops.conv1d_wgrad(x, dy, 3, pad=1, dw=dw, dbias=db)
     else:
         ops.conv1d_wgrad(x, dy, 3, pad=1, prologue=1, pro_stats=stats, pro_gamma=g, pro_beta=be, groups=8, dw=dw, dbias=db)
 
