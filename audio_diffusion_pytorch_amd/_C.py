@@ -75,6 +75,10 @@ SIGNATURES = {
     "adp_mse_bwd": (c_int, [P, P, P, I, P, P]),
     "adp_v_step": (c_int, [P, P, P, I, P, P]),
     "adp_add": (c_int, [P, P, I, P, P]),
+    "adp_axpby": (c_int, [F, P, F, P, I, P, P]),
+    "adp_copy2d": (c_int, [P, I, P, I, I, I, P]),
+    "adp_unshuffle": (c_int, [P, I, I, I, P, P]),
+    "adp_pool_sum": (c_int, [P, I, I, I, P, P, P]),
     "adp_v_inpaint_step": (c_int, [P, P, P, P, P, P, I, P, P]),
     "adp_cfg_mix": (c_int, [P, I, F, P, P]),
     "adp_select_rows": (c_int, [P, P, P, I, I, P, P]),

@@ -61,9 +61,8 @@ def attention_item(run, p, x: Tensor, context: Optional[Tensor]) -> Tensor:
             gbc = run.gspan(p.norm_context.weight, 2 * Cc)
             if is_cross:
                 dctx, _ = ops.ln_bwd(ctx, dcn, st_c, p.norm_context.weight, dgb=gbc)
-                if run.want_emb_grad:
-                    g_emb = dctx.transpose(1, 2)
-                    run.emb_grad = g_emb if run.emb_grad is None else run.emb_grad + g_emb
+                if run.want_emb_grad:  # kept channel-major [B, E, m]; the items' contributions meet in adp_add
+                    run.emb_grad = dctx if run.emb_grad is None else ops.add(run.emb_grad, dctx, out=run.emb_grad)
             else:
                 dx, _ = ops.ln_bwd(x, dcn, st_x, p.norm_context.weight, dres=dx, dgb=gbc)
             return dx

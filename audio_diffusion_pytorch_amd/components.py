@@ -3,9 +3,10 @@
 
 The reference composes a_unet module templates; here the same constructor arguments configure ONE
 kernel-backed module (unet.UNetV0Net); use_embedding_cfg wraps it in the classifier-free-guidance module below
-(the guided and the masked evaluation run as ONE batched U-Net call).  Out of scope:
-use_text_conditioning (T5 download), use_modulation=False (SkipCat), LTPlugin, MelSpectrogram -- each raises a
-clear error instead of silently degrading.
+(the guided and the masked evaluation run as ONE batched U-Net call); use_text_conditioning wraps it in the
+text-conditioning module (the embedder is the caller's module; the t5-base default needs local weights);
+use_modulation=False selects SkipCat; use_time_conditioning=False leaves `features` to the caller.  Out of scope
+(SURVEY.md section 2): LTPlugin, MelSpectrogram.
 """
 from typing import Callable, Optional, Sequence
 
@@ -73,9 +74,56 @@ class ClassifierFreeGuidanceNet(nn.Module):
             two = lambda t: None if t is None else torch.cat([t, t], dim=0)  # noqa: E731  (memory movement only)
             emb2 = torch.cat([embedding, fixed], dim=0)
             ch2 = None if channels is None else [two(c) for c in channels]
+            if kwargs.get("x_append") is not None:  # AppendChannelsPlugin's second input pointer follows the batch
+                kwargs = dict(kwargs, x_append=two(kwargs["x_append"]))
             y2 = self.net(two(x), two(time), embedding=emb2, features=two(features), channels=ch2, **kwargs)
             return ops.cfg_mix(y2.contiguous(), float(embedding_scale))
         return self.net(x, time, embedding=embedding, features=features, channels=channels, **kwargs)
+
+
+class T5Embedder(nn.Module):
+    """a_unet's T5Embedder as TextConditioningPlugin instantiates it (t5-base encoder, max_length tokens, frozen;
+    components.py:70-72).  The encoder is the `transformers` model on stock PyTorch: text encoding is outside the
+    denoising hot path.  Needs the weights in the local HuggingFace cache (no download here)."""
+
+    def __init__(self, model: str = "t5-base", max_length: int = 64):
+        super().__init__()
+        from transformers import AutoTokenizer, T5EncoderModel
+        try:
+            self.tokenizer = AutoTokenizer.from_pretrained(model, local_files_only=True)
+            self.transformer = T5EncoderModel.from_pretrained(model, local_files_only=True)
+        except Exception as e:  # no network on the build / GPU boxes
+            raise NotImplementedError(
+                f"TextConditioningPlugin's default T5Embedder needs the '{model}' weights in the local HuggingFace "
+                "cache; pass UNetV0(..., use_text_conditioning=True, text_embedder=<module: List[str] -> [B, m, E]>) "
+                "or feed `embedding=` directly") from e
+        self.max_length = max_length
+
+    @torch.no_grad()
+    def forward(self, texts) -> Tensor:
+        enc = self.tokenizer(texts, truncation=True, max_length=self.max_length, padding="max_length",
+                             return_tensors="pt")
+        device = next(self.transformer.parameters()).device
+        self.transformer.eval()
+        return self.transformer(input_ids=enc["input_ids"].to(device),
+                                attention_mask=enc["attention_mask"].to(device))["last_hidden_state"]
+
+
+class TextConditioningNet(nn.Module):
+    """a_unet TextConditioningPlugin (components.py:70-72): forward kwarg `text` (list of strings) is embedded and
+    passed on as `embedding` (concatenated in front of a caller-supplied `embedding` along the token axis)."""
+
+    def __init__(self, net: nn.Module, embedder: Optional[nn.Module] = None):
+        super().__init__()
+        self.net = net
+        self.embedder = embedder if exists(embedder) else T5Embedder()
+
+    def forward(self, x: Tensor, *args, text=None, embedding: Optional[Tensor] = None, **kwargs) -> Tensor:
+        assert exists(text), "TextConditioningPlugin requires `text` in forward"
+        text_embedding = self.embedder(text).to(device=x.device, dtype=torch.float32)
+        if exists(embedding):
+            text_embedding = torch.cat([text_embedding, embedding], dim=1)  # token axis; memory movement only
+        return self.net(x, *args, embedding=text_embedding, **kwargs)
 
 
 def UNetV0(
@@ -98,7 +146,11 @@ def UNetV0(
     use_embedding_cfg: bool = False,
     use_text_conditioning: bool = False,
     out_channels: Optional[int] = None,
+    text_embedder: Optional[nn.Module] = None,
 ) -> nn.Module:
+    """Same arguments as the reference factory (components.py:34-54) plus `text_embedder` (the module
+    TextConditioningPlugin would otherwise build from t5-base).  Plugin nesting order as at components.py:66-76:
+    Time(Text(CFG(XUNet))) -- time conditioning lives inside the kernel-backed net."""
     num_layers = len(channels)
     attentions = default(attentions, [0] * num_layers)
     cross_attentions = default(cross_attentions, [0] * num_layers)
@@ -107,41 +159,66 @@ def UNetV0(
     assert all(len(x) == num_layers for x in xs)
 
     if use_embedding_cfg:
-        assert exists(embedding_max_length), "use_embedding_cfg requires embedding_max_length"
+        msg = "use_embedding_cfg requires embedding_max_length"
+        assert exists(embedding_max_length), msg
         assert exists(embedding_features), "use_embedding_cfg requires embedding_features"
-    if use_text_conditioning:
-        raise NotImplementedError("TextConditioningPlugin needs the t5-base download; pass `embedding=` directly")
-    assert use_time_conditioning, "UNetV0 on MI355X is built with TimeConditioningPlugin (the reference default)"
-    assert use_modulation, "use_time_conditioning requires use_modulation=True"
+    if use_time_conditioning:
+        assert use_modulation, "use_time_conditioning requires use_modulation=True"
 
-    net = UNetV0Net(
+    net: nn.Module = UNetV0Net(
         dim=dim, in_channels=in_channels, channels=channels, factors=factors, items=items, attentions=attentions,
         cross_attentions=cross_attentions, context_channels=context_channels,
         attention_features=attention_features, attention_heads=attention_heads,
         embedding_features=embedding_features, resnet_groups=resnet_groups,
-        modulation_features=modulation_features, out_channels=out_channels)
+        modulation_features=modulation_features, out_channels=out_channels, use_modulation=use_modulation,
+        use_time_conditioning=use_time_conditioning)
     if use_embedding_cfg:
-        return ClassifierFreeGuidanceNet(net, embedding_max_length, embedding_features)
+        net = ClassifierFreeGuidanceNet(net, embedding_max_length, embedding_features)
+    if use_text_conditioning:
+        net = TextConditioningNet(net, text_embedder)
     return net
 
 
+class _ConcatChannels(torch.autograd.Function):
+    """cat([x, extra], dim=1) on adp_copy2d, with the split as its gradient."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, extra: Tensor) -> Tensor:
+        ctx.c1 = x.shape[1]
+        return ops.concat_channels(x.contiguous(), extra.contiguous())
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        ga, gb = ops.split_channels(g.contiguous(), ctx.c1)
+        return ga, gb
+
+
+def _accepts_x_append(net: nn.Module) -> bool:
+    """True when the wrapped net ends in a UNetV0Net, whose depth-0 convs can read a second input pointer."""
+    while isinstance(net, (ClassifierFreeGuidanceNet, TextConditioningNet)):
+        net = net.net
+    return isinstance(net, UNetV0Net)
+
+
 class _AppendChannelsNet(nn.Module):
-    """Module returned by AppendChannelsPlugin(net_t, channels)(...): the concat is not materialised --
-    the depth-0 convs read the two tensors through two base pointers (adp_conv_desc.x2)."""
+    """Module returned by AppendChannelsPlugin(net_t, channels)(...).  Around a UNetV0 the concat is not
+    materialised -- the depth-0 convs read the two tensors through two base pointers (adp_conv_desc.x2); around any
+    other net it is one strided-copy kernel pair (adp_copy2d) and the net sees the [B, C + channels, L] tensor."""
 
     def __init__(self, net: nn.Module):
         super().__init__()
         self.net = net
+        self.two_pointer = _accepts_x_append(net)
 
     def forward(self, x: Tensor, *args, append_channels: Tensor, **kwargs) -> Tensor:
-        return self.net(x, *args, x_append=append_channels, **kwargs)
+        if self.two_pointer:
+            return self.net(x, *args, x_append=append_channels, **kwargs)
+        return self.net(_ConcatChannels.apply(x, append_channels), *args, **kwargs)
 
 
 def AppendChannelsPlugin(net_t: Callable, channels: int):
     def Net(in_channels: int, out_channels: Optional[int] = None, **kwargs) -> nn.Module:
         out_channels = default(out_channels, in_channels)
-        net = net_t(in_channels=in_channels + channels, out_channels=out_channels, **kwargs)
-        assert isinstance(net, (UNetV0Net, ClassifierFreeGuidanceNet)), "AppendChannelsPlugin wraps UNetV0 on this backend"
-        return _AppendChannelsNet(net)
+        return _AppendChannelsNet(net_t(in_channels=in_channels + channels, out_channels=out_channels, **kwargs))
 
     return Net

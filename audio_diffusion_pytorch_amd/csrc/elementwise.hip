@@ -105,6 +105,47 @@ __global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = a[i] + b[i];
 }
 
+// out = a * x + b * y (y optional): gradient streams that meet with a constant factor (SkipCat's 2^-1/2 branch)
+__global__ __launch_bounds__(256) void axpby_kernel(float a, const float* x, float b, const float* y, int64_t n,
+                                                    float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = y ? fmaf(a, x[i], b * y[i]) : a * x[i];
+}
+
+// dst[r * dst_stride + c] = src[r * src_stride + c]: channel concat / split of [B, C, L] tensors seen as B rows
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* src, int64_t src_stride, float* dst,
+                                                     int64_t dst_stride, int64_t rows, int64_t cols) {
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols, c = i - r * cols;
+    dst[r * dst_stride + c] = src[r * src_stride + c];
+  }
+}
+
+// space-to-depth of a [rows, L] tensor by factor f: out[(row * f + k), l] = x[row, l * f + k]  (a kernel = stride = f
+// DownsampleItem with a factor the strided conv kernels do not cover becomes a 1x1 conv over the result)
+__global__ __launch_bounds__(256) void unshuffle_kernel(const float* x, int64_t rows, int64_t Lo, int64_t f,
+                                                        float* out) {
+  const int64_t n = rows * Lo * f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / (Lo * f), p = i - row * (Lo * f);  // reads are coalesced
+    const int64_t l = p / f, k = p - l * f;
+    out[(row * f + k) * Lo + l] = x[i];
+  }
+}
+
+// out[row, l] = sum_{k<f} x[row, l * f + k] (+ res[row, l]): gradient of a nearest upsample by any factor
+__global__ __launch_bounds__(256) void pool_sum_kernel(const float* x, int64_t rows, int64_t Lo, int64_t f,
+                                                       const float* res, float* out) {
+  const int64_t n = rows * Lo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float* p = x + i * f;
+    float s = 0.0f;
+    for (int64_t k = 0; k < f; ++k) s += p[k];
+    out[i] = res ? s + res[i] : s;
+  }
+}
+
 __device__ __forceinline__ float act_f(float x, int act) {
   return act == 1 ? adp_silu(x) : (act == 2 ? adp_gelu(x) : x);
 }
@@ -161,7 +202,7 @@ unsigned stream_grid(int64_t n) {
 
 }  // namespace
 
-extern "C" int adp_version(void) { return 101; }
+extern "C" int adp_version(void) { return 200; }
 
 // ---- launch trace (profiling introspection; off by default, host-side only, per thread)
 namespace {
@@ -316,6 +357,37 @@ extern "C" int adp_add(const float* a, const float* b, int64_t n, float* y, void
   if (!a || !b || !y) return ADP_ERR_NULL;
   if (n <= 0) return ADP_ERR_SHAPE;
   ADP_LAUNCH(add_kernel, dim3(stream_grid(n)), dim3(256), stream, a, b, n, y);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_axpby(float a, const float* x, float b, const float* y, int64_t n, float* out, void* stream) {
+  if (!x || !out) return ADP_ERR_NULL;
+  if (n <= 0) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(axpby_kernel, dim3(stream_grid(n)), dim3(256), stream, a, x, b, y, n, out);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_copy2d(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int64_t rows,
+                          int64_t cols, void* stream) {
+  if (!src || !dst) return ADP_ERR_NULL;
+  if (rows <= 0 || cols <= 0 || src_stride < cols || dst_stride < cols) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(copy2d_kernel, dim3(stream_grid(rows * cols)), dim3(256), stream, src, src_stride, dst, dst_stride, rows,
+             cols);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_unshuffle(const float* x, int64_t rows, int64_t L, int64_t f, float* out, void* stream) {
+  if (!x || !out) return ADP_ERR_NULL;
+  if (rows <= 0 || L <= 0 || f < 1 || L % f != 0) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(unshuffle_kernel, dim3(stream_grid(rows * L)), dim3(256), stream, x, rows, L / f, f, out);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_pool_sum(const float* x, int64_t rows, int64_t Lout, int64_t f, const float* res, float* out,
+                            void* stream) {
+  if (!x || !out) return ADP_ERR_NULL;
+  if (rows <= 0 || Lout <= 0 || f < 1) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(pool_sum_kernel, dim3(stream_grid(rows * Lout)), dim3(256), stream, x, rows, Lout, f, res, out);
   return ADP_LAUNCH_OK();
 }
 

@@ -9,8 +9,10 @@ Differences from the reference are structural, not numerical:
     loop never reads device memory (the reference's tqdm f-string syncs every step, diffusion.py:188),
     so one step (U-Net forward + rotation kernel) is captured in a hipGraph and replayed.
 """
+from collections import OrderedDict
+from contextlib import nullcontext
 from math import pi
-from typing import Any, Optional, Tuple
+from typing import Any, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -19,6 +21,13 @@ from torch import Tensor
 from tqdm import tqdm
 
 from . import ops
+
+
+
+def _on_device_of(t: Tensor):
+    """Kernel launches go to the current HIP device's stream: make the tensor's device current for the call."""
+    return torch.cuda.device(t.device) if t.is_cuda else nullcontext()
+
 
 """ Distributions """
 
@@ -98,14 +107,15 @@ class VDiffusion(Diffusion):
     def forward(self, x: Tensor, noise: Optional[Tensor] = None, **kwargs) -> Tensor:
         """`noise` (optional, default torch.randn_like(x) as at diffusion.py:88) lets a harness inject the draw."""
         batch_size, device = x.shape[0], x.device
-        sigmas = self.sigma_distribution(num_samples=batch_size, device=device)
-        if noise is None:
-            noise = torch.randn_like(x)
-        x_noisy, v_target = _VNoise.apply(x, noise, sigmas.to(torch.float32))
-        v_pred = self.net(x_noisy, sigmas, **kwargs)
-        if self.loss_fn is F.mse_loss:
-            return fused_mse_loss(v_pred, v_target)
-        return self.loss_fn(v_pred, v_target)
+        with _on_device_of(x):
+            sigmas = self.sigma_distribution(num_samples=batch_size, device=device)
+            if noise is None:
+                noise = torch.randn_like(x)
+            x_noisy, v_target = _VNoise.apply(x, noise, sigmas.to(torch.float32))
+            v_pred = self.net(x_noisy, sigmas, **kwargs)
+            if self.loss_fn is F.mse_loss:
+                return fused_mse_loss(v_pred, v_target)
+            return self.loss_fn(v_pred, v_target)
 
 
 """ Schedules """
@@ -134,16 +144,40 @@ class Sampler(nn.Module):
     pass
 
 
+def _kw_spec(value, tensors: List[Tensor]):
+    """Hashable structure of a forward kwarg (names / shapes / dtypes / python scalars -- never object identity);
+    the tensors it holds are appended to `tensors` in traversal order.  None when it cannot be made static."""
+    if isinstance(value, Tensor):
+        tensors.append(value)
+        return ("T", tuple(value.shape), value.dtype, value.device)
+    if value is None or isinstance(value, (bool, int, float, str)):
+        return ("S", type(value).__name__, value)
+    if isinstance(value, (list, tuple)):
+        items = tuple(_kw_spec(v, tensors) for v in value)
+        return None if any(i is None for i in items) else ("L", type(value).__name__, items)
+    return None
+
+
+def _kw_rebuild(value, it):
+    """The same structure with every tensor replaced by the next one from `it` (the cache entry's static copy)."""
+    if isinstance(value, Tensor):
+        return next(it)
+    if isinstance(value, (list, tuple)):
+        return type(value)(_kw_rebuild(v, it) for v in value)
+    return value
+
+
 class VSampler(Sampler):
 
     diffusion_types = [VDiffusion]
+    GRAPH_CACHE_ENTRIES = 4  # captured steps kept (LRU); each owns its private activation pool
 
     def __init__(self, net: nn.Module, schedule: Schedule = LinearSchedule(), use_graph: bool = True):
         super().__init__()
         self.net = net
         self.schedule = schedule
         self.use_graph = use_graph
-        self._graph_cache = {}
+        self._graph_cache: "OrderedDict" = OrderedDict()
 
     def get_alpha_beta(self, sigmas: Tensor) -> Tuple[Tensor, Tensor]:
         angle = sigmas * pi / 2
@@ -159,46 +193,68 @@ class VSampler(Sampler):
 
     @torch.no_grad()
     def forward(self, x_noisy: Tensor, num_steps: int, show_progress: bool = False, **kwargs) -> Tensor:
-        b = x_noisy.shape[0]
-        sig, ab = self._tables(num_steps, b, x_noisy.device)
-        x = x_noisy.contiguous().clone()
-        graphable = self.use_graph and x.is_cuda and not show_progress
-        if graphable:
-            return self._forward_graph(x, sig, ab, num_steps, kwargs)
-        bar = tqdm(range(num_steps), disable=not show_progress)
-        host_sigmas = torch.linspace(self.schedule.start, self.schedule.end, num_steps + 1).tolist() \
-            if (show_progress and isinstance(self.schedule, LinearSchedule)) else None
-        for i in bar:
-            v = self.net(x, sig[i], **kwargs)
-            x = ops.v_step(x, v.contiguous(), ab[i])
-            if host_sigmas is not None:
-                bar.set_description(f"Sampling (noise={host_sigmas[i + 1]:.2f})")
-        return x
+        with _on_device_of(x_noisy):
+            b = x_noisy.shape[0]
+            sig, ab = self._tables(num_steps, b, x_noisy.device)
+            x = x_noisy.contiguous().clone()
+            if self.use_graph and x.is_cuda and not show_progress:
+                out = self._forward_graph(x, sig, ab, num_steps, kwargs)
+                if out is not None:
+                    return out
+            bar = tqdm(range(num_steps), disable=not show_progress)
+            host_sigmas = torch.linspace(self.schedule.start, self.schedule.end, num_steps + 1).tolist() \
+                if (show_progress and isinstance(self.schedule, LinearSchedule)) else None
+            for i in bar:
+                v = self.net(x, sig[i], **kwargs)
+                x = ops.v_step(x, v.contiguous(), ab[i])
+                if host_sigmas is not None:
+                    bar.set_description(f"Sampling (noise={host_sigmas[i + 1]:.2f})")
+            return x
 
-    def _forward_graph(self, x: Tensor, sig: Tensor, ab: Tensor, num_steps: int, kwargs) -> Tensor:
-        """One step = U-Net forward + rotation kernel, captured once per (shape, kwargs identity) and replayed;
-        per step only two tiny device-to-device copies (sigma row, alpha/beta row) precede the replay."""
-        key = (tuple(x.shape), x.device, tuple(sorted((k, id(v)) for k, v in kwargs.items())))
+    def _forward_graph(self, x: Tensor, sig: Tensor, ab: Tensor, num_steps: int, kwargs) -> Optional[Tensor]:
+        """One step = U-Net forward + rotation kernel, captured once per call STRUCTURE and replayed.  The cache key
+        is (x shape, kwarg names, tensor shapes/dtypes, python scalar values); the entry owns static copies of every
+        tensor kwarg (also those nested in `channels`) and the caller's tensors are copied into them before the
+        replays, so fresh conditioning tensors per call reuse the graph and can never be read after they are freed.
+        Per step only two tiny device-to-device copies (sigma row, alpha/beta row) precede the replay.  Returns None
+        (eager fallback) for kwargs that cannot be made static."""
+        names = sorted(kwargs)
+        live: List[Tensor] = []
+        specs = tuple((k, _kw_spec(kwargs[k], live)) for k in names)
+        if any(sp is None for _, sp in specs) or any(not t.is_cuda for t in live):
+            return None
+        key = (tuple(x.shape), x.device, specs)
         entry = self._graph_cache.get(key)
         if entry is None:
             sx, ssig, sab = torch.empty_like(x), torch.empty_like(sig[0]), torch.empty_like(ab[0])
+            statics = [torch.empty_like(t, memory_format=torch.contiguous_format) for t in live]
             sx.copy_(x)
             ssig.copy_(sig[0])
             sab.copy_(ab[0])
+            for st, t in zip(statics, live):
+                st.copy_(t)
+            it = iter(statics)
+            skw = {k: _kw_rebuild(kwargs[k], it) for k in names}
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):  # warm-up outside capture
-                v = self.net(sx, ssig, **kwargs)
+                v = self.net(sx, ssig, **skw)
                 ops.v_step(sx, v.contiguous(), sab, out=torch.empty_like(sx))
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                v = self.net(sx, ssig, **kwargs)
+                v = self.net(sx, ssig, **skw)
                 ops.v_step(sx, v.contiguous(), sab, out=sx)  # in place: each element is read then written
-            entry = (graph, sx, ssig, sab)
+            entry = (graph, sx, ssig, sab, statics)
             self._graph_cache[key] = entry
-        graph, sx, ssig, sab = entry
+            while len(self._graph_cache) > self.GRAPH_CACHE_ENTRIES:
+                self._graph_cache.popitem(last=False)  # least recently used graph + its buffers
+        else:
+            self._graph_cache.move_to_end(key)
+        graph, sx, ssig, sab, statics = entry
         sx.copy_(x)
+        for st, t in zip(statics, live):
+            st.copy_(t)
         for i in range(num_steps):
             ssig.copy_(sig[i])
             sab.copy_(ab[i])
@@ -233,6 +289,10 @@ class VInpainter(Inpainter):
     @torch.no_grad()
     def forward(self, source: Tensor, mask: Tensor, num_steps: int, num_resamples: int, show_progress: bool = False,
                 x_noisy: Optional[Tensor] = None, **kwargs) -> Tensor:
+        with _on_device_of(source):
+            return self._run(source, mask, num_steps, num_resamples, show_progress, x_noisy, kwargs)
+
+    def _run(self, source, mask, num_steps, num_resamples, show_progress, x_noisy, kwargs) -> Tensor:
         x = (x_noisy if x_noisy is not None else torch.randn_like(source)).contiguous()
         b = x.shape[0]
         sigmas = self.schedule(num_steps + 1, device=x.device).to(torch.float32)

@@ -1,10 +1,21 @@
-"""`DiffusionModel` and `DiffusionUpsampler`, API-compatible with
-/root/reference/audio_diffusion_pytorch/models.py:22-45 and :134-165 (kwargs-prefix routing via
-utils.groupby; the same `net` object shared by diffusion and sampler), plus `DiffusionAE` (models.py:48-131; the
-latent is injected at `inject_depth` through InjectChannelsItem, whose concat is read through two base pointers by
-the 1x1 conv).  Vocoder / AR wrappers are out of the hot-path scope."""
+"""Model wrappers of the denoising hot path: `DiffusionModel`, `DiffusionUpsampler`, `DiffusionAE`.
+
+Public contract = /root/reference/audio_diffusion_pytorch/models.py:22-45 (DiffusionModel), :48-131 (DiffusionAE and its
+encoder / adapter interfaces) and :134-165 (DiffusionUpsampler): same constructor arguments, `forward` -> loss,
+`sample` / `decode` -> tensor under no_grad, `diffusion_*` / `sampler_*` kwarg prefixes routed to the diffusion and
+the sampler, everything else to `net_t`, ONE net shared by both.
+
+What is organised around the gfx950 kernels rather than around torch ops:
+  * the starting noise of `sample` / `decode` is drawn where it is consumed (on the HIP device) unless the caller
+    hands over a CPU generator, in which case the reference's host draw is reproduced bit for bit;
+  * `reupsample` is two launches of the polyphase resampler (adp_resample) on the caller's tensor -- the kernel
+    never writes its input, so no defensive clone;
+  * the appended / injected conditioning tensors are consumed through a second input pointer of the depth-0 /
+    inject convs (components.AppendChannelsPlugin, unet inject items): no concatenated copy exists.
+Vocoder / AR wrappers are outside the hot-path scope.
+"""
 from abc import ABC, abstractmethod
-from typing import Any, Callable, Optional, Sequence, Tuple, Union
+from typing import Any, Callable, Dict, Optional, Sequence, Tuple, Union
 
 import torch
 import torch.nn as nn
@@ -12,30 +23,54 @@ from torch import Generator, Tensor
 
 from .components import AppendChannelsPlugin
 from .diffusion import VDiffusion, VSampler
-from .utils import closest_power_2, default, downsample, exists, groupby, randn_like, upsample
+from .utils import closest_power_2, downsample, upsample
+
+
+def _split_prefixed(kwargs: Dict[str, Any], *prefixes: str):
+    """({prefix: {stripped name: value}}, the rest) -- the reference's chained utils.groupby calls in one pass."""
+    routed: Dict[str, Dict[str, Any]] = {p: {} for p in prefixes}
+    rest: Dict[str, Any] = {}
+    for name, value in kwargs.items():
+        for p in prefixes:
+            if name.startswith(p):
+                routed[p][name[len(p):]] = value
+                break
+        else:
+            rest[name] = value
+    return routed, rest
+
+
+def _start_noise(shape: Sequence[int], like: Tensor, generator: Optional[Generator]) -> Tensor:
+    """N(0, 1) starting point of a sampling run, produced on `like`'s device.  A CPU generator keeps the reference's
+    behaviour (utils.py:123-125: host draw, then one H2D copy) so seeded runs reproduce across backends."""
+    if generator is not None and generator.device.type == "cpu" and like.device.type != "cpu":
+        return torch.randn(tuple(shape), generator=generator, dtype=like.dtype).to(like.device)
+    return torch.randn(tuple(shape), generator=generator, dtype=like.dtype, device=like.device)
 
 
 class DiffusionModel(nn.Module):
+    """net + diffusion (training objective) + sampler over the same net (models.py:22-45)."""
+
     def __init__(self, net_t: Callable, diffusion_t: Callable = VDiffusion, sampler_t: Callable = VSampler,
                  loss_fn: Callable = torch.nn.functional.mse_loss, dim: int = 1, **kwargs):
         super().__init__()
-        diffusion_kwargs, kwargs = groupby("diffusion_", kwargs)
-        sampler_kwargs, kwargs = groupby("sampler_", kwargs)
-
-        self.net = net_t(dim=dim, **kwargs)
-        self.diffusion = diffusion_t(net=self.net, loss_fn=loss_fn, **diffusion_kwargs)
-        self.sampler = sampler_t(net=self.net, **sampler_kwargs)
+        routed, net_kwargs = _split_prefixed(kwargs, "diffusion_", "sampler_")
+        self.net = net_t(dim=dim, **net_kwargs)
+        self.diffusion = diffusion_t(net=self.net, loss_fn=loss_fn, **routed["diffusion_"])
+        self.sampler = sampler_t(net=self.net, **routed["sampler_"])
 
     def forward(self, *args, **kwargs) -> Tensor:
+        """Training loss of one batch (VDiffusion: fused noising kernel -> U-Net -> fused MSE)."""
         return self.diffusion(*args, **kwargs)
 
     @torch.no_grad()
     def sample(self, *args, **kwargs) -> Tensor:
+        """Runs the sampler from the given noise (VSampler: hipGraph-replayed steps)."""
         return self.sampler(*args, **kwargs)
 
 
 class EncoderBase(nn.Module, ABC):
-    """Abstract class for DiffusionAE encoder (models.py:48-55): sets `out_channels` and `downsample_factor`."""
+    """DiffusionAE encoder interface (models.py:48-55): subclasses set `out_channels` and `downsample_factor`."""
 
     @abstractmethod
     def __init__(self):
@@ -45,7 +80,7 @@ class EncoderBase(nn.Module, ABC):
 
 
 class AdapterBase(nn.Module, ABC):
-    """Abstract class for DiffusionAE adapter (models.py:58-67)."""
+    """DiffusionAE adapter interface (models.py:58-67): maps the waveform to / from the domain the U-Net works in."""
 
     @abstractmethod
     def encode(self, x: Tensor) -> Tensor:
@@ -57,59 +92,59 @@ class AdapterBase(nn.Module, ABC):
 
 
 class DiffusionAE(DiffusionModel):
-    """Diffusion Auto Encoder (models.py:70-131).  The user-supplied `encoder` is an ordinary torch module; its
-    latent enters the U-Net at `inject_depth` as `channels[inject_depth]` and receives its gradient from the U-Net
-    backward (the encoder trains through the HIP kernels' data gradient of the inject conv)."""
+    """Diffusion auto-encoder (models.py:70-131).  `encoder` is the caller's torch module; its latent reaches the
+    U-Net as `channels[inject_depth]`, where the InjectChannelsItem's 1x1 conv reads [x | latent] through two input
+    pointers, and the latent's gradient comes back from that conv's HIP data-gradient kernel into the encoder."""
 
     def __init__(self, in_channels: int, channels: Sequence[int], encoder: EncoderBase, inject_depth: int,
                  latent_factor: Optional[int] = None, adapter: Optional[AdapterBase] = None, **kwargs):
-        context_channels = [0] * len(channels)
-        context_channels[inject_depth] = encoder.out_channels
-        super().__init__(in_channels=in_channels, channels=channels, context_channels=context_channels, **kwargs)
+        per_depth_context = [encoder.out_channels if d == inject_depth else 0 for d in range(len(channels))]
+        super().__init__(in_channels=in_channels, channels=channels, context_channels=per_depth_context, **kwargs)
         self.in_channels = in_channels
-        self.encoder = encoder
         self.inject_depth = inject_depth
-        self.latent_factor = default(latent_factor, self.encoder.downsample_factor)
-        self.adapter = adapter.requires_grad_(False) if exists(adapter) else None
+        self.encoder = encoder
+        self.latent_factor = latent_factor if latent_factor is not None else encoder.downsample_factor
+        self.adapter = None if adapter is None else adapter.requires_grad_(False)
 
-    def forward(self, x: Tensor, with_info: bool = False, **kwargs) -> Union[Tensor, Tuple[Tensor, Any]]:
-        latent, info = self.encode(x, with_info=True)
-        channels = [None] * self.inject_depth + [latent]
-        x = self.adapter.encode(x) if exists(self.adapter) else x
-        loss = super().forward(x, channels=channels, **kwargs)
-        return (loss, info) if with_info else loss
+    def _context(self, latent: Tensor):
+        """`channels` list for the U-Net: placeholders down to the injection depth, then the latent."""
+        return [None] * self.inject_depth + [latent]
 
     def encode(self, *args, **kwargs):
         return self.encoder(*args, **kwargs)
 
+    def forward(self, x: Tensor, with_info: bool = False, **kwargs) -> Union[Tensor, Tuple[Tensor, Any]]:
+        latent, info = self.encode(x, with_info=True)
+        target = x if self.adapter is None else self.adapter.encode(x)
+        loss = super().forward(target, channels=self._context(latent), **kwargs)
+        return (loss, info) if with_info else loss
+
     @torch.no_grad()
     def decode(self, latent: Tensor, generator: Optional[Generator] = None, **kwargs) -> Tensor:
-        b = latent.shape[0]
-        noise_length = closest_power_2(latent.shape[2] * self.latent_factor)
-        noise = torch.randn((b, self.in_channels, noise_length), device=latent.device, dtype=latent.dtype,
-                            generator=generator)
-        channels = [None] * self.inject_depth + [latent]
-        out = super().sample(noise, channels=channels, **kwargs)
-        return self.adapter.decode(out) if exists(self.adapter) else out
+        length = closest_power_2(latent.shape[2] * self.latent_factor)
+        noise = _start_noise((latent.shape[0], self.in_channels, length), latent, generator)
+        out = super().sample(noise, channels=self._context(latent), **kwargs)
+        return out if self.adapter is None else self.adapter.decode(out)
 
 
 class DiffusionUpsampler(DiffusionModel):
+    """Diffusion upsampler (models.py:134-165): the U-Net denoises the full-rate signal conditioned on the
+    low-rate one re-upsampled to full rate, appended as extra input channels."""
+
     def __init__(self, in_channels: int, upsample_factor: int, net_t: Callable, **kwargs):
         self.upsample_factor = upsample_factor
         super().__init__(net_t=AppendChannelsPlugin(net_t, channels=in_channels), in_channels=in_channels, **kwargs)
 
     def reupsample(self, x: Tensor) -> Tensor:
-        x = x.clone()
-        x = downsample(x, factor=self.upsample_factor)
-        x = upsample(x, factor=self.upsample_factor)
-        return x
+        """down x f then up x f with the windowed-sinc polyphase kernel (utils.py:82-117 semantics); `x` is only read."""
+        f = self.upsample_factor
+        return upsample(downsample(x, factor=f), factor=f)
 
     def forward(self, x: Tensor, *args, **kwargs) -> Tensor:
-        reupsampled = self.reupsample(x)
-        return super().forward(x, *args, append_channels=reupsampled, **kwargs)
+        return super().forward(x, *args, append_channels=self.reupsample(x), **kwargs)
 
     @torch.no_grad()
     def sample(self, downsampled: Tensor, generator: Optional[Generator] = None, **kwargs) -> Tensor:
-        reupsampled = upsample(downsampled, factor=self.upsample_factor)
-        noise = randn_like(reupsampled, generator=generator)
-        return super().sample(noise, append_channels=reupsampled, **kwargs)
+        conditioning = upsample(downsampled, factor=self.upsample_factor)
+        noise = _start_noise(conditioning.shape, conditioning, generator)
+        return super().sample(noise, append_channels=conditioning, **kwargs)

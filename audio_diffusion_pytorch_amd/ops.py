@@ -343,6 +343,56 @@ def add(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
     return out
 
 
+def axpby(a: float, x: Tensor, b: float = 0.0, y: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """out = a * x + b * y (y optional)."""
+    if out is None:
+        out = torch.empty_like(x)
+    _C.call("adp_axpby", float(a), ptr(x), float(b), ptr(y), x.numel(), ptr(out), _C.stream())
+    return out
+
+
+def concat_channels(x: Tensor, x2: Tensor) -> Tensor:
+    """torch.cat([x, x2], dim=1) of [B, C, L] tensors as two strided row copies (adp_copy2d)."""
+    B, C1, L = x.shape
+    C2 = x2.shape[1]
+    assert x2.shape[0] == B and x2.shape[2] == L, "concat_channels: batch / length mismatch"
+    out = torch.empty((B, C1 + C2, L), dtype=torch.float32, device=x.device)
+    flat = out.view(-1)
+    s = _C.stream()
+    _C.call("adp_copy2d", ptr(x), C1 * L, ptr(flat), (C1 + C2) * L, B, C1 * L, s)
+    _C.call("adp_copy2d", ptr(x2), C2 * L, ptr(flat[C1 * L:]), (C1 + C2) * L, B, C2 * L, s)
+    return out
+
+
+def split_channels(g: Tensor, C1: int):
+    """Inverse of concat_channels: contiguous (g[:, :C1], g[:, C1:])."""
+    B, C, L = g.shape
+    a = torch.empty((B, C1, L), dtype=torch.float32, device=g.device)
+    b = torch.empty((B, C - C1, L), dtype=torch.float32, device=g.device)
+    flat = g.view(-1)
+    s = _C.stream()
+    _C.call("adp_copy2d", ptr(flat), C * L, ptr(a), C1 * L, B, C1 * L, s)
+    _C.call("adp_copy2d", ptr(flat[C1 * L:]), C * L, ptr(b), (C - C1) * L, B, (C - C1) * L, s)
+    return a, b
+
+
+def unshuffle(x: Tensor, f: int) -> Tensor:
+    """[B, C, L] -> [B, C*f, L/f] with out[b, c*f + k, l] = x[b, c, l*f + k] (adp_unshuffle)."""
+    B, C, L = x.shape
+    assert L % f == 0, "length must be divisible by the downsample factor"
+    out = torch.empty((B, C * f, L // f), dtype=torch.float32, device=x.device)
+    _C.call("adp_unshuffle", ptr(x), B * C, L, f, ptr(out), _C.stream())
+    return out
+
+
+def pool_sum(x: Tensor, f: int, res: Optional[Tensor] = None) -> Tensor:
+    """[B, C, L*f] -> [B, C, L]: sums f adjacent positions (+ res) (adp_pool_sum)."""
+    B, C, Lf = x.shape
+    out = torch.empty((B, C, Lf // f), dtype=torch.float32, device=x.device)
+    _C.call("adp_pool_sum", ptr(x), B * C, Lf // f, f, ptr(res), ptr(out), _C.stream())
+    return out
+
+
 def attn_fwd(q: Tensor, kv: Tensor, heads: int, head_features: int):
     """q [B, H*D, n]; kv [B, 2*H*D, m] (k = first half of the channels, v = second half) -> o [B, H*D, n], lse."""
     B, mid, n = q.shape

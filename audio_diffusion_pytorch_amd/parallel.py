@@ -36,8 +36,19 @@ def init_process_group_from_env(backend: Optional[str] = None) -> int:
 
 
 class DataParallel(nn.Module):
-    """Wraps a DiffusionModel (or any module whose `.net` is a UNetV0 instance): broadcasts rank 0's parameters
-    once, then averages gradients across ranks inside backward.  forward(*a, **kw) -> module(*a, **kw)."""
+    """Wraps a DiffusionModel (or any module containing a UNetV0 instance): broadcasts rank 0's parameters once, then
+    averages gradients across ranks during backward.  forward(*a, **kw) -> module(*a, **kw).
+
+    Two gradient families:
+      * the U-Net's parameters -- one flat buffer written by the kernels, all-reduced in place in buckets as the
+        backward finalises contiguous regions (hook called from unet._UNetFn.backward);
+      * every other trainable parameter of the wrapped module (ClassifierFreeGuidance's fixed embedding table, a
+        DiffusionAE encoder, ...) -- ordinary autograd gradients, gathered into ONE trailing bucket and all-reduced
+        when the whole backward pass is over (together with a per-parameter "some rank produced a gradient" flag, so
+        parameters unused on every rank keep grad = None).
+    The U-Net's collectives are waited for (stream wait, no host sync) at the end of the U-Net's backward node --
+    before autograd's AccumulateGrad touches the flat buffer's views; the trailing bucket is issued and waited for
+    in an autograd final callback, after the last node of the backward pass."""
 
     def __init__(self, module: nn.Module, min_bucket_bytes: int = 32 << 20, process_group=None):
         super().__init__()
@@ -47,13 +58,22 @@ class DataParallel(nn.Module):
         self.min_bucket = min_bucket_bytes // 4
         self._works: List = []
         self._pending: List = []  # contiguous (start, end) regions not yet sent
+        self._final_queued = False
         self.unet = self._find_unet(module)
+        own = {id(p) for p in self.unet.parameters()}
+        self._extra = [p for p in module.parameters() if id(p) not in own and p.requires_grad]
+        dev = next(module.parameters()).device
+        if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+            raise RuntimeError(f"DataParallel: the module lives on {dev} but the current device is "
+                               f"cuda:{torch.cuda.current_device()}; call torch.cuda.set_device first")
         if self.world > 1:
             with torch.no_grad():
                 for p in module.parameters():
                     dist.broadcast(p, src=0, group=process_group)
             self.unet._grad_ready_hook = self._on_ready
             self._avg = dist.get_backend(process_group) == "nccl"
+            for p in self._extra:
+                p.register_post_accumulate_grad_hook(self._on_extra_grad)
 
     @staticmethod
     def _find_unet(module: nn.Module):
@@ -69,6 +89,48 @@ class DataParallel(nn.Module):
     def sample(self, *args, **kwargs):  # sampling is replica-local: no communication
         return self.module.sample(*args, **kwargs)
 
+    # ---- end-of-backward synchronisation (one autograd final callback per backward pass)
+    def _queue_final(self):
+        if not self._final_queued:
+            self._final_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+
+    def _on_extra_grad(self, p):
+        self._queue_final()
+
+    def _finalize(self):
+        self._final_queued = False
+        if self._extra:  # trailing bucket: [grad of every non-U-Net parameter | has-grad flags]
+            sizes = [p.numel() for p in self._extra]
+            ref = self._extra[0]
+            buf = torch.zeros(sum(sizes) + len(sizes), dtype=torch.float32, device=ref.device)
+            off = 0
+            for i, (p, n) in enumerate(zip(self._extra, sizes)):
+                if p.grad is not None:
+                    buf[off:off + n].copy_(p.grad.reshape(-1))
+                    buf[sum(sizes) + i] = 1.0
+                off += n
+            self._works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
+        self._wait_all()
+        if self._extra:
+            flags = buf[sum(sizes):].tolist()  # tiny host read, once per step, after every collective was issued
+            off = 0
+            for p, n, used in zip(self._extra, sizes, flags):
+                if used > 0:
+                    avg = (buf[off:off + n] / self.world).view(p.shape)
+                    if p.grad is None:
+                        p.grad = avg.clone()
+                    else:
+                        p.grad.copy_(avg)
+                off += n
+
+    def _wait_all(self):
+        for w, scaled in self._works:
+            w.wait()
+            if scaled is not None:
+                scaled.mul_(1.0 / self.world)
+        self._works = []
+
     # ---- called from the U-Net backward as regions of the flat gradient become final
     def _send(self, flat: torch.Tensor, a: int, b: int):
         buf = flat[a:b]
@@ -78,15 +140,13 @@ class DataParallel(nn.Module):
             self._works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf))
 
     def _on_ready(self, flat: torch.Tensor, start, end):
-        if start is None:  # end of backward: flush and make the compute stream wait for the collectives
+        if start is None:  # end of the U-Net backward: flush, then make the compute stream wait for the collectives
             for reg in self._pending:
                 self._send(flat, *reg)
             self._pending = []
-            for w, buf in self._works:
-                w.wait()
-                if buf is not None:
-                    buf.mul_(1.0 / self.world)
-            self._works = []
+            self._wait_all()
+            if self._extra:
+                self._queue_final()
             return
         # Regions arrive as several interleaved address-descending streams (the blocks deepest-first, and each
         # depth's rows of the conditioning bank): merge a new region into the pending region it touches, and send a

@@ -87,10 +87,12 @@ class UNetV0Net(nn.Module):
                  items: Sequence[int], attentions: Sequence[int], cross_attentions: Sequence[int],
                  context_channels: Sequence[int], attention_features: Optional[int], attention_heads: Optional[int],
                  embedding_features: Optional[int], resnet_groups: int, modulation_features: int,
-                 out_channels: Optional[int]):
+                 out_channels: Optional[int], use_modulation: bool = True, use_time_conditioning: bool = True):
         super().__init__()
         assert dim == 1, "audio U-Net is 1-D"
+        assert use_modulation or not use_time_conditioning, "use_time_conditioning requires use_modulation=True"
         n = len(channels)
+        self.use_modulation, self.use_time = bool(use_modulation), bool(use_time_conditioning)
         self.in_channels = in_channels
         self.out_channels = out_channels if out_channels is not None else in_channels
         self.channels, self.factors = list(channels), list(factors)
@@ -102,12 +104,15 @@ class UNetV0Net(nn.Module):
         for c in channels:
             assert c % resnet_groups == 0, "channels must be divisible by resnet_groups"
         for f in factors:
-            assert f in (1, 2, 4), "down/upsample factors 1, 2, 4 are supported by the gfx950 conv kernels"
+            assert int(f) == f and f >= 1, "down/upsample factors are positive integers"
+        # factors 1 / 2 / 4 run on the strided-conv and upsample-loader kernel variants; any other integer factor
+        # goes through adp_unshuffle + a 1x1 conv (down) and the generic upsample loader + adp_pool_sum (up)
 
         # ---- TimeConditioningPlugin: NumberEmbedder(features=MF, dim=256) + 2 x (Linear + GELU)
-        self.time_weights = nn.Parameter(torch.randn(TIME_EMBED_DIM // 2))
-        self.time_linear = _linear_params(TIME_EMBED_DIM + 1, self.mf)
-        self.time_mlp = nn.ModuleList([_linear_params(self.mf, self.mf) for _ in range(TIME_NUM_LAYERS)])
+        if self.use_time:
+            self.time_weights = nn.Parameter(torch.randn(TIME_EMBED_DIM // 2))
+            self.time_linear = _linear_params(TIME_EMBED_DIM + 1, self.mf)
+            self.time_mlp = nn.ModuleList([_linear_params(self.mf, self.mf) for _ in range(TIME_NUM_LAYERS)])
 
         # ---- blocks; every Modulation / SkipModulate Linear goes into the bank
         bank_w, bank_b = [], []
@@ -128,7 +133,7 @@ class UNetV0Net(nn.Module):
             in_ch = in_channels if d == 0 else channels[d - 1]
             out_ch = self.out_channels if d == 0 else in_ch
             C, f = channels[d], factors[d]
-            its = item_list(items[d], True, context_channels[d], attentions[d], cross_attentions[d])
+            its = item_list(items[d], self.use_modulation, context_channels[d], attentions[d], cross_attentions[d])
             self.item_types.append(its)
             blk = _P()
             blk.down = _conv_params(in_ch, C, f)
@@ -138,7 +143,10 @@ class UNetV0Net(nn.Module):
             blk.up = _conv_params(C, out_ch, 3)
             if in_ch != out_ch:
                 blk.skip_adapter = _conv_params(in_ch, out_ch, 1)
-            bank_add((d, "skip"), out_ch)
+            if self.use_modulation:
+                bank_add((d, "skip"), out_ch)                        # SkipModulate (components.py:99)
+            else:
+                blk.skip_cat = _conv_params(2 * out_ch, out_ch, 1)   # SkipCat: Conv1x1(cat[skip * 2^-1/2, x])
             blk.in_ch, blk.out_ch = in_ch, out_ch
             blocks.append(blk)
         self.blocks = nn.ModuleList(blocks)
@@ -148,8 +156,9 @@ class UNetV0Net(nn.Module):
         for d in range(n):
             offs = [(o, o + c) for k, (o, c) in self.bank_slices.items() if k[0] == d]
             self.bank_depth_rows.append((min(a for a, _ in offs), max(b for _, b in offs)) if offs else (0, 0))
-        self.bank_weight = nn.Parameter(torch.cat(bank_w, 0).contiguous())
-        self.bank_bias = nn.Parameter(torch.cat(bank_b, 0).contiguous())
+        if off > 0:
+            self.bank_weight = nn.Parameter(torch.cat(bank_w, 0).contiguous())
+            self.bank_bias = nn.Parameter(torch.cat(bank_b, 0).contiguous())
 
     def _make_item(self, t: str, d: int, C: int, key, bank_add) -> nn.Module:
         p = _P()
@@ -189,6 +198,8 @@ class UNetV0Net(nn.Module):
                 if parts[2] in ("items_down", "items_up") and parts[4] == "to_scale_shift":
                     off, nout = self.bank_slices[(d, parts[2][6:], int(parts[3]))]
                     (self.bank_weight if parts[5] == "weight" else self.bank_bias)[off:off + nout].copy_(v)
+                elif parts[2] == "skip" and parts[3] == "conv":      # SkipCat's 1x1 conv
+                    own[f"blocks.{d}.skip_cat.{parts[4]}"].copy_(v)
                 elif parts[2] == "skip":
                     off, nout = self.bank_slices[(d, "skip")]
                     (self.bank_weight if parts[4] == "weight" else self.bank_bias)[off:off + nout].copy_(v)
@@ -201,7 +212,7 @@ class UNetV0Net(nn.Module):
         for k, v in grads.items():
             if k in ("bank_weight", "bank_bias"):
                 continue
-            out[k] = v
+            out[k.replace(".skip_cat.", ".skip.conv.")] = v
         for key, (off, nout) in self.bank_slices.items():
             if key[1] == "skip":
                 base = f"blocks.{key[0]}.skip.to_scale"
@@ -244,11 +255,38 @@ class UNetV0Net(nn.Module):
     def forward(self, x: Tensor, time: Optional[Tensor] = None, *, features: Optional[Tensor] = None,
                 embedding: Optional[Tensor] = None, channels: Optional[Sequence[Optional[Tensor]]] = None,
                 x_append: Optional[Tensor] = None) -> Tensor:
-        assert time is not None, "TimeConditioningPlugin requires time in forward"
+        if self.use_time:
+            assert time is not None, "TimeConditioningPlugin requires time in forward"
+        elif time is not None:  # the reference's bare XUNet.forward takes x only (keyword conditioning)
+            raise TypeError("UNetV0(use_time_conditioning=False).forward() takes 1 positional argument (x); "
+                            "`time` was given")
+        if self.bank_total > 0 and not self.use_time:
+            assert features is not None, "ModulationItem requires `features` when use_time_conditioning=False"
         params = list(self.parameters())
         ctx_list = [c for c in (channels or []) if c is not None]
-        return _UNetFn.apply(self, x, time, features, embedding, x_append, channels, len(ctx_list), *ctx_list,
-                             *params)
+        if not x.is_cuda:  # CPU tensors only reach the kernels through the test-suite's SIMT emulator build
+            return _UNetFn.apply(self, x, time, features, embedding, x_append, channels, len(ctx_list), *ctx_list,
+                                 *params)
+        for t in (time, features, embedding, x_append, *ctx_list, params[0]):
+            if t is not None and t.device != x.device:
+                raise RuntimeError(f"UNetV0: every tensor must live on the input's device {x.device}; got {t.device}")
+        with torch.cuda.device(x.device):  # launches go to the current device's stream
+            return _UNetFn.apply(self, x, time, features, embedding, x_append, channels, len(ctx_list), *ctx_list,
+                                 *params)
+
+
+NATIVE_FACTORS = (1, 2, 4)      # down/upsample factors with dedicated conv kernel variants
+SKIP_CAT_SCALE = 2 ** -0.5      # a_unet SkipCat / MergeCat: cat[skip * scale, x]
+POISON_GRADS = os.environ.get("ADP_DEBUG_POISON", "0") == "1"
+
+
+def _grad_buffer(shape, device) -> Tensor:
+    """Gradient destination the kernels OVERWRITE slice by slice: left uninitialised (no 0.7 GB memset per backward).
+    ADP_DEBUG_POISON=1 (set by the test-suite) fills it with NaN so that a slice nobody wrote cannot pass a test."""
+    buf = torch.empty(shape, dtype=torch.float32, device=device)
+    if POISON_GRADS:
+        buf.fill_(float("nan"))
+    return buf
 
 
 # channel count from which SiLU(GroupNorm(x)) is materialised instead of recomputed in the conv loaders
@@ -277,25 +315,35 @@ class _Run:
     # -- conditioning ---------------------------------------------------------------------
     def conditioning(self, time: Tensor, features: Optional[Tensor]):
         n = self.net
-        t = time.reshape(-1).to(torch.float32).contiguous()
-        four = ops.time_fourier_fwd(t, n.time_weights)
-        pre = [ops.linear_fwd(four, n.time_linear.weight, n.time_linear.bias)]
-        acts = [ops.act_fwd(pre[0], ACT_GELU)]
-        for lin in n.time_mlp:
-            pre.append(ops.linear_fwd(acts[-1], lin.weight, lin.bias))
-            acts.append(ops.act_fwd(pre[-1], ACT_GELU))
-        feats = acts[-1] if features is None else ops.add(features.contiguous(), acts[-1])
-        ss_all = ops.linear_fwd(feats, n.bank_weight, n.bank_bias, act=ACT_SILU)
-        self.t, self.four, self.pre, self.acts, self.feats, self.ss_all = t, four, pre, acts, feats, ss_all
-        if self.need_grad:
-            self.dss_all = torch.zeros_like(ss_all)
-        return ss_all
+        self.ss_all = self.dss_all = None
+        if n.use_time:
+            t = time.reshape(-1).to(torch.float32).contiguous()
+            four = ops.time_fourier_fwd(t, n.time_weights)
+            pre = [ops.linear_fwd(four, n.time_linear.weight, n.time_linear.bias)]
+            acts = [ops.act_fwd(pre[0], ACT_GELU)]
+            for lin in n.time_mlp:
+                pre.append(ops.linear_fwd(acts[-1], lin.weight, lin.bias))
+                acts.append(ops.act_fwd(pre[-1], ACT_GELU))
+            feats = acts[-1] if features is None else ops.add(features.contiguous(), acts[-1])
+            self.t, self.four, self.pre, self.acts = t, four, pre, acts
+        else:
+            feats = features.contiguous() if features is not None else None
+        self.feats = feats
+        if n.bank_total > 0:
+            self.ss_all = ops.linear_fwd(feats, n.bank_weight, n.bank_bias, act=ACT_SILU)
+            if self.need_grad:  # every Modulation / SkipModulate backward OVERWRITES its slice: no zero fill
+                self.dss_all = _grad_buffer(self.ss_all.shape, self.ss_all.device)
+        return self.ss_all
 
     def conditioning_backward(self) -> Tensor:
         """Back-propagates dss_all through the bank and the time MLP; returns d(features)."""
         n = self.net
+        if n.bank_total == 0:
+            return None
         dfa = ops.linear_bwd_data(self.dss_all, n.bank_weight)  # the bank's own gradient: bank_grad_for_depth
         dfeat = ops.act_bwd(self.feats, dfa, ACT_SILU)
+        if not n.use_time:
+            return dfeat
         dcur = dfeat
         lins = [n.time_linear] + list(n.time_mlp)
         for i in range(len(lins) - 1, -1, -1):
@@ -312,7 +360,7 @@ class _Run:
         end of the backward pass -- their all-reduce overlaps the shallower blocks instead of trailing the step.
         Returns the (start, end) row range."""
         n = self.net
-        a, b = n.bank_depth_rows[d]
+        a, b = n.bank_depth_rows[d] if n.bank_total > 0 else (0, 0)
         if b > a:
             K = n.mf
             ops.linear_bwd_weight(self.dss_all.view(-1)[a:], self.feats, act=ACT_SILU,
@@ -429,58 +477,84 @@ class _Run:
             return x
         blk = n.blocks[d]
         f, NT = n.factors[d], n.bank_total
+        native = f in NATIVE_FACTORS          # strided-conv / upsample-loader kernel variants exist for 1, 2, 4
         has_adapter = hasattr(blk, "skip_adapter")
         if has_adapter:
             skip = ops.conv1d(x, blk.skip_adapter.weight, blk.skip_adapter.bias, x2=x2)
         else:
             assert x2 is None
             skip = x
-        h0 = ops.conv1d(x, blk.down.weight, blk.down.bias, stride=f, x2=x2)
+        wd = blk.down.weight
+        if native:
+            xs = x2s = None
+            h0 = ops.conv1d(x, wd, blk.down.bias, stride=f, x2=x2)
+        else:  # Conv1d(kernel = stride = f) == 1x1 conv over the space-to-depth view of its input
+            xs = ops.unshuffle(x, f)
+            x2s = ops.unshuffle(x2, f) if x2 is not None else None
+            h0 = ops.conv1d(xs, wd.view(wd.shape[0], -1, 1), blk.down.bias, x2=x2s)
         tape_mark_down = len(self.tape)
         h = self.run_items(d, "down", blk.items_down, h0, embedding, channels)
         h = self.block(d + 1, h, None, embedding, channels, True)
         h = self.run_items(d, "up", blk.items_up, h, embedding, channels)
-        sc, dsc = self.ss((d, "skip"))
-        u = torch.empty((x.shape[0], blk.out_ch, h.shape[2] * f), dtype=torch.float32, device=x.device) \
-            if self.need_grad else None
-        y = self._up_conv(blk, h, f, sc, NT, skip, u)
+        modulate = n.use_modulation
+        if modulate:
+            # y = skip + scale[b,c] * (conv_k3(nearest_up_f(h)) + bias); u keeps the pre-merge value for the backward
+            sc, dsc = self.ss((d, "skip"))
+            u = torch.empty((x.shape[0], blk.out_ch, h.shape[2] * f), dtype=torch.float32, device=x.device) \
+                if self.need_grad else None
+            y = ops.conv1d(h, blk.up.weight, blk.up.bias, pad=1, up=f, e_scale=sc, e_bstride=NT, res=skip, out_pre=u)
+        else:
+            # SkipCat: y = Conv1x1(cat[skip * 2^-1/2, u]) -- the concat is the conv's two input pointers
+            u = ops.conv1d(h, blk.up.weight, blk.up.bias, pad=1, up=f)
+            skip_s = ops.axpby(SKIP_CAT_SCALE, skip)
+            y = ops.conv1d(skip_s, blk.skip_cat.weight, blk.skip_cat.bias, x2=u)
         if self.need_grad:
             h_up = h
 
             def bwd_up(gy):
-                du = ops.skipmod_bwd(gy, u, sc, NT, dsc, NT)
+                if modulate:
+                    du = ops.skipmod_bwd(gy, u, sc, NT, dsc, NT)
+                    gskip = gy
+                else:
+                    wc, C = blk.skip_cat.weight, blk.out_ch
+                    ops.conv1d_wgrad(skip_s, gy, 1, x2=u, dw=self.g(wc), dbias=self.g(blk.skip_cat.bias))
+                    gskip = ops.conv1d(gy, wc[:, :C, :].contiguous(), None, transposed=True)
+                    gskip = ops.axpby(SKIP_CAT_SCALE, gskip, out=gskip)
+                    du = ops.conv1d(gy, wc[:, C:, :].contiguous(), None, transposed=True)
                 ops.conv1d_wgrad(h_up, du, 3, pad=1, up=f, dw=self.g(blk.up.weight), dbias=self.g(blk.up.bias))
-                gh = ops.conv1d(du, blk.up.weight, None, pad=1, transposed=True, store=2 if f > 1 else 0, sp=f)
-                self.skip_grads.append(gy)
+                if native:
+                    gh = ops.conv1d(du, blk.up.weight, None, pad=1, transposed=True, store=2 if f > 1 else 0, sp=f)
+                else:  # gradient of the nearest upsample = sum over the f replicas of each source position
+                    gh = ops.pool_sum(ops.conv1d(du, blk.up.weight, None, pad=1, transposed=True), f)
+                self.skip_grads.append(gskip)
                 return gh
 
             def bwd_down(gh):
                 gskip = self.skip_grads.pop()
-                ops.conv1d_wgrad(x, gh, f, stride=f, x2=x2, dw=self.g(blk.down.weight), dbias=self.g(blk.down.bias))
+                if native:
+                    ops.conv1d_wgrad(x, gh, f, stride=f, x2=x2, dw=self.g(wd), dbias=self.g(blk.down.bias))
+                else:
+                    ops.conv1d_wgrad(xs, gh, 1, x2=x2s, dw=self.g(wd).view(wd.shape[0], -1, 1),
+                                     dbias=self.g(blk.down.bias))
                 if has_adapter:
                     ops.conv1d_wgrad(x, gskip, 1, x2=x2, dw=self.g(blk.skip_adapter.weight),
                                      dbias=self.g(blk.skip_adapter.bias))
                 if not need_dx:
                     return None
                 assert x2 is None, "input gradient through an appended-channel input is not needed on the hot path"
-                w = blk.down.weight
                 if has_adapter:
                     gx = ops.conv1d(gskip, blk.skip_adapter.weight, None, transposed=True)
                 else:
                     gx = gskip
                 if f == 1:
-                    return ops.conv1d(gh, w, None, transposed=True, res=gx)
-                M, R, KT = w.shape
-                return ops.conv1d(gh, w.view(M, R * KT, 1), None, transposed=True, store=1, sp=f, res=gx)
+                    return ops.conv1d(gh, wd, None, transposed=True, res=gx)
+                M, R, KT = wd.shape
+                return ops.conv1d(gh, wd.view(M, R * KT, 1), None, transposed=True, store=1, sp=f, res=gx)
 
             # tape order: [..., bwd_down, items_down..., inner..., items_up..., bwd_up]
             self.tape.insert(tape_mark_down, (bwd_down, d))   # tag d: block d's parameter gradients are complete
             self.tape.append((bwd_up, None))
         return y
-
-    def _up_conv(self, blk, h, f, sc, NT, skip, u):
-        # y = skip + scale[b,c] * (conv_k3(nearest_up_f(h)) + bias); u (optional) keeps the pre-merge value
-        return ops.conv1d(h, blk.up.weight, blk.up.bias, pad=1, up=f, e_scale=sc, e_bstride=NT, res=skip, out_pre=u)
 
 
 class _UNetFn(torch.autograd.Function):
@@ -515,10 +589,13 @@ class _UNetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         run: _Run = ctx.run
+        if run is None:
+            raise RuntimeError("the U-Net tape was released by a previous backward through this forward; "
+                               "run the forward again (retain_graph is not supported by the one-node U-Net)")
         net = run.net
         params = list(net.parameters())
         total = sum(p.numel() for p in params)
-        flat = torch.zeros(total, dtype=torch.float32, device=gy.device)
+        flat = _grad_buffer((total,), gy.device)  # every parameter's slice is overwritten by its gradient kernel
         run.flat = flat
         off = 0
         views = []
@@ -548,7 +625,9 @@ class _UNetFn(torch.autograd.Function):
             hook(flat, None, None)
         gx = g if ctx.needs_input_grad[1] else None
         gfeat = dfeat if (ctx.has_features and ctx.needs_input_grad[3]) else None
-        gemb = run.emb_grad if (ctx.has_embedding and ctx.needs_input_grad[4]) else None
+        gemb = None
+        if ctx.has_embedding and ctx.needs_input_grad[4] and run.emb_grad is not None:
+            gemb = run.emb_grad.transpose(1, 2)  # [B, E, m] -> the embedding's [B, m, E] (a view)
         gctx = tuple(run.ctx_grads) if run.ctx_grads is not None else (None,) * ctx.n_ctx
         # AccumulateGrad adopts an incoming gradient without a copy only when nobody else holds it: drop every
         # reference of ours to the per-parameter views (they stay views of the one flat buffer RCCL reduced)

@@ -4,13 +4,10 @@ Pure host-side glue: kwargs routing for DiffusionModel and small predicates.  Th
 from functools import reduce
 from inspect import isfunction
 from math import ceil, floor, log2, pi
-from typing import Callable, Dict, List, Optional, Sequence, Tuple, TypeVar, Union
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
-import torch.nn.functional as F
 from torch import Generator, Tensor
-
-T = TypeVar("T")
 
 
 def exists(val) -> bool:

@@ -250,6 +250,23 @@ int adp_resample(const float* x, const float* kern, int64_t rows, int64_t length
 /* y = a + b (n elements); used where two gradient streams meet */
 int adp_add(const float* a, const float* b, int64_t n, float* y, void* stream);
 
+/* out = a * x + b * y (y may be NULL: out = a * x).  SkipCat's 2^-1/2 skip branch (a_unet SkipCat, selected by
+ * components.py:99 when use_modulation is False) and the accumulation of the embedding gradient over the
+ * CrossAttentionItems (components.py:93). */
+int adp_axpby(float a, const float* x, float b, const float* y, int64_t n, float* out, void* stream);
+
+/* dst[r*dst_stride + c] = src[r*src_stride + c], r < rows, c < cols: torch.cat / split along channels of [B, C, L]
+ * tensors (AppendChannelsPlugin around a net that is not a UNetV0, components.py:174-176). */
+int adp_copy2d(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int64_t rows, int64_t cols,
+               void* stream);
+
+/* DownsampleItem / UpsampleItem with a factor other than 1, 2, 4 (a_unet accepts any integer factor,
+ * components.py:38; README.md:27) run through two index-only helpers around the 1x1 / k3 convs:
+ *   adp_unshuffle: out[(row*f + k), l] = x[row, l*f + k]        ([rows, L] -> [rows*f, L/f], space-to-depth)
+ *   adp_pool_sum : out[row, l] = sum_{k<f} x[row, l*f + k] (+ res[row, l])   (gradient of the nearest upsample) */
+int adp_unshuffle(const float* x, int64_t rows, int64_t L, int64_t f, float* out, void* stream);
+int adp_pool_sum(const float* x, int64_t rows, int64_t Lout, int64_t f, const float* res, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

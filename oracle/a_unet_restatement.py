@@ -37,6 +37,7 @@ TIME_NUM_LAYERS = 2             # TimeConditioningPlugin(num_layers=2): Linear+G
 TIME_GELU_AFTER_EMBEDDER = True  # time_features = F.gelu(embedder(time)) before the MLP
 ATTN_SEPARATE_CONTEXT_NORM = True  # Attention: norm(x) for q, norm_context(context) for k,v (also in self-attn)
 SKIP_SCALES_BRANCH = True       # MergeModulate: skip + scale(features) * x_branch
+SKIP_CAT_SCALE = 2 ** -0.5      # MergeCat (SkipCat, use_modulation=False): Conv1x1(cat[skip * scale, x_branch])
 GN_EPS = 1e-5
 LN_EPS = 1e-5
 
@@ -163,6 +164,18 @@ class MergeModulate(nn.Module):
         return scale * skip + x
 
 
+class MergeCat(nn.Module):
+    """a_unet SkipCat -> MergeCat (selected at components.py:99 when use_modulation is False):
+    Conv1d(2C -> C, kernel 1)(cat[skip * 2^-1/2, x])."""
+
+    def __init__(self, channels: int):
+        super().__init__()
+        self.conv = nn.Conv1d(2 * channels, channels, 1)
+
+    def forward(self, skip: Tensor, x: Tensor, features=None) -> Tensor:
+        return self.conv(torch.cat([skip * SKIP_CAT_SCALE, x], dim=1))
+
+
 class Upsample(nn.Module):
     """a_unet UpsampleInterpolate: nn.Upsample(scale_factor=f, mode='nearest') then Conv1d(k=3, padding=1)."""
 
@@ -202,7 +215,7 @@ class Block(nn.Module):
         if cfg["use_modulation"]:
             self.skip = MergeModulate(out_channels, cfg["modulation_features"])
         else:
-            raise NotImplementedError("SkipCat (use_modulation=False) is outside the hot-path scope")
+            self.skip = MergeCat(out_channels)
 
     @staticmethod
     def _make(t: str, depth: int, channels: int, context_channels: int, cfg: dict) -> nn.Module:
@@ -255,17 +268,19 @@ class UNetV0Oracle(nn.Module):
         xs = (channels, factors, items, attentions, cross_attentions, context_channels)
         assert all(len(x) == n for x in xs)
         assert not use_embedding_cfg and not use_text_conditioning, "CFG / T5 plugins are out of scope (SURVEY 8a-19)"
-        assert use_time_conditioning and use_modulation, "use_time_conditioning requires use_modulation=True"
+        assert use_modulation or not use_time_conditioning, "use_time_conditioning requires use_modulation=True"
+        self.use_time = use_time_conditioning
         out_channels = out_channels if out_channels is not None else in_channels
         cfg = dict(resnet_groups=resnet_groups, modulation_features=modulation_features,
                    attention_features=attention_features, attention_heads=attention_heads,
                    embedding_features=embedding_features, use_modulation=use_modulation)
         mf = modulation_features
         # TimeConditioningPlugin: NumberEmbedder(features=MF, dim=256) + num_layers x (Linear + GELU)
-        half = TIME_EMBED_DIM // 2
-        self.time_weights = nn.Parameter(torch.randn(half))
-        self.time_linear = nn.Linear(TIME_EMBED_DIM + 1, mf)
-        self.time_mlp = nn.ModuleList([nn.Linear(mf, mf) for _ in range(TIME_NUM_LAYERS)])
+        if use_time_conditioning:
+            half = TIME_EMBED_DIM // 2
+            self.time_weights = nn.Parameter(torch.randn(half))
+            self.time_linear = nn.Linear(TIME_EMBED_DIM + 1, mf)
+            self.time_mlp = nn.ModuleList([nn.Linear(mf, mf) for _ in range(TIME_NUM_LAYERS)])
         blocks = []
         for d in range(n):
             in_ch = in_channels if d == 0 else channels[d - 1]
@@ -299,9 +314,12 @@ class UNetV0Oracle(nn.Module):
 
     def forward(self, x: Tensor, time: Optional[Tensor] = None, *, features: Optional[Tensor] = None,
                 embedding: Optional[Tensor] = None, channels=None) -> Tensor:
-        assert time is not None, "TimeConditioningPlugin requires time in forward"
-        tf = self.time_features(time)
-        features = features + tf if features is not None else tf
+        if self.use_time:
+            assert time is not None, "TimeConditioningPlugin requires time in forward"
+            tf = self.time_features(time)
+            features = features + tf if features is not None else tf
+        else:
+            assert time is None, "the bare XUNet takes x only (keyword conditioning)"
         return self.run_block(0, x, features, embedding, channels)
 
 

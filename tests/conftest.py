@@ -1,6 +1,9 @@
 import os
 import sys
 
+# gradient buffers the kernels must overwrite slice by slice are NaN-filled under test: an unwritten slice fails
+os.environ.setdefault("ADP_DEBUG_POISON", "1")
+
 import pytest
 import torch
 

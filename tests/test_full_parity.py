@@ -128,6 +128,93 @@ def test_config5_upsampler_full(hip):
     assert out.shape == (1, 2, 2 ** 18) and rel_err(out, ref) < 1e-3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["config4", "config5"])
+def test_configs_4_and_5_at_batch_8(hip, which):
+    """BASELINE configs 4 and 5 at their stated batch of 8 on ONE GPU (the 8-GPU runs split this batch): loss and every
+    parameter gradient against the CPU oracle at 1e-3.  Config 4: cross attention over embedding [8, 64, 768];
+    config 5: DiffusionUpsampler(upsample_factor=16) training step on [8, 2, 2**18]."""
+    from oracle.a_unet_restatement import AppendChannelsOracle
+    B = 8
+    sig = [0.05, 0.2, 0.35, 0.5, 0.65, 0.8, 0.95, 0.45]
+    g = torch.Generator().manual_seed(2)
+    x, noise = torch.randn(B, 2, 2 ** 18, generator=g), torch.randn(B, 2, 2 ** 18, generator=g)
+    torch.manual_seed(0)
+    if which == "config4":
+        cfg = dict(FULL, **CROSS_CFG4)
+        oracle = UNetV0Oracle(**cfg)
+        model = adp.DiffusionModel(net_t=adp.UNetV0, diffusion_sigma_distribution=FixedSigmas(sig), **cfg)
+        model.net.load_oracle_state_dict(oracle.state_dict())
+        emb = torch.randn(B, 64, 768, generator=g)
+        loss_ref = ovd.v_loss(oracle, x, noise, torch.tensor(sig), embedding=emb)
+        loss_ref.backward()
+        model = model.to(hip)
+        loss = model(x.to(hip), noise=noise.to(hip), embedding=emb.to(hip))
+        unet, ounet = model.net, oracle
+    else:
+        cfg = dict(FULL)
+        cfg.pop("in_channels")
+        model = adp.DiffusionUpsampler(net_t=adp.UNetV0, in_channels=2, upsample_factor=16,
+                                       diffusion_sigma_distribution=FixedSigmas(sig), **cfg)
+        oracle = AppendChannelsOracle(lambda **kw: UNetV0Oracle(**kw), channels=2)(in_channels=2, **cfg)
+        model.net.net.load_oracle_state_dict(oracle.net.state_dict())
+        re_ref = ovd.upsample(ovd.downsample(x, 16), 16)
+        loss_ref = ovd.v_loss(oracle, x, noise, torch.tensor(sig), append_channels=re_ref)
+        loss_ref.backward()
+        model = model.to(hip)
+        loss = model(x.to(hip), noise=noise.to(hip))
+        unet, ounet = model.net.net, oracle.net
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-3 * abs(loss_ref.item())
+    compare_grads(unet, ounet)
+
+
+@pytest.mark.gpu
+def test_sampler_graph_cache_follows_kwargs(hip):
+    """VSampler's hipGraph cache is keyed on the call STRUCTURE and owns static copies of the tensor kwargs: fresh
+    `embedding` / `append_channels` tensors per call replay the same graph with the new values (never a stale or
+    freed pointer), python scalars are part of the key, and the cache is LRU-bounded."""
+    cfg = dict(in_channels=2, channels=[8, 32, 64], factors=[1, 4, 4], items=[1, 2, 2], modulation_features=64,
+               cross_attentions=[0, 1, 1], attention_heads=2, attention_features=16, embedding_features=24,
+               use_embedding_cfg=True, embedding_max_length=6)
+    torch.manual_seed(0)
+    model = adp.DiffusionModel(net_t=adp.UNetV0, **cfg).to(hip)
+    g = torch.Generator().manual_seed(3)
+    noise = torch.randn(2, 2, 1024, generator=g).to(hip)
+
+    def run(emb, use_graph, **kw):
+        model.sampler.use_graph = use_graph
+        return model.sample(noise, num_steps=3, embedding=emb, **kw)
+
+    outs = []
+    for i in range(3):  # a NEW embedding tensor of the same shape per call (the id()-reuse pattern of ADVICE r1)
+        emb = torch.randn(2, 5, 24, generator=g).to(hip)
+        eager = run(emb, False)
+        graphed = run(emb, True)
+        assert rel_err(graphed, eager) < 1e-5, i
+        outs.append(graphed)
+        del emb
+    assert len(model.sampler._graph_cache) == 1
+    assert rel_err(outs[1], outs[0]) > 1e-3 and rel_err(outs[2], outs[1]) > 1e-3  # the new values were really used
+    emb = torch.randn(2, 5, 24, generator=g).to(hip)
+    for scale in (1.5, 2.0, 2.5, 3.0, 3.5, 4.0):  # a python scalar baked into the capture -> its own entry
+        assert rel_err(run(emb, True, embedding_scale=scale), run(emb, False, embedding_scale=scale)) < 1e-5, scale
+    assert len(model.sampler._graph_cache) <= adp.VSampler.GRAPH_CACHE_ENTRIES
+    # DiffusionUpsampler.sample creates its append_channels tensor inside every call
+    ucfg = dict(channels=[8, 32, 64], factors=[1, 4, 4], items=[1, 2, 2], modulation_features=64)
+    up = adp.DiffusionUpsampler(net_t=adp.UNetV0, in_channels=2, upsample_factor=4, **ucfg).to(hip)
+    for i in range(3):
+        low = torch.randn(1, 2, 256, generator=g).to(hip)
+        gen = torch.Generator().manual_seed(10 + i)
+        up.sampler.use_graph = True
+        a = up.sample(low, num_steps=2, generator=gen)
+        gen = torch.Generator().manual_seed(10 + i)
+        up.sampler.use_graph = False
+        b = up.sample(low, num_steps=2, generator=gen)
+        assert a.shape == (1, 2, 1024) and rel_err(a, b) < 1e-5, i
+    assert len(up.sampler._graph_cache) == 1
+
+
 def up_sample_input(up, low):
     from audio_diffusion_pytorch_amd.utils import upsample
     return upsample(low, factor=up.upsample_factor)

@@ -97,35 +97,49 @@ def test_oracle_matches_live_reference():
     assert torch.equal(ref, ovd.v_inpaint(net, x, mask, 5, 2))
 
 
-def test_oracle_and_product_inpainter_match_golden(emul):
-    """VInpainter: the oracle restatement is bit-equal to the live reference's fixtures; the product (one fused
-    kernel per resample, torch's generator for the draws in the reference's call order) matches within fp32
-    reassociation."""
+def test_oracle_inpainter_matches_golden():
+    """VInpainter: the oracle restatement is bit-equal to the live reference's fixtures."""
     net = StubNet()
     for steps, res in ((4, 3), (6, 1)):
         torch.manual_seed(77)
         assert torch.equal(ovd.v_inpaint(net, GOLD["vi_source"], GOLD["vi_mask"], steps, res), GOLD[f"vi_out_{steps}_{res}"])
+
+
+def test_product_inpainter_matches_golden(dev, monkeypatch):
+    """The product VInpainter (adp_v_inpaint_step: rotation + re-noise + masked blend in one kernel per resample)
+    against the live reference's fixtures (diffusion.py:321-354), on the emulator and -- with -m gpu -- on the HIP
+    kernel.  The reference's draws come from torch's CPU generator; the harness keeps them on the host stream so
+    the device run sees the same noise (the product itself draws on the device)."""
+    host_randn_like = torch.randn_like
+    monkeypatch.setattr(torch, "randn_like", lambda t, **kw: host_randn_like(t.cpu(), **kw).to(t.device))
+    net = StubNet().to(dev)
+    for steps, res in ((4, 3), (6, 1)):
         torch.manual_seed(77)
-        out = adp.VInpainter(net)(GOLD["vi_source"], GOLD["vi_mask"], num_steps=steps, num_resamples=res)
+        out = adp.VInpainter(net)(GOLD["vi_source"].to(dev), GOLD["vi_mask"].to(dev), num_steps=steps,
+                                  num_resamples=res)
+        assert out.device.type == dev.type
         assert rel_err(out, GOLD[f"vi_out_{steps}_{res}"]) < 1e-5
 
 
-def test_product_vdiffusion_and_sampler_match_golden(emul):
-    """The product VDiffusion/VSampler (fused kernels, emulated here) against the reference-generated fixtures."""
-    net = StubNet()
+def test_product_vdiffusion_and_sampler_match_golden(dev):
+    """The product VDiffusion / VSampler (fused kernels) against the reference-generated fixtures
+    (diffusion.py:82-95, :172-190), on the emulator and -- with -m gpu -- on the HIP kernels, eager and through the
+    hipGraph-replayed step."""
+    net = StubNet().to(dev)
 
     class Fixed(adp.Distribution):
         def __call__(self, num_samples, device=torch.device("cpu")):
-            return GOLD["vd_sigmas"][:num_samples]
+            return GOLD["vd_sigmas"][:num_samples].to(device)
 
-    loss = adp.VDiffusion(net, sigma_distribution=Fixed())(GOLD["vd_x"], noise=GOLD["vd_noise"])
+    loss = adp.VDiffusion(net, sigma_distribution=Fixed())(GOLD["vd_x"].to(dev), noise=GOLD["vd_noise"].to(dev))
     assert loss.item() == pytest.approx(GOLD["vd_loss"].item(), rel=1e-5)
-    samp = adp.VSampler(net, use_graph=False)
-    for steps in (1, 5, 50):
-        assert rel_err(samp(GOLD["vs_noise"], num_steps=steps), GOLD[f"vs_out_{steps}"]) < 1e-5
+    for use_graph in ((False, True) if dev.type == "cuda" else (False,)):
+        samp = adp.VSampler(net, use_graph=use_graph)
+        for steps in (1, 5, 50):
+            assert rel_err(samp(GOLD["vs_noise"].to(dev), num_steps=steps), GOLD[f"vs_out_{steps}"]) < 1e-5
     # custom loss_fn keeps working through autograd
     l1 = adp.VDiffusion(net, sigma_distribution=Fixed(), loss_fn=torch.nn.functional.l1_loss)
-    l1(GOLD["vd_x"], noise=GOLD["vd_noise"]).backward()
+    l1(GOLD["vd_x"].to(dev), noise=GOLD["vd_noise"].to(dev)).backward()
     assert net.w.grad is not None
 
 

@@ -12,6 +12,71 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = dict(in_channels=2, channels=[8, 16], factors=[2, 2], items=[1, 1], modulation_features=32)
 
 
+CFG_GUIDED = dict(in_channels=2, channels=[8, 16], factors=[2, 2], items=[1, 1], modulation_features=32,
+                  cross_attentions=[0, 1], attention_heads=2, attention_features=8, embedding_features=12,
+                  use_embedding_cfg=True, embedding_max_length=5)
+
+
+def _worker_cfg(rank, world, port, out_dir):
+    """Same as _worker for UNetV0(use_embedding_cfg=True): the fixed-embedding table lives OUTSIDE the U-Net's flat
+    gradient buffer and must be averaged through the trailing bucket."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import conftest
+    conftest._use_emulator()
+    import audio_diffusion_pytorch_amd as adp
+    from audio_diffusion_pytorch_amd.parallel import DataParallel
+    from test_unet import FixedSigmas
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    sig = [0.2, 0.7, 0.4, 0.9]
+    model = adp.DiffusionModel(net_t=adp.UNetV0, diffusion_sigma_distribution=FixedSigmas(sig[2 * rank:2 * rank + 2]),
+                               **CFG_GUIDED)
+    dp = DataParallel(model, min_bucket_bytes=1024)
+    assert len(dp._extra) == 1  # the fixed embedding table
+    g = torch.Generator().manual_seed(7)
+    x, noise = torch.randn(4, 2, 64, generator=g), torch.randn(4, 2, 64, generator=g)
+    emb = torch.randn(4, 5, 12, generator=g)
+    mask = torch.tensor([True, False, False, True])
+    sl = slice(2 * rank, 2 * rank + 2)
+    loss = dp(x[sl], noise=noise[sl], embedding=emb[sl], embedding_mask_proba=0.5, batch_mask=mask[sl])
+    loss.backward()
+    torch.save({"grads": {n: p.grad.clone() for n, p in model.named_parameters()},
+                "params": {n: p.detach().clone() for n, p in model.named_parameters()}},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp2_gloo_reduces_parameters_outside_the_unet(emul, tmp_path):
+    import audio_diffusion_pytorch_amd as adp
+    from test_unet import FixedSigmas
+    port = 30100 + (os.getpid() % 500)
+    mp.spawn(_worker_cfg, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    assert "net.fixed_embedding.weight" in r0["grads"]
+    for n in r0["grads"]:
+        assert torch.equal(r0["params"][n], r1["params"][n]), n
+        assert torch.equal(r0["grads"][n], r1["grads"][n]), n   # every parameter -- also outside the U-Net -- agrees
+    sig = [0.2, 0.7, 0.4, 0.9]
+    torch.manual_seed(0)
+    model = adp.DiffusionModel(net_t=adp.UNetV0, diffusion_sigma_distribution=FixedSigmas(sig), **CFG_GUIDED)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(r0["params"][n])
+    g = torch.Generator().manual_seed(7)
+    x, noise = torch.randn(4, 2, 64, generator=g), torch.randn(4, 2, 64, generator=g)
+    emb = torch.randn(4, 5, 12, generator=g)
+    mask = torch.tensor([True, False, False, True])
+    model(x, noise=noise, embedding=emb, embedding_mask_proba=0.5, batch_mask=mask).backward()
+    gmax = max(p.grad.abs().max().item() for p in model.parameters())
+    for n, p in model.named_parameters():
+        err = (r0["grads"][n] - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-3 * gmax)
+        assert err < 1e-4, (n, err)
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

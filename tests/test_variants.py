@@ -1,0 +1,250 @@
+"""UNetV0 variants beyond the BASELINE configs, each against the CPU oracle (emulator + `-m gpu` on the HIP kernels):
+arbitrary integer down/upsample factors (components.py:38), SkipCat / use_modulation=False (components.py:99),
+use_time_conditioning=False (components.py:74-76), TextConditioningPlugin with a caller-supplied embedder
+(components.py:70-72), AppendChannelsPlugin around a net that is not a UNetV0 (components.py:162-180); plus the
+C-ABI's error contract (negative return codes) and the host-side failure modes."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn as nn
+
+import audio_diffusion_pytorch_amd as adp
+from audio_diffusion_pytorch_amd import _C, ops
+from audio_diffusion_pytorch_amd._C import ConvDesc, WgradDesc
+from conftest import rel_err
+from oracle.a_unet_restatement import AppendChannelsOracle, UNetV0Oracle
+from test_unet import TOL, build_pair, compare_grads
+
+
+def _fwd_bwd(oracle, net, dev, B, C, L, seed, **kw_pairs):
+    """kw_pairs: name -> CPU tensor fed to both nets (moved to `dev` for the product)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, L, generator=g)
+    kw_ref = {k: v for k, v in kw_pairs.items()}
+    kw = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in kw_pairs.items()}
+    return x, g, kw_ref, kw
+
+
+@pytest.mark.parametrize("factors,L", [([1, 3, 5], 120), ([3, 2, 6], 144), ([8, 1, 3], 96)])
+def test_unet_any_integer_factor(dev, factors, L):
+    """a_unet's Downsample / Upsample take any integer factor; factors outside {1, 2, 4} run through
+    adp_unshuffle + 1x1 conv (down) and the generic upsample loader + adp_pool_sum (up)."""
+    cfg = dict(in_channels=2, channels=[8, 16, 32], factors=factors, items=[1, 1, 1], modulation_features=32)
+    oracle, net = build_pair(cfg, dev)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 2, L, generator=g, requires_grad=True)
+    t = torch.tensor([0.3, 0.8])
+    y_ref = oracle(x, t)
+    xd = x.detach().to(dev).requires_grad_()
+    y = net(xd, t.to(dev))
+    assert y.shape == y_ref.shape and rel_err(y, y_ref) < TOL
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    y.backward(gy.to(dev))
+    compare_grads(net, oracle)
+    assert rel_err(xd.grad, x.grad) < TOL
+
+
+def test_unet_skipcat_without_modulation(dev):
+    """UNetV0(use_modulation=False, use_time_conditioning=False): no ModulationItems, SkipCat merges
+    (Conv1x1(cat[skip * 2^-1/2, x])), forward takes x only."""
+    cfg = dict(in_channels=2, out_channels=3, channels=[8, 16, 32], factors=[1, 2, 4], items=[1, 2, 1],
+               use_modulation=False, use_time_conditioning=False)
+    oracle, net = build_pair(cfg, dev)
+    assert not any("bank" in n for n, _ in net.named_parameters())
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 2, 64, generator=g, requires_grad=True)
+    y_ref = oracle(x)
+    xd = x.detach().to(dev).requires_grad_()
+    y = net(xd)
+    assert rel_err(y, y_ref) < TOL
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    y.backward(gy.to(dev))
+    compare_grads(net, oracle)
+    assert rel_err(xd.grad, x.grad) < TOL
+    with pytest.raises(TypeError):
+        net(xd, torch.tensor([0.5, 0.5]).to(dev))     # the bare XUNet has no positional `time`
+    with pytest.raises(AssertionError):
+        adp.UNetV0(dim=1, in_channels=2, channels=[8], factors=[1], items=[1], use_modulation=False)  # components.py:75
+
+
+def test_unet_features_without_time_conditioning(dev):
+    """use_time_conditioning=False with modulation: the caller supplies `features` (and gets their gradient)."""
+    cfg = dict(in_channels=2, channels=[8, 16], factors=[2, 2], items=[1, 1], modulation_features=24,
+               use_time_conditioning=False)
+    oracle, net = build_pair(cfg, dev)
+    assert not any(n.startswith("time_") for n, _ in net.named_parameters())
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(3, 2, 32, generator=g)
+    f = torch.randn(3, 24, generator=g, requires_grad=True)
+    y_ref = oracle(x, features=f)
+    fd = f.detach().to(dev).requires_grad_()
+    y = net(x.to(dev), features=fd)
+    assert rel_err(y, y_ref) < TOL
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    y.backward(gy.to(dev))
+    compare_grads(net, oracle)
+    assert rel_err(fd.grad, f.grad) < TOL
+    with pytest.raises(AssertionError):
+        net(x.to(dev))  # ModulationItem without features
+
+
+class _ToyTextEmbedder(nn.Module):
+    """Deterministic text -> [B, 3, E] embedder (stands in for T5: List[str] -> token embeddings)."""
+
+    def __init__(self, features: int):
+        super().__init__()
+        self.table = nn.Parameter(torch.linspace(-1, 1, 16 * features).view(16, features), requires_grad=False)
+
+    def forward(self, texts):
+        idx = torch.tensor([[ord(c) % 16 for c in (s + "   ")[:3]] for s in texts], device=self.table.device)
+        return self.table[idx]
+
+
+def test_text_conditioning_with_supplied_embedder(dev):
+    """UNetV0(use_text_conditioning=True, text_embedder=...): `text=` is embedded and prepended to `embedding=`
+    (TextConditioningPlugin, components.py:70-72)."""
+    cfg = dict(in_channels=2, channels=[8, 16], factors=[2, 2], items=[1, 1], modulation_features=32,
+               cross_attentions=[0, 1], attention_heads=2, attention_features=8, embedding_features=12)
+    torch.manual_seed(0)
+    oracle = UNetV0Oracle(**cfg)
+    emb = _ToyTextEmbedder(12)
+    net = adp.UNetV0(dim=1, use_text_conditioning=True, text_embedder=emb, **cfg)
+    assert isinstance(net, adp.components.TextConditioningNet)
+    net.net.load_oracle_state_dict(oracle.state_dict())
+    net = net.to(dev)
+    g = torch.Generator().manual_seed(14)
+    x, t = torch.randn(2, 2, 64, generator=g), torch.tensor([0.2, 0.6])
+    texts = ["abc", "xyz"]
+    extra = torch.randn(2, 2, 12, generator=g)
+    y_ref = oracle(x, t, embedding=torch.cat([emb(texts).cpu(), extra], dim=1))
+    y = net(x.to(dev), t.to(dev), text=texts, embedding=extra.to(dev))
+    assert rel_err(y, y_ref) < TOL
+    y_ref.sum().backward()
+    y.sum().backward()
+    compare_grads(net.net, oracle)
+    with pytest.raises(NotImplementedError):  # the default embedder is t5-base, whose weights are not on this box
+        adp.UNetV0(dim=1, use_text_conditioning=True, **cfg)
+
+
+def test_append_channels_around_any_net(dev):
+    """AppendChannelsPlugin(net_t) with a net_t that is not UNetV0: the plugin concatenates with adp_copy2d and the
+    wrapped net sees [B, C + channels, L] (components.py:174-176); gradients flow to both inputs."""
+
+    def toy_net_t(in_channels, out_channels, **kw):
+        torch.manual_seed(3)
+        return nn.Conv1d(in_channels, out_channels, 3, padding=1)
+
+    class _Wrap(nn.Module):  # net(x, time) signature
+        def __init__(self, conv):
+            super().__init__()
+            self.conv = conv
+
+        def forward(self, x, time=None, **kw):
+            return self.conv(x) * (1 + time.view(-1, 1, 1))
+
+    plug = adp.AppendChannelsPlugin(lambda **kw: _Wrap(toy_net_t(**kw)), channels=3)
+    net = plug(in_channels=2).to(dev)
+    assert not net.two_pointer and net.net.conv.in_channels == 5 and net.net.conv.out_channels == 2
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(2, 2, 40, generator=g, requires_grad=True)
+    a = torch.randn(2, 3, 40, generator=g, requires_grad=True)
+    t = torch.tensor([0.1, 0.7])
+    ref_conv = toy_net_t(5, 2)
+    y_ref = ref_conv(torch.cat([x, a], dim=1)) * (1 + t.view(-1, 1, 1))
+    xd, ad = x.detach().to(dev).requires_grad_(), a.detach().to(dev).requires_grad_()
+    y = net(xd, t.to(dev), append_channels=ad)
+    assert rel_err(y, y_ref) < 1e-5
+    y_ref.square().sum().backward()
+    y.square().sum().backward()
+    assert rel_err(xd.grad, x.grad) < 1e-5 and rel_err(ad.grad, a.grad) < 1e-5
+    # and the UNetV0 case keeps the two-pointer path
+    up = adp.AppendChannelsPlugin(adp.UNetV0, channels=2)(dim=1, in_channels=2, channels=[8], factors=[1], items=[1],
+                                                          modulation_features=16)
+    assert up.two_pointer
+
+
+def test_second_backward_raises_clearly(dev):
+    cfg = dict(in_channels=2, channels=[8, 16], factors=[2, 2], items=[1, 1], modulation_features=16)
+    _, net = build_pair(cfg, dev)
+    y = net(torch.randn(1, 2, 32).to(dev), torch.tensor([0.5]).to(dev))
+    y.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="tape was released"):
+        y.sum().backward()
+
+
+# ------------------------------------------------------------------ C-ABI error contract (include/adp.h)
+def _conv_desc(dev, B=1, R=8, M=8, L=64, KT=3, **over):
+    x = torch.randn(2, 64, 64).to(dev)      # generous fixed buffers: only the descriptor fields vary
+    w = torch.randn(64, 64, 5).to(dev)
+    out = torch.empty(2, 64, 64).to(dev)
+    f = dict(x=x.data_ptr(), x2=None, w=w.data_ptr(), bias=None, pro_stats=None, pro_gamma=None, pro_beta=None,
+             e_scale=None, res=None, out=out.data_ptr(), out_pre=None, B=B, R=R, R1=R, Lin=L, M=M, N=L, KT=KT, stride=1,
+             dil=1, pad=1, up=1, transposed=0, prologue=0, groups=1, store=0, sp=1, e_bstride=0)
+    f.update(over)
+    d = ConvDesc(*[f[n] for n, _ in ConvDesc._fields_])
+    d._keep = (x, w, out)
+    return d
+
+
+def test_c_abi_returns_error_codes(dev):
+    """Bad arguments come back as negative ADP_ERR_* codes (no exception crosses the C boundary, nothing is
+    launched); the Python layer turns them into RuntimeError."""
+    lib = _C.lib()
+    s = _C.stream()
+    ERR_SHAPE, ERR_UNSUPPORTED, ERR_NULL = -1, -2, -5
+    assert lib.adp_conv1d(None, s) == ERR_NULL
+    assert lib.adp_conv1d(ctypes.byref(_conv_desc(dev, out=None)), s) == ERR_NULL
+    assert lib.adp_conv1d(ctypes.byref(_conv_desc(dev, B=0)), s) == ERR_SHAPE
+    assert lib.adp_conv1d(ctypes.byref(_conv_desc(dev, R1=4)), s) == ERR_NULL          # concat without x2
+    assert lib.adp_conv1d(ctypes.byref(_conv_desc(dev, KT=5)), s) == ERR_UNSUPPORTED   # kernel 5 has no variant
+    assert lib.adp_conv1d(ctypes.byref(_conv_desc(dev, dil=9)), s) == ERR_UNSUPPORTED
+    assert lib.adp_conv1d(ctypes.byref(_conv_desc(dev, prologue=1)), s) == ERR_NULL    # prologue without statistics
+    st = torch.zeros(1, 3, 2).to(dev)
+    assert lib.adp_conv1d(ctypes.byref(_conv_desc(dev, prologue=1, pro_stats=st.data_ptr(), groups=3)), s) == ERR_SHAPE
+    assert lib.adp_conv1d(ctypes.byref(_conv_desc(dev, store=2, sp=3)), s) == ERR_UNSUPPORTED
+    x = torch.randn(2, 8, 32).to(dev)
+    stats = torch.empty(2, 4, 2).to(dev)
+    ws = torch.empty(1 << 14).to(dev)
+    assert lib.adp_gn_stats(None, 2, 8, 32, 4, 1e-5, stats.data_ptr(), ws.data_ptr(), s) == ERR_NULL
+    assert lib.adp_gn_stats(x.data_ptr(), 2, 8, 32, 3, 1e-5, stats.data_ptr(), ws.data_ptr(), s) == ERR_SHAPE
+    assert lib.adp_v_step(x.data_ptr(), x.data_ptr(), None, x.numel(), x.data_ptr(), s) == ERR_NULL
+    assert lib.adp_v_step(x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, x.data_ptr(), s) == ERR_SHAPE
+    assert lib.adp_unshuffle(x.data_ptr(), 16, 32, 5, x.data_ptr(), s) == ERR_SHAPE    # 32 % 5 != 0
+    assert lib.adp_copy2d(x.data_ptr(), 4, x.data_ptr(), 8, 2, 8, s) == ERR_SHAPE       # row stride < row length
+    wd = WgradDesc()
+    assert lib.adp_conv1d_wgrad(ctypes.byref(wd), s) == ERR_NULL
+    assert lib.adp_conv1d_wgrad_ws_bytes(None) == ERR_UNSUPPORTED
+    # the host layer raises on a non-zero code, naming the call
+    with pytest.raises(RuntimeError, match="adp_conv1d failed: unsupported"):
+        ops.conv1d(x, torch.randn(8, 8, 3).to(dev), None, dil=9)
+    with pytest.raises(TypeError):
+        ops.add(x.double(), x.double())
+    with pytest.raises(ValueError):
+        ops.add(x.transpose(1, 2), x.transpose(1, 2))
+
+
+def test_kernels_reject_host_tensors_without_the_emulator():
+    """The product path has no CPU fallback: outside the test-only emulator hook a CPU tensor is refused."""
+    _C._testing_use_library(None, allow_cpu=False)
+    with pytest.raises(RuntimeError, match="HIP"):
+        _C.ptr(torch.zeros(4))
+
+
+@pytest.mark.parametrize("f", [3, 5])
+def test_unshuffle_and_pool_sum(dev, f):
+    g = torch.Generator().manual_seed(f)
+    x = torch.randn(2, 3, 8 * f, generator=g)
+    ref = x.view(2, 3, 8, f).permute(0, 1, 3, 2).reshape(2, 3 * f, 8)
+    assert torch.equal(ops.unshuffle(x.to(dev), f).cpu(), ref)
+    res = torch.randn(2, 3, 8, generator=g)
+    assert rel_err(ops.pool_sum(x.to(dev), f, res.to(dev)), x.view(2, 3, 8, f).sum(-1) + res) < 1e-6
+    a, b = torch.randn(2, 3, 10, generator=g), torch.randn(2, 4, 10, generator=g)
+    cat = ops.concat_channels(a.to(dev), b.to(dev))
+    assert torch.equal(cat.cpu(), torch.cat([a, b], 1))
+    sa, sb = ops.split_channels(cat, 3)
+    assert torch.equal(sa.cpu(), a) and torch.equal(sb.cpu(), b)
+    assert rel_err(ops.axpby(0.5, a.to(dev), -2.0, a.to(dev)), -1.5 * a) < 1e-6
