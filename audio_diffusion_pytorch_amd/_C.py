@@ -29,7 +29,8 @@ class ConvDesc(Structure):
     _fields_ = [(n, c_void_p) for n in ("x", "x2", "w", "bias", "pro_stats", "pro_gamma", "pro_beta", "e_scale",
                                         "res", "out", "out_pre")] + \
                [(n, c_int64) for n in ("B", "R", "R1", "Lin", "M", "N", "KT", "stride", "dil", "pad", "up",
-                                       "transposed", "prologue", "groups", "store", "sp", "e_bstride")]
+                                       "transposed", "prologue", "groups", "store", "sp", "e_bstride")] + \
+               [("ws", c_void_p)]
 
 
 class WgradDesc(Structure):
@@ -43,6 +44,7 @@ SIGNATURES = {
     "adp_version": (c_int, []),
     "adp_launch_trace": (I, [I, ctypes.c_char_p, I]),
     "adp_launch_times": (I, [P, I]),
+    "adp_conv1d_ws_bytes": (I, [POINTER(ConvDesc)]),
     "adp_conv1d": (c_int, [POINTER(ConvDesc), P]),
     "adp_conv1d_tile": (I, [POINTER(ConvDesc)]),
     "adp_conv1d_wgrad_ws_bytes": (I, [POINTER(WgradDesc)]),
@@ -58,6 +60,7 @@ SIGNATURES = {
     "adp_chan_ln_bwd_ws_bytes": (I, [I, I, I]),
     "adp_modulation_bwd": (c_int, [P, P, P, I, P, I, I, I, P, P, I, P, P]),
     "adp_ln_stats": (c_int, [P, I, I, I, F, P, P]),
+    "adp_ln_affine_fwd": (c_int, [P, I, I, I, F, P, P, P, P, P, P, P, P]),
     "adp_ln_bwd": (c_int, [P, P, P, P, P, I, I, I, I, P, P, P, P]),
     "adp_linear_fwd": (c_int, [P, P, P, I, I, I, I, I, P, I, P]),
     "adp_linear_bwd_data_ws_bytes": (I, [I, I, I]),

@@ -6,8 +6,8 @@ row a15, oracle/a_unet_restatement.py:Attention):
     ctx = x (self attention, separate LayerNorm parameters) or the embedding [B,m,E] (cross attention).
 
 MI355X structure: activations never leave the channel-major [B,C,n] layout (the reference packs to [B,n,C] and
-back).  A Linear over channels is a 1x1 conv on the MFMA conv kernel whose loader applies the LayerNorm from
-per-position statistics; the attention core is the flash-style kernel in csrc/attention.hip, which consumes the
+back).  The LayerNorms are one channel-axis kernel (both normalisations of a self-attention item in one pass), a
+Linear over channels is a 1x1 conv on the MFMA conv kernel; the attention core is the flash-style kernel in csrc/attention.hip, which consumes the
 projections exactly as the convs produce them (k and v are the two channel halves of one to_kv output) and
 never materialises the [n, m] score matrix; the residual add is the out-projection's epilogue.
 """
@@ -25,19 +25,22 @@ def attention_item(run, p, x: Tensor, context: Optional[Tensor]) -> Tensor:
     mid = H * D
     B, C, n = x.shape
     is_cross = context is not None
-    st_x = ops.ln_stats(x)
     wq = p.to_q.weight.view(mid, C, 1)
-    q = ops.conv1d(x, wq, None, prologue=2, pro_stats=st_x, pro_gamma=p.norm.weight, pro_beta=p.norm.bias)
     if is_cross:
         assert context.shape[0] == B, "embedding batch mismatch"
         ctx = context.transpose(1, 2).contiguous()  # [B, E, m] channel-major (layout change only)
-        st_c = ops.ln_stats(ctx)
-    else:
-        ctx, st_c = x, st_x
+        xn, _, st_x = ops.ln_affine_fwd(x, p.norm.weight, p.norm.bias)
+        cn, _, st_c = ops.ln_affine_fwd(ctx, p.norm_context.weight, p.norm_context.bias)
+    else:  # self attention: one pass over x yields both normalisations (same statistics, two affine maps)
+        ctx = x
+        xn, cn, st_x = ops.ln_affine_fwd(x, p.norm.weight, p.norm.bias, p.norm_context.weight, p.norm_context.bias)
+        st_c = st_x
     Cc = ctx.shape[1]
     wkv = p.to_kv.weight.view(2 * mid, Cc, 1)
-    kv = ops.conv1d(ctx, wkv, None, prologue=2, pro_stats=st_c, pro_gamma=p.norm_context.weight,
-                    pro_beta=p.norm_context.bias)
+    # the normalised tensors are materialised once (2-4 MB) so that the projections are plain MFMA 1x1 convs; the
+    # LayerNorm-in-the-loader variant ran on the generic conv kernel at 1-4 TF (round-1 profile)
+    q = ops.conv1d(xn, wq, None)
+    kv = ops.conv1d(cn, wkv, None)
     o, lse = ops.attn_fwd(q, kv, H, D)
     wo = p.to_out.weight.view(C, mid, 1)
     y = ops.conv1d(o, wo, None, res=x)
@@ -48,15 +51,12 @@ def attention_item(run, p, x: Tensor, context: Optional[Tensor]) -> Tensor:
             do = ops.conv1d(gy, wo, None, transposed=True)
             dq, dkv = ops.attn_bwd(q, kv, o, do, lse, H, D)
             # q path: weight gradient with the LayerNorm applied in the loader, then LayerNorm backward (+ residual)
-            ops.conv1d_wgrad(x, dq, 1, prologue=2, pro_stats=st_x, pro_gamma=p.norm.weight, pro_beta=p.norm.bias,
-                             dw=run.g(p.to_q.weight).view(mid, C, 1), want_bias=False)
+            ops.conv1d_wgrad(xn, dq, 1, dw=run.g(p.to_q.weight).view(mid, C, 1), want_bias=False)
             dxn = ops.conv1d(dq, wq, None, transposed=True)
             # [dgamma | dbeta] land directly in the flat gradient buffer (weight and bias are adjacent parameters)
             dx, _ = ops.ln_bwd(x, dxn, st_x, p.norm.weight, dres=gy, dgb=run.gspan(p.norm.weight, 2 * C))
             # k/v path
-            ops.conv1d_wgrad(ctx, dkv, 1, prologue=2, pro_stats=st_c, pro_gamma=p.norm_context.weight,
-                             pro_beta=p.norm_context.bias, dw=run.g(p.to_kv.weight).view(2 * mid, Cc, 1),
-                             want_bias=False)
+            ops.conv1d_wgrad(cn, dkv, 1, dw=run.g(p.to_kv.weight).view(2 * mid, Cc, 1), want_bias=False)
             dcn = ops.conv1d(dkv, wkv, None, transposed=True)
             gbc = run.gspan(p.norm_context.weight, 2 * Cc)
             if is_cross:

@@ -9,48 +9,110 @@
 // probability tile already sits in the B-operand layout of the P*V product -- no LDS round trip, the [n, m]
 // score matrix is never materialised (the reference writes B*H*n*m floats: 33.5 MB per item at n = 1024).
 //
-// One workgroup = 4 waves = 4 x 32 queries of one (batch, head); K/V tiles of 32 keys are staged in LDS once
-// per workgroup and shared by the 4 waves.  D (head features) <= 64, multiple of 2.
+// Structure (round 2): every WAVE is independent -- it owns 32 queries (forward, dq pass) or 32 keys (dk/dv pass)
+// and reads its MFMA operands STRAIGHT from global memory in the two fragment shapes the matrix cores want:
+//   "column" fragments  x[d = 2s + hi][p0 + l31]        32 coalesced 128-byte half-wave rows per 32-position tile
+//   "row"    fragments  x[d = 32t + l31][p0 + 8k + 4hi .. +3]   four 16-byte pieces per lane, whole 128-B lines used
+// K/V (or Q/dO) of one head are 128-512 KB and are re-read by every wave of that head out of L2 -- staging them in
+// LDS bought nothing but two workgroup barriers per 32-key tile with all global latency exposed (round 1: 8 TF at
+// n = 1024).  Without LDS and barriers the waves free-run, several per SIMD, and hide each other's L2 latency.
+// The dk/dv pass splits the QUERY range over several waves when there are few key tiles (cross attention: m = 64
+// keys x n = 4096 queries) and sums the partial tiles in a second, deterministic stage.  D <= 64, multiple of 2.
 #include "adp_rt.h"
 #include "adp.h"
 
 namespace {
 
 constexpr int DMAX = 64;
-constexpr int KP = 33;  // LDS row stride of a [D][32] tile (+1: column reads down D are conflict-free)
 
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-// stage a [D][32] tile of channel-major src (row stride ld) starting at column c0 into dst[D][KP]; zero past cmax
-__device__ __forceinline__ void stage_tile(const float* src, int64_t ld, int64_t c0, int64_t cmax, int D, float* dst) {
-  for (int e = threadIdx.x; e < D * 32; e += 256) {
-    const int dd = e >> 5, c = e & 31;
-    dst[dd * KP + c] = (c0 + c < cmax) ? src[dd * ld + c0 + c] : 0.0f;
+// Addressing: every tensor of one (batch, head) is a [D, len] slab (len = n or m) behind a wave-uniform base pointer;
+// lanes use 32-bit element offsets into it (the host checks D * len < 2^31).  Out-of-range positions / channels are
+// read at a CLAMPED in-range address and replaced by zero with a select -- no divergent branches in the loops.
+
+// "column" fragment element x[d][p]: col = hi * len + min(p, len - 1) precomputed per tile, pok = p < len
+template <bool D64>
+__device__ __forceinline__ float ld_col(const float* x, int len, int s, int hi, int D, int col, bool pok) {
+  if (D64) return pok ? x[2 * s * len + col] : 0.0f;
+  const int d = 2 * s + hi;
+  const float v = x[(d < D ? 2 * s : 0) * len + col];
+  return (pok && d < D) ? v : 0.0f;
+}
+
+// "row" fragment of one lane: the 16 values x[d][p0 + acc_row(s, hi)], s = 0..15, as four 4-float pieces (piece k =
+// positions p0 + 8k + 4hi .. +3).  `full`: the whole 32-position tile is in range and rows are 16-byte tileable.
+template <bool D64>
+__device__ __forceinline__ void ld_row16(const float* x, int len, int d, int D, int p0, int hi, bool full,
+                                         float (&out)[16]) {
+  const bool dok = D64 || d < D;
+  const float* row = x + (dok ? d : 0) * len;
+  if (full) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(row + p0 + 8 * k + 4 * hi);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[4 * k + e] = dok ? v[e] : 0.0f;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int p = p0 + 8 * k + 4 * hi + e;
+        const float v = row[p < len ? p : len - 1];
+        out[4 * k + e] = (dok && p < len) ? v : 0.0f;
+      }
   }
 }
 
+// the 16 per-position scalars a lane needs for its accumulator rows: x[p0 + acc_row(r, hi)], r = 0..15
+__device__ __forceinline__ void ld_vec16(const float* x, int p0, int hi, int len, bool full, float (&out)[16]) {
+  if (full) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + p0 + 8 * k + 4 * hi);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[4 * k + e] = v[e];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = p0 + acc_row(r, hi);
+      const float v = x[p < len ? p : len - 1];
+      out[r] = p < len ? v : 0.0f;
+    }
+  }
+}
+
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 // ---------------------------------------------------------------------------------------------------
 // forward: o[d, i] = sum_j softmax_j(q_i . k_j * scale) v[d, j];  lse[i] = log sum_j exp(s_ij)
+// one wave = 32 queries of one (batch, head); 4 independent waves per workgroup
 // ---------------------------------------------------------------------------------------------------
+template <bool D64>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* q, const float* k, const float* v, int H, int D,
-                                                       int64_t n, int64_t m, int64_t qbs, int64_t kvbs, float scale,
+                                                       int n, int m, int64_t qbs, int64_t kvbs, float scale,
                                                        float* o, float* lse) {
-  __shared__ float Ks[DMAX * KP];
-  __shared__ float Vs[DMAX * KP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int64_t b = blockIdx.z, h = blockIdx.y;
-  const int64_t i0 = (int64_t)blockIdx.x * 128 + wave * 32;
-  const float* qh = q + b * qbs + h * D * n;
-  const float* kh = k + b * kvbs + h * D * m;
-  const float* vh = v + b * kvbs + h * D * m;
-  const int64_t iq = i0 + l31;
+  const int i0 = blockIdx.x * 128 + wave * 32;
+  if (i0 >= n) return;  // no workgroup-wide synchronisation anywhere below
+  const float* qh = q + b * qbs + h * (int64_t)D * n;
+  const float* kh = k + b * kvbs + h * (int64_t)D * m;
+  const float* vh = v + b * kvbs + h * (int64_t)D * m;
+  const int iq = i0 + l31;
   const bool qok = iq < n;
+  const bool vec = ((m & 3) == 0) && aligned16(vh);
 
-  // Q fragments for this wave's 32 queries: B operand of S^T = K^T Q, lane (i = l31, kk = hi) -> q[d][i]
+  // Q fragments for this wave's 32 queries: B operand of S^T = K^T Q, lane (i = l31, kk = hi) -> q[d][i] * scale
   float qf[DMAX / 2];
+  {
+    const int qcol = hi * n + (qok ? iq : n - 1);
 #pragma unroll
-  for (int s = 0; s < DMAX / 2; ++s) qf[s] = (qok && 2 * s + hi < D) ? qh[(2 * s + hi) * n + iq] * scale : 0.0f;
-
+    for (int s = 0; s < DMAX / 2; ++s) qf[s] = (D64 || 2 * s < D) ? ld_col<D64>(qh, n, s, hi, D, qcol, qok) * scale : 0.0f;
+  }
   f32x16 oacc[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -58,23 +120,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* q, const flo
     for (int r = 0; r < 16; ++r) oacc[t][r] = 0.0f;
   float mrun = -3.0e38f, lrun = 0.0f;
 
-  for (int64_t j0 = 0; j0 < m; j0 += 32) {
-    __syncthreads();
-    stage_tile(kh, m, j0, m, D, Ks);
-    stage_tile(vh, m, j0, m, D, Vs);
-    __syncthreads();
+  for (int j0 = 0; j0 < m; j0 += 32) {
+    const bool full = j0 + 32 <= m;
+    const bool kok = j0 + l31 < m;
+    const int kcol = hi * m + (kok ? j0 + l31 : m - 1);
     // S^T tile: rows j (regs), cols i (lanes): A[i'=j][kk=d] = k[d][j], B[kk=d][j'=i] = q[d][i]
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.0f;
 #pragma unroll
     for (int s = 0; s < DMAX / 2; ++s)
-      if (2 * s < D) st = adp_mfma32(Ks[(2 * s + hi) * KP + l31], qf[s], st);
+      if (D64 || 2 * s < D) st = adp_mfma32(ld_col<D64>(kh, m, s, hi, D, kcol, kok), qf[s], st);
+    // V row fragments are requested before the softmax arithmetic that separates the two MFMA groups
+    float vr[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (D64 || 32 * t < D) ld_row16<D64>(vh, m, 32 * t + l31, D, j0, hi, full && vec, vr[t]);
     // online softmax over j: 16 in-register rows + the other half-wave
     float tmax = -3.0e38f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      if (j0 + acc_row(r, hi) >= m) st[r] = -3.0e38f;
+      if (!full && j0 + acc_row(r, hi) >= m) st[r] = -3.0e38f;
       tmax = fmaxf(tmax, st[r]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -83,7 +149,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* q, const flo
     float psum = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = (j0 + acc_row(r, hi) < m) ? __expf(st[r] - mnew) : 0.0f;
+      const float p = (full || j0 + acc_row(r, hi) < m) ? __expf(st[r] - mnew) : 0.0f;
       st[r] = p;
       psum += p;
     }
@@ -93,16 +159,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* q, const flo
     // O^T[d][i] = alpha * O^T + sum_j v[d][j] P^T[j][i]: A[i'=d][kk=j] = v[d][j(s,hi)], B = own register s
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      if (32 * t < D) {
+      if (D64 || 32 * t < D) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) oacc[t] = adp_mfma32(Vs[(32 * t + l31) * KP + acc_row(s, hi)], st[s], oacc[t]);
+        for (int s = 0; s < 16; ++s) oacc[t] = adp_mfma32(vr[t][s], st[s], oacc[t]);
       }
     }
   }
   const float inv = (lrun > 0.0f) ? 1.0f / lrun : 0.0f;
-  float* oh = o + b * (int64_t)H * D * n + h * D * n;
+  float* oh = o + (b * H + h) * (int64_t)D * n;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -110,7 +176,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* q, const flo
       const int dd = 32 * t + acc_row(r, hi);
       if (dd < D && qok) oh[dd * n + iq] = oacc[t][r] * inv;
     }
-  if (hi == 0 && qok) lse[(b * H + h) * n + iq] = mrun + logf(lrun);
+  if (hi == 0 && qok) lse[(b * H + h) * (int64_t)n + iq] = mrun + logf(lrun);
 }
 
 // delta[b,h,i] = sum_d dO[d,i] * O[d,i]
@@ -127,33 +193,43 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* o, const f
 }
 
 // ---------------------------------------------------------------------------------------------------
-// backward, key-major pass: one wave owns 32 keys and loops over query tiles:
+// backward, key-major pass: one wave owns 32 keys and a slice of the query tiles:
 //   S[i][j] (rows i in regs, cols j across lanes), P = exp(S - lse_i), dP = dO^T V, dS = P (dP - delta_i) scale
 //   dv[d][j] += sum_i dO[d][i] P[i][j] ; dk[d][j] += sum_i q[d][i] dS[i][j]
+// grid.x = ceil(key tiles x nsplit / 4); split sp covers query tiles [sp * tps, (sp + 1) * tps).  With nsplit > 1 the
+// partial [D, 32] tiles go to part[sp] (addressed like dk / dv) and attn_kv_reduce_kernel sums them in split order.
 // ---------------------------------------------------------------------------------------------------
+template <bool D64>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* q, const float* k, const float* v,
                                                           const float* dout, const float* lse, const float* delta,
-                                                          int H, int D, int64_t n, int64_t m, int64_t qbs,
-                                                          int64_t kvbs, float scale, float* dk, float* dv) {
-  __shared__ float Qs[DMAX * KP];
-  __shared__ float Ds[DMAX * KP];
-  __shared__ float Ls[32], Dl[32];
+                                                          int H, int D, int n, int m, int64_t qbs, int64_t kvbs,
+                                                          float scale, int nsplit, int tps, int64_t pstride,
+                                                          float* dk, float* dv) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int64_t b = blockIdx.z, h = blockIdx.y;
-  const int64_t j0 = (int64_t)blockIdx.x * 128 + wave * 32;
-  const float* qh = q + b * qbs + h * D * n;
-  const float* kh = k + b * kvbs + h * D * m;
-  const float* vh = v + b * kvbs + h * D * m;
+  const int ktiles = (m + 31) / 32;
+  const int wid = blockIdx.x * 4 + wave;  // wave id within (b, h): key tile fastest
+  const int kt = wid % ktiles, sp = wid / ktiles;
+  if (sp >= nsplit) return;
+  const int j0 = kt * 32;
+  const float* qh = q + b * qbs + h * (int64_t)D * n;
+  const float* kh = k + b * kvbs + h * (int64_t)D * m;
+  const float* vh = v + b * kvbs + h * (int64_t)D * m;
   const float* doh = dout + (b * H + h) * (int64_t)D * n;
-  const int64_t jk = j0 + l31;
+  const float* lh = lse + (b * H + h) * (int64_t)n;
+  const float* dlh = delta + (b * H + h) * (int64_t)n;
+  const int jk = j0 + l31;
   const bool kok = jk < m;
+  const bool vec = ((n & 3) == 0) && aligned16(qh) && aligned16(doh) && aligned16(lh) && aligned16(dlh);
   // K and V fragments of this wave's 32 keys: B operands (lane (j = l31, kk = hi) -> x[d][j])
   float kf[DMAX / 2], vf[DMAX / 2];
+  {
+    const int kcol = hi * m + (kok ? jk : m - 1);
 #pragma unroll
-  for (int s = 0; s < DMAX / 2; ++s) {
-    const bool ok = kok && (2 * s + hi < D);
-    kf[s] = ok ? kh[(2 * s + hi) * m + jk] : 0.0f;
-    vf[s] = ok ? vh[(2 * s + hi) * m + jk] : 0.0f;
+    for (int s = 0; s < DMAX / 2; ++s) {
+      kf[s] = (D64 || 2 * s < D) ? ld_col<D64>(kh, m, s, hi, D, kcol, kok) : 0.0f;
+      vf[s] = (D64 || 2 * s < D) ? ld_col<D64>(vh, m, s, hi, D, kcol, kok) : 0.0f;
+    }
   }
   f32x16 dka[2], dva[2];
 #pragma unroll
@@ -161,48 +237,48 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* q, const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) dka[t][r] = dva[t][r] = 0.0f;
 
-  for (int64_t i0 = 0; i0 < n; i0 += 32) {
-    __syncthreads();
-    stage_tile(qh, n, i0, n, D, Qs);
-    stage_tile(doh, n, i0, n, D, Ds);
-    if (threadIdx.x < 32) {
-      const int64_t i = i0 + threadIdx.x;
-      Ls[threadIdx.x] = (i < n) ? lse[(b * H + h) * n + i] : 0.0f;
-      Dl[threadIdx.x] = (i < n) ? delta[(b * H + h) * n + i] : 0.0f;
-    }
-    __syncthreads();
-    // S tile: A[i'=i][kk=d] = q[d][i] (unit stride in LDS row), B = kf
+  const int i_beg = sp * tps * 32;
+  const int i_end = (i_beg + tps * 32 < n) ? i_beg + tps * 32 : n;
+  for (int i0 = i_beg; i0 < i_end; i0 += 32) {
+    const bool full = i0 + 32 <= n;
+    const bool iok = i0 + l31 < n;
+    const int qcol = hi * n + (iok ? i0 + l31 : n - 1);
+    // S tile: A[i'=i][kk=d] = q[d][i], B = kf ; dP tile: A = dO[d][i], B = vf
     f32x16 sa, dpa;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sa[r] = dpa[r] = 0.0f;
 #pragma unroll
     for (int s = 0; s < DMAX / 2; ++s)
-      if (2 * s < D) {
-        sa = adp_mfma32(Qs[(2 * s + hi) * KP + l31], kf[s], sa);
-        dpa = adp_mfma32(Ds[(2 * s + hi) * KP + l31], vf[s], dpa);
+      if (D64 || 2 * s < D) {
+        sa = adp_mfma32(ld_col<D64>(qh, n, s, hi, D, qcol, iok), kf[s], sa);
+        dpa = adp_mfma32(ld_col<D64>(doh, n, s, hi, D, qcol, iok), vf[s], dpa);
       }
+    float ls[16], dl[16];
+    ld_vec16(lh, i0, hi, n, full && vec, ls);
+    ld_vec16(dlh, i0, hi, n, full && vec, dl);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int il = acc_row(r, hi);
-      const bool ok = (i0 + il < n) && kok;
-      const float p = ok ? __expf(sa[r] * scale - Ls[il]) : 0.0f;
-      sa[r] = p;                                   // P[i][j]
-      dpa[r] = p * (dpa[r] - Dl[il]) * scale;      // dS[i][j]
+      const bool ok = (full || i0 + acc_row(r, hi) < n) && kok;
+      const float p = ok ? __expf(sa[r] * scale - ls[r]) : 0.0f;
+      sa[r] = p;                                  // P[i][j]
+      dpa[r] = p * (dpa[r] - dl[r]) * scale;      // dS[i][j]
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      if (32 * t < D) {
+      if (D64 || 32 * t < D) {
+        float dor[16], qr[16];
+        ld_row16<D64>(doh, n, 32 * t + l31, D, i0, hi, full && vec, dor);
+        ld_row16<D64>(qh, n, 32 * t + l31, D, i0, hi, full && vec, qr);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-          const int il = acc_row(s, hi);
-          dva[t] = adp_mfma32(Ds[(32 * t + l31) * KP + il], sa[s], dva[t]);
-          dka[t] = adp_mfma32(Qs[(32 * t + l31) * KP + il], dpa[s], dka[t]);
+          dva[t] = adp_mfma32(dor[s], sa[s], dva[t]);
+          dka[t] = adp_mfma32(qr[s], dpa[s], dka[t]);
         }
       }
     }
   }
-  float* dkh = dk + b * kvbs + h * D * m;
-  float* dvh = dv + b * kvbs + h * D * m;
+  float* dkh = (nsplit > 1 ? dk + sp * pstride : dk) + b * kvbs + h * (int64_t)D * m;
+  float* dvh = (nsplit > 1 ? dv + sp * pstride : dv) + b * kvbs + h * (int64_t)D * m;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -215,70 +291,90 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* q, const 
     }
 }
 
+// dk / dv [b][e] = sum_{sp < nsplit} part_{k,v}[sp * pstride + b * kvbs + e], e < cnt   (fixed order: deterministic);
+// blockIdx.y = 2 * b + (0: k, 1: v)
+__global__ __launch_bounds__(256) void attn_kv_reduce_kernel(const float* pk, const float* pv, int nsplit,
+                                                             int64_t pstride, int64_t kvbs, int64_t cnt, float* dk,
+                                                             float* dv) {
+  const int64_t b = blockIdx.y >> 1;
+  const float* part = ((blockIdx.y & 1) ? pv : pk) + b * kvbs;
+  float* out = ((blockIdx.y & 1) ? dv : dk) + b * kvbs;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < cnt; e += (int64_t)gridDim.x * 256) {
+    float s = 0.0f;
+    for (int sp = 0; sp < nsplit; ++sp) s += part[sp * pstride + e];
+    out[e] = s;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // backward, query-major pass: one wave owns 32 queries and loops over key tiles (transposed tiles, as forward):
 //   dS^T[j][i] -> dq[d][i] = sum_j k[d][j] dS^T[j][i]
 // ---------------------------------------------------------------------------------------------------
+template <bool D64>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* q, const float* k, const float* v,
                                                          const float* dout, const float* lse, const float* delta,
-                                                         int H, int D, int64_t n, int64_t m, int64_t qbs,
-                                                         int64_t kvbs, float scale, float* dq) {
-  __shared__ float Ks[DMAX * KP];
-  __shared__ float Vs[DMAX * KP];
+                                                         int H, int D, int n, int m, int64_t qbs, int64_t kvbs,
+                                                         float scale, float* dq) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int64_t b = blockIdx.z, h = blockIdx.y;
-  const int64_t i0 = (int64_t)blockIdx.x * 128 + wave * 32;
-  const float* qh = q + b * qbs + h * D * n;
-  const float* kh = k + b * kvbs + h * D * m;
-  const float* vh = v + b * kvbs + h * D * m;
+  const int i0 = blockIdx.x * 128 + wave * 32;
+  if (i0 >= n) return;
+  const float* qh = q + b * qbs + h * (int64_t)D * n;
+  const float* kh = k + b * kvbs + h * (int64_t)D * m;
+  const float* vh = v + b * kvbs + h * (int64_t)D * m;
   const float* doh = dout + (b * H + h) * (int64_t)D * n;
-  const int64_t iq = i0 + l31;
+  const int iq = i0 + l31;
   const bool qok = iq < n;
+  const bool vec = ((m & 3) == 0) && aligned16(kh);
   float qf[DMAX / 2], df[DMAX / 2];
+  {
+    const int qcol = hi * n + (qok ? iq : n - 1);
 #pragma unroll
-  for (int s = 0; s < DMAX / 2; ++s) {
-    const bool ok = qok && (2 * s + hi < D);
-    qf[s] = ok ? qh[(2 * s + hi) * n + iq] : 0.0f;
-    df[s] = ok ? doh[(2 * s + hi) * n + iq] : 0.0f;
+    for (int s = 0; s < DMAX / 2; ++s) {
+      qf[s] = (D64 || 2 * s < D) ? ld_col<D64>(qh, n, s, hi, D, qcol, qok) : 0.0f;
+      df[s] = (D64 || 2 * s < D) ? ld_col<D64>(doh, n, s, hi, D, qcol, qok) : 0.0f;
+    }
   }
-  const float li = qok ? lse[(b * H + h) * n + iq] : 0.0f;
-  const float di = qok ? delta[(b * H + h) * n + iq] : 0.0f;
+  const float li = qok ? lse[(b * H + h) * (int64_t)n + iq] : 0.0f;
+  const float di = qok ? delta[(b * H + h) * (int64_t)n + iq] : 0.0f;
   f32x16 dqa[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqa[t][r] = 0.0f;
 
-  for (int64_t j0 = 0; j0 < m; j0 += 32) {
-    __syncthreads();
-    stage_tile(kh, m, j0, m, D, Ks);
-    stage_tile(vh, m, j0, m, D, Vs);
-    __syncthreads();
+  for (int j0 = 0; j0 < m; j0 += 32) {
+    const bool full = j0 + 32 <= m;
+    const bool kok = j0 + l31 < m;
+    const int kcol = hi * m + (kok ? j0 + l31 : m - 1);
     f32x16 st, dpt;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = dpt[r] = 0.0f;
 #pragma unroll
     for (int s = 0; s < DMAX / 2; ++s)
-      if (2 * s < D) {
-        st = adp_mfma32(Ks[(2 * s + hi) * KP + l31], qf[s], st);    // S^T[j][i]
-        dpt = adp_mfma32(Vs[(2 * s + hi) * KP + l31], df[s], dpt);  // dP^T[j][i] = sum_d v[d][j] dO[d][i]
+      if (D64 || 2 * s < D) {
+        st = adp_mfma32(ld_col<D64>(kh, m, s, hi, D, kcol, kok), qf[s], st);    // S^T[j][i]
+        dpt = adp_mfma32(ld_col<D64>(vh, m, s, hi, D, kcol, kok), df[s], dpt);  // dP^T[j][i] = sum_d v[d][j] dO[d][i]
       }
+    float kr[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (D64 || 32 * t < D) ld_row16<D64>(kh, m, 32 * t + l31, D, j0, hi, full && vec, kr[t]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const bool ok = (j0 + acc_row(r, hi) < m) && qok;
+      const bool ok = (full || j0 + acc_row(r, hi) < m) && qok;
       const float p = ok ? __expf(st[r] * scale - li) : 0.0f;
       dpt[r] = p * (dpt[r] - di) * scale;  // dS^T[j][i]
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      if (32 * t < D) {
+      if (D64 || 32 * t < D) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
-          dqa[t] = adp_mfma32(Ks[(32 * t + l31) * KP + acc_row(s, hi)], dpt[s], dqa[t]);
+        for (int s = 0; s < 16; ++s) dqa[t] = adp_mfma32(kr[t][s], dpt[s], dqa[t]);
       }
     }
   }
-  float* dqh = dq + b * qbs + h * D * n;
+  float* dqh = dq + b * qbs + h * (int64_t)D * n;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -288,8 +384,19 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* q, const f
     }
 }
 
+// query split of the key-major pass: enough waves to cover the chip when there are few key tiles
+int64_t kv_nsplit(int64_t B, int64_t H, int64_t n, int64_t m) {
+  const int64_t ktiles = (m + 31) / 32, qtiles = (n + 31) / 32;
+  int64_t ns = 1024 / (B * H * ktiles);          // target >= ~1024 waves (4 per CU)
+  if (ns > qtiles / 2) ns = qtiles / 2;          // at least two query tiles per wave
+  if (ns > 64) ns = 64;
+  if (ns < 1) ns = 1;
+  return ns;
+}
+
 bool attn_shape_ok(int64_t B, int64_t H, int64_t D, int64_t n, int64_t m) {
-  return B > 0 && H > 0 && D >= 2 && D <= DMAX && (D % 2 == 0) && n > 0 && m > 0 && B <= 65535 && H <= 65535;
+  return B > 0 && H > 0 && D >= 2 && D <= DMAX && (D % 2 == 0) && n > 0 && m > 0 && B <= 65535 && H <= 65535 &&
+         D * n < ((int64_t)1 << 31) && D * m < ((int64_t)1 << 31);  // 32-bit element offsets inside one head's slab
 }
 
 }  // namespace
@@ -300,14 +407,22 @@ extern "C" int adp_attn_fwd(const float* q, const float* k, const float* v, int6
   if (!q || !k || !v || !o || !lse) return ADP_ERR_NULL;
   if (!attn_shape_ok(B, H, D, n, m)) return ADP_ERR_SHAPE;
   const float scale = 1.0f / sqrtf((float)D);
-  ADP_LAUNCH(attn_fwd_kernel, dim3((unsigned)adp_cdiv(n, 128), (unsigned)H, (unsigned)B), dim3(256), stream, q, k, v,
-             (int)H, (int)D, n, m, q_bstride, kv_bstride, scale, o, lse);
+  const dim3 grid((unsigned)adp_cdiv(n, 128), (unsigned)H, (unsigned)B);
+  if (D == 64)
+    ADP_LAUNCH(attn_fwd_kernel<true>, grid, dim3(256), stream, q, k, v, (int)H, (int)D, (int)n, (int)m, q_bstride,
+               kv_bstride, scale, o, lse);
+  else
+    ADP_LAUNCH(attn_fwd_kernel<false>, grid, dim3(256), stream, q, k, v, (int)H, (int)D, (int)n, (int)m, q_bstride,
+               kv_bstride, scale, o, lse);
   return ADP_LAUNCH_OK();
 }
 
 extern "C" int64_t adp_attn_bwd_ws_bytes(int64_t B, int64_t H, int64_t D, int64_t n, int64_t m) {
   if (!attn_shape_ok(B, H, D, n, m)) return ADP_ERR_SHAPE;
-  return B * H * n * (int64_t)sizeof(float);
+  const int64_t ns = kv_nsplit(B, H, n, m);
+  // delta [B, H, n] + (query-split dk/dv pass) nsplit partial copies of dk and of dv, each B * kv_bstride floats at
+  // most 2*H*D*m per batch element (k and v are the two halves of one projection output)
+  return (B * H * n + (ns > 1 ? 2 * ns * B * 2 * H * D * m : 0)) * (int64_t)sizeof(float);
 }
 
 extern "C" int adp_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
@@ -319,9 +434,33 @@ extern "C" int adp_attn_bwd(const float* q, const float* k, const float* v, cons
   const float scale = 1.0f / sqrtf((float)D);
   ADP_LAUNCH(attn_delta_kernel, dim3((unsigned)adp_cdiv(n, 256), (unsigned)(B * H)), dim3(256), stream, o, dout,
              (int)H, (int)D, n, ws);
-  ADP_LAUNCH(attn_bwd_kv_kernel, dim3((unsigned)adp_cdiv(m, 128), (unsigned)H, (unsigned)B), dim3(256), stream, q,
-             k, v, dout, lse, (const float*)ws, (int)H, (int)D, n, m, q_bstride, kv_bstride, scale, dk, dv);
-  ADP_LAUNCH(attn_bwd_q_kernel, dim3((unsigned)adp_cdiv(n, 128), (unsigned)H, (unsigned)B), dim3(256), stream, q, k,
-             v, dout, lse, (const float*)ws, (int)H, (int)D, n, m, q_bstride, kv_bstride, scale, dq);
+  const int64_t ns = kv_nsplit(B, H, n, m), ktiles = adp_cdiv(m, 32), qtiles = adp_cdiv(n, 32);
+  const int64_t tps = adp_cdiv(qtiles, ns);  // query tiles per split
+  float* pk = dk;
+  float* pv = dv;
+  int64_t pstride = 0;
+  if (ns > 1) {
+    if (kv_bstride > 2 * H * D * m) return ADP_ERR_UNSUPPORTED;  // the partial copies are sized for packed k|v
+    pstride = B * kv_bstride;                 // one partial copy, addressed exactly like dk / dv
+    pk = ws + B * H * n;
+    pv = pk + ns * pstride;
+  }
+  const dim3 gkv((unsigned)adp_cdiv(ktiles * ns, 4), (unsigned)H, (unsigned)B);
+  const dim3 gq((unsigned)adp_cdiv(n, 128), (unsigned)H, (unsigned)B);
+  if (D == 64)
+    ADP_LAUNCH(attn_bwd_kv_kernel<true>, gkv, dim3(256), stream, q, k, v, dout, lse, (const float*)ws, (int)H, (int)D,
+               (int)n, (int)m, q_bstride, kv_bstride, scale, (int)ns, (int)tps, pstride, pk, pv);
+  else
+    ADP_LAUNCH(attn_bwd_kv_kernel<false>, gkv, dim3(256), stream, q, k, v, dout, lse, (const float*)ws, (int)H, (int)D,
+               (int)n, (int)m, q_bstride, kv_bstride, scale, (int)ns, (int)tps, pstride, pk, pv);
+  if (ns > 1)  // dk and dv are [H*D, m] slabs inside each batch stride
+    ADP_LAUNCH(attn_kv_reduce_kernel, dim3((unsigned)adp_cdiv(H * D * m, 1024), (unsigned)(2 * B)), dim3(256), stream,
+               (const float*)pk, (const float*)pv, (int)ns, pstride, kv_bstride, H * D * m, dk, dv);
+  if (D == 64)
+    ADP_LAUNCH(attn_bwd_q_kernel<true>, gq, dim3(256), stream, q, k, v, dout, lse, (const float*)ws, (int)H, (int)D,
+               (int)n, (int)m, q_bstride, kv_bstride, scale, dq);
+  else
+    ADP_LAUNCH(attn_bwd_q_kernel<false>, gq, dim3(256), stream, q, k, v, dout, lse, (const float*)ws, (int)H, (int)D,
+               (int)n, (int)m, q_bstride, kv_bstride, scale, dq);
   return ADP_LAUNCH_OK();
 }

@@ -860,6 +860,15 @@ extern "C" int adp_conv1d(const adp_conv_desc* dp, void* stream) {
   return dispatch_conv<4, 4>(d, stream);
 }
 
+extern "C" int64_t adp_conv1d_ws_bytes(const adp_conv_desc* dp) {
+  if (!dp) return ADP_ERR_NULL;
+  const adp_conv_desc& d = *dp;
+  if (d.B <= 0 || d.R <= 0 || d.M <= 0 || d.N <= 0 || d.Lin <= 0) return ADP_ERR_SHAPE;
+  if (adp_conv_stream_eligible(d) || !adp_conv_mm_eligible(d)) return 0;
+  const int64_t ks = adp_conv_mm_ksplit(d);
+  return ks > 1 ? ks * d.B * d.M * d.N * (int64_t)sizeof(float) : 0;
+}
+
 // which tile the dispatcher picks for this problem: BM * 1000 + BN (introspection for profiling / roofline reports)
 extern "C" int64_t adp_conv1d_tile(const adp_conv_desc* dp) {
   if (!dp) return ADP_ERR_NULL;

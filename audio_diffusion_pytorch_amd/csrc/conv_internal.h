@@ -7,6 +7,7 @@
 bool adp_conv_mm_eligible(const adp_conv_desc& d);
 int adp_conv_mm(const adp_conv_desc& d, void* stream);
 int64_t adp_conv_mm_tile(const adp_conv_desc& d);  // NKG * 1000000 + BM * 1000 + BN
+int64_t adp_conv_mm_ksplit(const adp_conv_desc& d);  // cross-workgroup K split the dispatcher picks (1 = none)
 
 // wgrad_mm.hip: wave-specialised weight gradient of the same convolutions (channels % 32 == 0)
 bool adp_wgrad_mm_eligible(const adp_wgrad_desc& d);

@@ -18,7 +18,63 @@ bool mm_use64(const adp_conv_desc& d) {
   return (d.M / 64) * adp_cdiv(d.N, 64) * d.B >= 200;
 }
 
+// sum of the KS split-K partial tiles (fixed order) + the conv epilogue of store mode 0:
+//   v = bias[m] + sum_ks ws[ks][b][m][n] ; out_pre = v ; out = e_scale[b,m] * v + res
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(adp_conv_desc d, int KS) {
+  const int64_t total = d.B * d.M * d.N;
+  const int64_t ebs = d.e_bstride ? d.e_bstride : d.M;
+  const bool vec = (d.N & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(d.ws) | reinterpret_cast<uintptr_t>(d.out) |
+                     reinterpret_cast<uintptr_t>(d.res) | reinterpret_cast<uintptr_t>(d.out_pre)) & 15) == 0;
+  const int64_t step = vec ? 4 : 1;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * step; i < total; i += (int64_t)gridDim.x * 256 * step) {
+    const int64_t row = i / d.N, m = row % d.M, b = row / d.M;
+    const float bias = d.bias ? d.bias[m] : 0.0f;
+    const float sc = d.e_scale ? d.e_scale[b * ebs + m] : 1.0f;
+    if (vec) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(d.ws + i);
+      for (int k = 1; k < KS; ++k) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(d.ws + k * total + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += p[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += bias;
+      if (d.out_pre) *reinterpret_cast<f32x4*>(d.out_pre + i) = v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= sc;
+      if (d.res) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(d.res + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+      }
+      *reinterpret_cast<f32x4*>(d.out + i) = v;
+    } else {
+      float v = d.ws[i];
+      for (int k = 1; k < KS; ++k) v += d.ws[k * total + i];
+      v += bias;
+      if (d.out_pre) d.out_pre[i] = v;
+      v *= sc;
+      if (d.res) v += d.res[i];
+      d.out[i] = v;
+    }
+  }
+}
+
 }  // namespace
+
+// Cross-workgroup K split: when the output tiles alone leave most of the 256 CUs idle (batch-1 deep layers: depth 8
+// has 64 tiles of 32 x 64) the reduction over input channels is cut into 2 / 4 / 8 slices run by separate
+// workgroups (>= 4 chunks of 32 channels each), combined by conv_splitk_reduce_kernel (deterministic order).
+int64_t adp_conv_mm_ksplit(const adp_conv_desc& d) {
+  if (d.store != 0) return 1;  // pixel-shuffle / pooled stores keep their in-kernel epilogue
+  const int64_t bm = mm_use64(d) ? 64 : 32;
+  const int64_t blocks = (d.M / bm) * adp_cdiv(d.N, 64) * d.B;
+  const int64_t nchunks = d.R / (d.stride == 4 ? 16 : MM_BKT);
+  int64_t ks = 1;
+  while (ks < 8 && blocks * ks < 200 && nchunks / (ks * 2) >= 4) ks *= 2;
+  return ks;
+}
 
 bool adp_conv_mm_eligible(const adp_conv_desc& d) {
   if (d.R1 != d.R) return false;
@@ -44,5 +100,14 @@ int64_t adp_conv_mm_tile(const adp_conv_desc& d) {
 }
 
 int adp_conv_mm(const adp_conv_desc& d, void* stream) {
-  return mm_use64(d) ? adp_conv_mm_m64(d, stream) : adp_conv_mm_m32(d, stream);
+  const int rc = mm_use64(d) ? adp_conv_mm_m64(d, stream) : adp_conv_mm_m32(d, stream);
+  const int64_t ks = d.ws ? adp_conv_mm_ksplit(d) : 1;
+  if (rc == ADP_OK && ks > 1) {
+    const int64_t total = d.B * d.M * d.N;
+    int64_t g = adp_cdiv(total, 1024);
+    if (g > 2048) g = 2048;
+    ADP_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), stream, d, (int)ks);
+    return ADP_LAUNCH_OK();
+  }
+  return rc;
 }

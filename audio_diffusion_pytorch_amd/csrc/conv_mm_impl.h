@@ -78,7 +78,8 @@ struct cmax {
 // UP: nearest-upsample factor folded into the X loader (UpsampleItem: the [B, C, L*UP] intermediate is never
 // materialised); BKT: channels per staged chunk; PD: loader prefetch distance in chunks (register stages).
 template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD>
-__global__ __launch_bounds__(((BM / 32) * (BKT / 8) + mm_nld(PRO, BM, PD)) * 64) void conv_mm_kernel(adp_conv_desc d) {
+__global__ __launch_bounds__(((BM / 32) * (BKT / 8) + mm_nld(PRO, BM, PD)) * 64) void conv_mm_kernel(adp_conv_desc d,
+                                                                                                   int KS) {
   constexpr int MM_NLD = mm_nld(PRO, BM, PD);
   constexpr int BN = MM_BN, NKG = BKT / 8, NQM = BM / 32;
   constexpr int NMMA = NQM * NKG;                   // MMA waves
@@ -111,7 +112,13 @@ __global__ __launch_bounds__(((BM / 32) * (BKT / 8) + mm_nld(PRO, BM, PD)) * 64)
   const int mt = id / per_m, rem = id - mt * per_m;
   const int b = rem / ntn, nt = rem - b * ntn;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int nchunks = R / BKT;
+  // Cross-workgroup K split (grid.y = KS > 1: small grids, i.e. the deep layers at batch 1): this block reduces
+  // channel chunks [c_lo, c_lo + nchunks) only and parks its raw partial tile in d.ws[ks]; the epilogue (bias,
+  // e_scale, residual) then runs in conv_splitk_reduce_kernel, which sums the KS partials in a fixed order.
+  const int ks = blockIdx.y;
+  const int cps = (R / BKT + KS - 1) / KS;
+  const int c_lo = ks * cps;
+  const int nchunks = (R / BKT - c_lo) < cps ? (R / BKT - c_lo) : cps;
   const int nrounds = ((nchunks + PD - 1) / PD) * PD;  // ghost iterations (barrier only) pad the loop to PD
 
   if (PRO == 1) {
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(((BM / 32) * (BKT / 8) + mm_nld(PRO, BM, PD)) * 64)
     // and the compiler waits with vmcnt(loads of the younger stages) instead of vmcnt(0).
     f32x4 ra[PD][NA4], rx[PD][NX4];
     auto load_chunk = [&](f32x4 (&a)[NA4], f32x4 (&x)[NX4], int chunk) {
-      const int rn = (chunk < nchunks ? chunk : nchunks - 1) * BKT;
+      const int rn = (c_lo + (chunk < nchunks ? chunk : nchunks - 1)) * BKT;
       const float* wp = TR ? wbase + (int64_t)rn * M * KT : wbase + rn * KT;
 #pragma unroll
       for (int i = 0; i < NA4; ++i) a[i] = *reinterpret_cast<const f32x4*>(wp + a_src[i]);
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(((BM / 32) * (BKT / 8) + mm_nld(PRO, BM, PD)) * 64)
       for (int i = 0; i < NX4; ++i) x[i] = load_xquad<UP>(xp + x_src[i]);
     };
     auto store_chunk = [&](const f32x4 (&a)[NA4], const f32x4 (&x)[NX4], int chunk) {
-      const int r0 = (chunk < nchunks ? chunk : nchunks - 1) * BKT;
+      const int r0 = (c_lo + (chunk < nchunks ? chunk : nchunks - 1)) * BKT;
       float* Ab = smem + (chunk & 1) * (A_ELEMS + X_ELEMS);
       float* Xb = Ab + A_ELEMS;
 #pragma unroll
@@ -288,6 +295,10 @@ __global__ __launch_bounds__(((BM / 32) * (BKT / 8) + mm_nld(PRO, BM, PD)) * 64)
       }
       const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       const bool ok = (m < M) && (n < N);
+      if (KS > 1) {  // raw partial tile; the epilogue runs in the reduce kernel
+        if (ok) d.ws[(((int64_t)ks * d.B + b) * M + m) * N + n] = v;
+        continue;
+      }
       if (ok) {
         if (d.bias) v += d.bias[m];
         if (d.out_pre) d.out_pre[((int64_t)b * M + m) * N + n] = v;
@@ -323,15 +334,17 @@ __global__ __launch_bounds__(((BM / 32) * (BKT / 8) + mm_nld(PRO, BM, PD)) * 64)
 template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD>
 int launch_mm(const adp_conv_desc& d, void* stream) {
   const int64_t blocks = (d.M / BM) * adp_cdiv(d.N, MM_BN) * d.B;
-  ADP_LAUNCH((conv_mm_kernel<BM, KT, S, UP, TR, PRO, BKT, PD>), dim3((unsigned)blocks),
-             dim3(((BM / 32) * (BKT / 8) + mm_nld(PRO, BM, PD)) * 64), stream, d);
+  const int KS = d.ws ? (int)adp_conv_mm_ksplit(d) : 1;
+  ADP_LAUNCH((conv_mm_kernel<BM, KT, S, UP, TR, PRO, BKT, PD>), dim3((unsigned)blocks, (unsigned)KS),
+             dim3(((BM / 32) * (BKT / 8) + mm_nld(PRO, BM, PD)) * 64), stream, d, KS);
   return ADP_LAUNCH_OK();
 }
 
 // short K (one or two chunks: the HBM-bound shallow layers) runs without ghost iterations
 template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT>
 int launch_pd(const adp_conv_desc& d, void* stream) {
-  if (d.R / BKT >= 4) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 2>(d, stream);
+  const int64_t KS = d.ws ? adp_conv_mm_ksplit(d) : 1;
+  if (d.R / BKT / KS >= 4) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 2>(d, stream);
   return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1>(d, stream);
 }
 

@@ -218,10 +218,14 @@ __global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* ab, int
 // segments), the remaining lane bits and the waves stride the channels (CG = NT/TL channel groups, each thread
 // holds channels cg, cg+CG, ...).  Deep layers have few positions (depth 8 at batch 4: 512) but 1024 channels:
 // they take TL = 16 with 1024-thread workgroups, so even 32 workgroups keep 512 waves of loads in flight.
-// mode: y = xhat * (1 + ss[b*bstride + c]) + ss[b*bstride + C + c]      (Modulation); y == NULL: statistics only.
+// mode: y = xhat * (1 + ss[b*bstride + c]) + ss[b*bstride + C + c]      (Modulation); y == NULL: statistics only;
+//       gam != NULL: y = xhat * gam[c] + bet[c] (affine LayerNorm of the attention items, materialised once for the
+//       q / kv projections) and optionally a second affine output y2 with (gam2, bet2) from the same statistics.
 template <int TL, int NT, int VPT>
 __global__ __launch_bounds__(NT) void chan_ln_fwd_kernel(const float* x, const float* ss, int64_t bstride, int C, int L,
-                                                         float eps, float* y, float* stats) {
+                                                         float eps, float* y, float* stats, const float* gam,
+                                                         const float* bet, const float* gam2, const float* bet2,
+                                                         float* y2) {
   constexpr int CG = NT / TL, NW = NT / 64, GPW = 64 / TL;  // channel groups, waves, channel groups per wave
   __shared__ float red[NW][TL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -267,6 +271,19 @@ __global__ __launch_bounds__(NT) void chan_ln_fwd_kernel(const float* x, const f
   }
   if (y == nullptr) return;
   float* yb = y + (int64_t)b * C * L + l;
+  if (gam != nullptr) {
+    float* yb2 = y2 ? y2 + (int64_t)b * C * L + l : nullptr;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int c = cg + i * CG;
+      if (valid && c < C) {
+        const float xh = (v[i] - mean) * rstd;
+        yb[(int64_t)c * L] = fmaf(xh, gam[c], bet[c]);
+        if (yb2) yb2[(int64_t)c * L] = fmaf(xh, gam2[c], bet2[c]);
+      }
+    }
+    return;
+  }
   const float* sb = ss + b * bstride;
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
@@ -362,27 +379,26 @@ LnCfg ln_cfg(int64_t C, int64_t B, int64_t L) {
 constexpr int64_t LN_CMAX = 1024;
 
 int launch_ln_fwd(const float* x, const float* ss, int64_t bstride, int64_t B, int64_t C, int64_t L, float eps, float* y,
-                  float* stats, void* stream) {
+                  float* stats, void* stream, const float* gam = nullptr, const float* bet = nullptr,
+                  const float* gam2 = nullptr, const float* bet2 = nullptr, float* y2 = nullptr) {
   const LnCfg k = ln_cfg(C, B, L);
   dim3 grid((unsigned)adp_cdiv(L, k.tl), (unsigned)B);
   if (k.tl == 8)
-    ADP_LAUNCH((chan_ln_fwd_kernel<8, 1024, 8>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats);
+    ADP_LAUNCH((chan_ln_fwd_kernel<8, 1024, 8>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
   else if (k.tl == 4)
-    ADP_LAUNCH((chan_ln_fwd_kernel<4, 1024, 4>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats);
+    ADP_LAUNCH((chan_ln_fwd_kernel<4, 1024, 4>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
   else if (k.tl == 64 && C <= 8)
-    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 2>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats);
+    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 2>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
   else if (k.tl == 64 && C <= 32)
-    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 8>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats);
+    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 8>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
   else if (k.tl == 64)
-    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 16>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats);
+    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 16>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
   else if (k.tl == 32 && k.nt == 256)
-    ADP_LAUNCH((chan_ln_fwd_kernel<32, 256, 16>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats);
+    ADP_LAUNCH((chan_ln_fwd_kernel<32, 256, 16>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
   else if (k.tl == 32)
-    ADP_LAUNCH((chan_ln_fwd_kernel<32, 1024, 8>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y,
-               stats);
+    ADP_LAUNCH((chan_ln_fwd_kernel<32, 1024, 8>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
   else
-    ADP_LAUNCH((chan_ln_fwd_kernel<16, 1024, 16>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y,
-               stats);
+    ADP_LAUNCH((chan_ln_fwd_kernel<16, 1024, 16>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
   return ADP_LAUNCH_OK();
 }
 
@@ -548,6 +564,17 @@ extern "C" int adp_ln_stats(const float* x, int64_t B, int64_t C, int64_t L, flo
   if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
   if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
   return launch_ln_fwd(x, (const float*)nullptr, (int64_t)0, B, C, L, eps, (float*)nullptr, stats, stream);
+}
+
+extern "C" int adp_ln_affine_fwd(const float* x, int64_t B, int64_t C, int64_t L, float eps, const float* gamma,
+                                 const float* beta, float* y, const float* gamma2, const float* beta2, float* y2,
+                                 float* stats, void* stream) {
+  if (!x || !gamma || !beta || !y || !stats) return ADP_ERR_NULL;
+  if (y2 && (!gamma2 || !beta2)) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
+  if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
+  return launch_ln_fwd(x, (const float*)nullptr, (int64_t)0, B, C, L, eps, y, stats, stream, gamma, beta, gamma2, beta2,
+                       y2);
 }
 
 extern "C" int64_t adp_chan_ln_bwd_ws_bytes(int64_t B, int64_t C, int64_t L) {

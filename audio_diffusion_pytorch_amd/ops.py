@@ -53,7 +53,11 @@ def conv1d(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int =
         assert tuple(out.shape) == oshape, (out.shape, oshape)
     d = ConvDesc(ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(pro_stats), ptr(pro_gamma), ptr(pro_beta), ptr(e_scale),
                  ptr(res), ptr(out), ptr(out_pre), B, R, R1, Lin, M, N, KT, stride, dil, pad, up, int(transposed), prologue, groups,
-                 store, sp, e_bstride)
+                 store, sp, e_bstride, None)
+    need = _C.query("adp_conv1d_ws_bytes", byref(d))
+    if need > 0:  # split-K partial tiles (small grids: the deep layers at batch 1)
+        ws = _ws(need, x)
+        d.ws = ptr(ws)
     if _C.PROFILE is not None:  # algorithmic work of this launch: A_in + A_out (+A_res) + weights
         _C.tag(flops=2 * B * M * N * R * KT,
                bytes=4 * (B * R * Lin + out.numel() + w.numel() + (res.numel() if res is not None else 0)),
@@ -159,6 +163,19 @@ def ln_stats(x: Tensor, eps: float = LN_EPS) -> Tensor:
     stats = torch.empty((B, L, 2), dtype=torch.float32, device=x.device)
     _C.call("adp_ln_stats", ptr(x), B, C, L, eps, ptr(stats), _C.stream())
     return stats
+
+
+def ln_affine_fwd(x: Tensor, gamma: Tensor, beta: Tensor, gamma2: Optional[Tensor] = None,
+                  beta2: Optional[Tensor] = None, eps: float = LN_EPS):
+    """(y, y2 or None, stats): y = LayerNorm_C(x) * gamma + beta, y2 likewise with (gamma2, beta2), stats [B, L, 2]."""
+    B, C, L = x.shape
+    y = torch.empty_like(x)
+    y2 = torch.empty_like(x) if gamma2 is not None else None
+    stats = torch.empty((B, L, 2), dtype=torch.float32, device=x.device)
+    _C.tag(bytes=4 * x.numel() * (3 if y2 is not None else 2), shape=f"B{B} C{C} L{L}")
+    _C.call("adp_ln_affine_fwd", ptr(x), B, C, L, eps, ptr(gamma), ptr(beta), ptr(y), ptr(gamma2), ptr(beta2), ptr(y2),
+            ptr(stats), _C.stream())
+    return y, y2, stats
 
 
 def ln_bwd(x: Tensor, dxn: Tensor, stats: Tensor, gamma: Tensor, dres: Optional[Tensor] = None,
@@ -402,6 +419,7 @@ def attn_fwd(q: Tensor, kv: Tensor, heads: int, head_features: int):
     o = torch.empty_like(q)
     lse = torch.empty((B, H, n), dtype=torch.float32, device=q.device)
     kvf = kv.view(-1)
+    _C.tag(flops=4 * B * H * n * m * D, bytes=4 * (2 * q.numel() + kv.numel()), shape=f"B{B} H{H} D{D} n{n} m{m}")
     _C.call("adp_attn_fwd", ptr(q), ptr(kvf), ptr(kvf[mid * m:]), B, H, D, n, m, mid * n, 2 * mid * m, ptr(o),
             ptr(lse), _C.stream())
     return o, lse
@@ -415,6 +433,8 @@ def attn_bwd(q: Tensor, kv: Tensor, o: Tensor, dout: Tensor, lse: Tensor, heads:
     dq, dkv = torch.empty_like(q), torch.empty_like(kv)
     ws = _ws(_C.query("adp_attn_bwd_ws_bytes", B, H, D, n, m), q)
     kvf, dkvf = kv.view(-1), dkv.view(-1)
+    # QK^T is recomputed in both passes: dV, dP, dK in the key/value pass and dP, dQ in the query pass (7 contractions)
+    _C.tag(flops=14 * B * H * n * m * D, bytes=4 * (4 * q.numel() + 2 * kv.numel()), shape=f"B{B} H{H} D{D} n{n} m{m}")
     _C.call("adp_attn_bwd", ptr(q), ptr(kvf), ptr(kvf[mid * m:]), ptr(o), ptr(dout), ptr(lse), B, H, D, n, m,
             mid * n, 2 * mid * m, ptr(dq), ptr(dkvf), ptr(dkvf[mid * m:]), ptr(ws), _C.stream())
     return dq, dkv

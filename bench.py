@@ -71,6 +71,20 @@ def cpu_baseline(batch: int, threads: int = 16, budget_s: float = 25.0):
                       f"CPU, {cores} threads, after 1 warm-up step), scaled to the bench step of {batch} samples"}
 
 
+def profiled_step(model, step):
+    """Runs `step()` once with every C-ABI launch bracketed by HIP events on its launch stream; returns the records
+    [(call, kernel, meta, ms), ...] (see audio_diffusion_pytorch_amd._C.profile_collect)."""
+    from audio_diffusion_pytorch_amd import _C
+    for p in model.parameters():
+        p.grad = None
+    _C.PROFILE = []
+    try:
+        step()
+    finally:
+        recs = _C.profile_collect()   # waits for the events
+    return recs
+
+
 def roofline_leg(model, x, top: int = 14):
     """One instrumented eager step: while recording is on, libadp_hip.so brackets EVERY kernel launch with a pair of
     HIP events recorded on the stream the kernel is launched on (`adp_launch_trace` / `adp_launch_times`) and names
@@ -82,15 +96,7 @@ def roofline_leg(model, x, top: int = 14):
       kernels                  the `top` kernels by total time.
     `traffic` (HBM bytes per launch from the rocprofv3 PMC passes) is looked up in profiles/pmc_traffic.json, which
     tools/pmc_summary.py writes from the FETCH_SIZE / WRITE_SIZE passes of this same command."""
-    from audio_diffusion_pytorch_amd import _C
-    for p in model.parameters():
-        p.grad = None
-    _C.PROFILE = []
-    try:
-        loss = model(x)
-        loss.backward()
-    finally:
-        recs = _C.profile_collect()   # waits for the events
+    recs = profiled_step(model, lambda: model(x).backward())
     agg = {}
     for call, kern, meta, ms in recs:
         a = agg.setdefault(kern, {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0})
@@ -161,6 +167,113 @@ def roofline_leg(model, x, top: int = 14):
     return rf, hbm, table, round(total_ms, 3)
 
 
+def _graphed(step, zero):
+    """Captures `step` in a hipGraph (after two eager warm-ups on a side stream); returns the replay callable."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    zero()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    return graph.replay
+
+
+def _time(fn, n, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def _attn_summary(recs):
+    """Per attention kernel: launches, average time and TFLOP/s against the f32 MFMA peak."""
+    out = {}
+    for call, kern, meta, ms in recs:
+        if not call.startswith("adp_attn"):
+            continue
+        a = out.setdefault(kern.split("(")[0], {"launches": 0, "ms": 0.0, "flops": 0})
+        a["launches"] += 1
+        a["ms"] += ms
+        a["flops"] += meta.get("flops", 0)
+    res = {}
+    for k, a in out.items():
+        tf = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["flops"] and a["ms"] > 0 else None
+        res[k] = {"launches": a["launches"], "avg_us": round(a["ms"] / a["launches"] * 1e3, 2),
+                  "tflops": None if tf is None else round(tf, 2),
+                  "frac_of_f32_mfma_peak": None if tf is None else round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+    return res
+
+
+def extra_legs(model, x, dev):
+    """Numbers SURVEY 8d asks for next to the headline, OUTSIDE its timed region (same random-init weights):
+      batch1            config 1's shape on the GPU: fwd+bwd at [1,2,2**18], hipGraph-replayed;
+      sampler           config 3: VSampler 50 steps on noise [1,2,2**18], hipGraph-captured step (sampler steps/s);
+      readme_attention  config 1 + README attentions=[0,0,0,0,0,1,1,1,1] (8 heads x 64), fwd+bwd at batch 1, with
+                        the attention kernels' TFLOP/s from an instrumented step;
+      config4           text-conditional layout (cross attention at depths 3-8 over embedding [B,64,768]), batch 1."""
+    import audio_diffusion_pytorch_amd as adp
+    out = {}
+
+    def zero(m):
+        for p in m.parameters():
+            p.grad = None
+
+    x1 = x[:1].contiguous()
+    try:
+        def step1():
+            zero(model)
+            model(x1).backward()
+        dt = _time(_graphed(step1, lambda: zero(model)), 20)
+        out["batch1"] = {"workload": "BASELINE configs[0] shape on the GPU: fwd+bwd, audio [1,2,2**18]",
+                         "steps_per_s": round(1.0 / dt, 2), "ms_per_step": round(dt * 1e3, 3), "launch": "hipGraph replay"}
+    except Exception as e:
+        out["batch1"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        noise = torch.randn(1, 2, LENGTH, device=dev)
+        model.sample(noise, num_steps=2)  # captures the step
+        dt = _time(lambda: model.sample(noise, num_steps=50), 2, warmup=1)
+        out["sampler"] = {"workload": "BASELINE configs[2]: VSampler.sample num_steps=50, noise [1,2,2**18], "
+                                      "hipGraph-captured step", "sampler_steps_per_s": round(50.0 / dt, 2),
+                          "ms_per_step": round(dt / 50 * 1e3, 3), "ms_per_50_step_sample": round(dt * 1e3, 2)}
+    except Exception as e:
+        out["sampler"] = {"error": f"{type(e).__name__}: {e}"}
+    legs = {
+        "readme_attention": (dict(attentions=[0, 0, 0, 0, 0, 1, 1, 1, 1], attention_heads=8, attention_features=64), False),
+        "config4": (dict(cross_attentions=[0, 0, 0, 1, 1, 1, 1, 1, 1], embedding_features=768, attention_heads=8,
+                         attention_features=64), True),
+    }
+    for name, (extra, use_emb) in legs.items():
+        try:
+            torch.manual_seed(0)
+            m = adp.DiffusionModel(net_t=adp.UNetV0, in_channels=2, channels=CHANNELS, factors=FACTORS, items=ITEMS,
+                                   **extra).to(dev)
+            kw = dict(embedding=torch.randn(1, 64, 768, device=dev)) if use_emb else {}
+
+            def stepa():
+                zero(m)
+                m(x1, **kw).backward()
+            dt = _time(_graphed(stepa, lambda: zero(m)), 10)
+            recs = profiled_step(m, lambda: m(x1, **kw).backward())
+            out[name] = {"workload": f"UNetV0 README channels + {extra}, fwd+bwd at [1,2,2**18]"
+                                     + (", embedding [1,64,768]" if use_emb else ""),
+                         "steps_per_s": round(1.0 / dt, 2), "ms_per_step": round(dt * 1e3, 3),
+                         "attention_kernels": _attn_summary(recs)}
+            del m
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +284,7 @@ def main():
                                                           "default: graph on 1 GPU, eager with RCCL")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the batch-1 / sampler / attention legs")
     args = ap.parse_args()
 
     from audio_diffusion_pytorch_amd import parallel
@@ -266,6 +380,8 @@ def main():
             line["instrumented_kernel_ms_per_step"] = eager_ms
         except Exception as e:
             line["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and world == 1 and not args.no_extras:
+        line.update(extra_legs(model, x, dev))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.batch)
     if rank == 0:

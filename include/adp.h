@@ -80,8 +80,12 @@ typedef struct adp_conv_desc {
   int64_t KT, stride, dil, pad, up;
   int64_t transposed, prologue, groups, store, sp;
   int64_t e_bstride;       /* batch stride of e_scale in floats (0 -> M) */
+  float* ws;               /* scratch of adp_conv1d_ws_bytes(d) bytes (NULL when that is 0): cross-workgroup split-K
+                              partial tiles of small-grid problems (batch-1 deep layers) */
 } adp_conv_desc;
 
+/* Scratch the launch wants (0 for most shapes).  With ws == NULL the call still succeeds on the unsplit path. */
+int64_t adp_conv1d_ws_bytes(const adp_conv_desc* d);
 int adp_conv1d(const adp_conv_desc* d, void* stream);
 /* tile the dispatcher selects for this problem, BM*1000+BN (introspection for profiling / roofline reports) */
 int64_t adp_conv1d_tile(const adp_conv_desc* d);
@@ -161,6 +165,12 @@ int adp_modulation_bwd(const float* x, const float* dy, const float* ss, int64_t
 
 /* LayerNorm-over-channels statistics only (LayerNorm prologue of the attention projections, components.py:92-93) */
 int adp_ln_stats(const float* x, int64_t B, int64_t C, int64_t L, float eps, float* stats, void* stream);
+/* Affine LayerNorm over channels, materialised: y = LayerNorm_C(x) * gamma + beta (and, from the same statistics,
+ * y2 with gamma2 / beta2 when y2 != NULL: self attention normalises x twice, for q and for k/v -- a_unet Attention's
+ * `norm` and `norm_context`, components.py:92).  The projections then run as plain 1x1 convs on the MFMA kernel. */
+int adp_ln_affine_fwd(const float* x, int64_t B, int64_t C, int64_t L, float eps, const float* gamma,
+                      const float* beta, float* y, const float* gamma2, const float* beta2, float* y2, float* stats,
+                      void* stream);
 /* Backward of xn = LayerNorm_C(x) * gamma + beta given dxn: dx = ... (+ dres); dgamma_dbeta = [dgamma | dbeta] (2C).
  * ws: adp_chan_ln_bwd_ws_bytes(B, C, L). */
 int adp_ln_bwd(const float* x, const float* dxn, const float* stats, const float* gamma, const float* dres,

@@ -49,6 +49,35 @@ def test_conv1d_plain(dev, B, R, M, L, KT, stride, pad, up):
     assert rel_err(out, ref) < TOL
 
 
+@pytest.mark.parametrize("B,R,M,L,KT,tr", [(1, 512, 64, 64, 3, False), (1, 256, 96, 128, 3, True),
+                                           (2, 1024, 32, 60, 1, False), (1, 512, 128, 32, 2, False)])
+def test_conv1d_cross_workgroup_split_k(dev, B, R, M, L, KT, tr):
+    """Small grids (batch-1 deep layers) split the channel reduction over several workgroups: partial tiles in the
+    caller's scratch (adp_conv1d_ws_bytes) + a fixed-order reduce kernel that owns the epilogue (bias, e_scale,
+    residual, out_pre)."""
+    from ctypes import byref
+    from audio_diffusion_pytorch_amd import _C
+    stride = 2 if KT == 2 else 1
+    x = rnd(B, R, L, seed=1)
+    w = rnd(R, M, KT, seed=2, scale=0.05) if tr else rnd(M, R, KT, seed=2, scale=0.05)
+    N = L // stride
+    b, res, sc = rnd(M, seed=3), rnd(B, M, N, seed=4), rnd(B * M, seed=5)
+    if tr:
+        ref = F.conv_transpose1d(x, w, None, padding=1)
+    else:
+        ref = F.conv1d(x, w, None, stride=stride, padding=1 if KT == 3 else 0)
+    pre_ref = ref + b[None, :, None]
+    ref = pre_ref * sc.view(B, M, 1) + res
+    xd, wd = x.to(dev), w.to(dev)
+    d = _C.ConvDesc(_C.ptr(xd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(xd), None, B, R, R, L, M,
+                    N, KT, stride, 1, 1 if KT == 3 else 0, 1, int(tr), 0, 1, 0, 1, 0)
+    assert _C.query("adp_conv1d_ws_bytes", byref(d)) > 0, "this shape is meant to take the split-K path"
+    pre = torch.empty(B, M, N).to(dev)
+    out = ops.conv1d(xd, wd, b.to(dev), stride=stride, pad=1 if KT == 3 else 0, transposed=tr, e_scale=sc.to(dev),
+                     res=res.to(dev), out_pre=pre)
+    assert rel_err(out, ref) < TOL and rel_err(pre, pre_ref) < TOL
+
+
 def test_conv1d_big_tile(dev):
     # enough workgroups to select the 128x128 tile on the dispatcher
     B, R, M, L = 6, 32, 128, 1024 if dev.type == "cuda" else 1024
@@ -554,7 +583,10 @@ def test_v_noise_mse_step(dev):
 
 
 # ------------------------------------------------------------------ attention core
-@pytest.mark.parametrize("B,H,D,n,m", [(2, 2, 64, 160, 160), (1, 3, 32, 70, 45), (1, 8, 64, 128, 64)])
+@pytest.mark.parametrize("B,H,D,n,m", [(2, 2, 64, 160, 160), (1, 3, 32, 70, 45), (1, 8, 64, 128, 64),
+                                       (1, 2, 64, 512, 64),    # few key tiles: the dk/dv pass splits the queries
+                                       (2, 1, 16, 203, 37),    # ragged both ways, query split with a short last slice
+                                       (1, 2, 64, 96, 256)])
 def test_attention_fwd_bwd(dev, B, H, D, n, m):
     mid = H * D
     q = rnd(B, mid, n, seed=1).requires_grad_()
