@@ -34,10 +34,32 @@ __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r 
 // "column" fragment element x[d][p]: col = hi * len + min(p, len - 1) precomputed per tile, pok = p < len
 template <bool D64>
 __device__ __forceinline__ float ld_col(const float* x, int len, int s, int hi, int D, int col, bool pok) {
-  if (D64) return pok ? x[2 * s * len + col] : 0.0f;
+  // the load is UNCONDITIONAL (the address is always in range) and the guard is a select on its result: a load
+  // inside the conditional arm makes hipcc branch around every single load and wait for each one separately
+  if (D64) {
+    const float v = x[2 * s * len + col];
+    return pok ? v : 0.0f;
+  }
   const int d = 2 * s + hi;
   const float v = x[(d < D ? 2 * s : 0) * len + col];
   return (pok && d < D) ? v : 0.0f;
+}
+
+// all D/2 column fragments of one 32-position tile.  Interior tiles (`full`) take plain loads with NO select on the
+// result: a select right behind a prefetch load would make the wave wait for the load it was meant to overlap.
+template <bool D64>
+__device__ __forceinline__ void ld_cols(const float* x, int len, int hi, int l31, int D, int p0, bool full,
+                                        float (&out)[DMAX / 2]) {
+  if (D64 && full) {
+    const float* xp = x + hi * len + p0 + l31;
+#pragma unroll
+    for (int s = 0; s < DMAX / 2; ++s) out[s] = xp[2 * s * len];
+  } else {
+    const bool pok = p0 + l31 < len;
+    const int col = hi * len + (pok ? p0 + l31 : len - 1);
+#pragma unroll
+    for (int s = 0; s < DMAX / 2; ++s) out[s] = (D64 || 2 * s < D) ? ld_col<D64>(x, len, s, hi, D, col, pok) : 0.0f;
+  }
 }
 
 // "row" fragment of one lane: the 16 values x[d][p0 + acc_row(s, hi)], s = 0..15, as four 4-float pieces (piece k =
@@ -52,7 +74,7 @@ __device__ __forceinline__ void ld_row16(const float* x, int len, int d, int D, 
     for (int k = 0; k < 4; ++k) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(row + p0 + 8 * k + 4 * hi);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) out[4 * k + e] = dok ? v[e] : 0.0f;
+      for (int e = 0; e < 4; ++e) out[4 * k + e] = (D64 || dok) ? v[e] : 0.0f;
     }
   } else {
 #pragma unroll
@@ -120,22 +142,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* q, const flo
     for (int r = 0; r < 16; ++r) oacc[t][r] = 0.0f;
   float mrun = -3.0e38f, lrun = 0.0f;
 
-  for (int j0 = 0; j0 < m; j0 += 32) {
+  // K column fragments of a tile (A operand of S^T): one 4-byte load per MFMA.  They are requested ONE TILE AHEAD
+  // into the other register set, so a tile's 64 MFMAs cover the L2 latency of the next tile's loads.
+  auto load_kc = [&](float (&kc)[DMAX / 2], int j0) { ld_cols<D64>(kh, m, hi, l31, D, j0, j0 + 32 <= m, kc); };
+  auto tile = [&](const float (&kc)[DMAX / 2], float (&kn)[DMAX / 2], int j0) {
     const bool full = j0 + 32 <= m;
-    const bool kok = j0 + l31 < m;
-    const int kcol = hi * m + (kok ? j0 + l31 : m - 1);
+    // V row fragments of THIS tile: needed only after the 32 S MFMAs and the softmax
+    float vr[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (D64 || 32 * t < D) ld_row16<D64>(vh, m, 32 * t + l31, D, j0, hi, full && vec, vr[t]);
+    if (j0 + 32 < m) load_kc(kn, j0 + 32);
+#ifndef ADP_EMULATE
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the matrix work
+#endif
     // S^T tile: rows j (regs), cols i (lanes): A[i'=j][kk=d] = k[d][j], B[kk=d][j'=i] = q[d][i]
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.0f;
 #pragma unroll
     for (int s = 0; s < DMAX / 2; ++s)
-      if (D64 || 2 * s < D) st = adp_mfma32(ld_col<D64>(kh, m, s, hi, D, kcol, kok), qf[s], st);
-    // V row fragments are requested before the softmax arithmetic that separates the two MFMA groups
-    float vr[2][16];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      if (D64 || 32 * t < D) ld_row16<D64>(vh, m, 32 * t + l31, D, j0, hi, full && vec, vr[t]);
+      if (D64 || 2 * s < D) st = adp_mfma32(kc[s], qf[s], st);
     // online softmax over j: 16 in-register rows + the other half-wave
     float tmax = -3.0e38f;
 #pragma unroll
@@ -166,6 +193,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* q, const flo
         for (int s = 0; s < 16; ++s) oacc[t] = adp_mfma32(vr[t][s], st[s], oacc[t]);
       }
     }
+  };
+  float ka[DMAX / 2], kb[DMAX / 2];
+  load_kc(ka, 0);
+  for (int j0 = 0; j0 < m; j0 += 64) {  // two tiles per trip: the register sets swap roles statically
+    tile(ka, kb, j0);
+    if (j0 + 32 < m) tile(kb, ka, j0 + 32);
   }
   const float inv = (lrun > 0.0f) ? 1.0f / lrun : 0.0f;
   float* oh = o + (b * H + h) * (int64_t)D * n;
@@ -239,23 +272,33 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* q, const 
 
   const int i_beg = sp * tps * 32;
   const int i_end = (i_beg + tps * 32 < n) ? i_beg + tps * 32 : n;
-  for (int i0 = i_beg; i0 < i_end; i0 += 32) {
+  // Register plan per 32-query tile (everything else would spill: K/V fragments 64 + accumulators 64 are resident):
+  //   top    : dO columns and t = 0 row fragments + lse / delta of THIS tile, Q columns of the NEXT tile
+  //   S      : 32 MFMAs on the Q columns requested one tile ago (cover the latency of the loads above)
+  //   dP     : 32 MFMAs on the dO columns; then the t = 1 row fragments are requested (covered by the t = 0 products)
+  auto load_q = [&](float (&qc)[DMAX / 2], int i0) { ld_cols<D64>(qh, n, hi, l31, D, i0, i0 + 32 <= n, qc); };
+  auto tile = [&](const float (&qc)[DMAX / 2], float (&qn)[DMAX / 2], int i0) {
     const bool full = i0 + 32 <= n;
-    const bool iok = i0 + l31 < n;
-    const int qcol = hi * n + (iok ? i0 + l31 : n - 1);
+    float dc[DMAX / 2], dor[16], qr[16], ls[16], dl[16];
+    ld_cols<D64>(doh, n, hi, l31, D, i0, full, dc);
+    ld_row16<D64>(doh, n, l31, D, i0, hi, full && vec, dor);
+    ld_row16<D64>(qh, n, l31, D, i0, hi, full && vec, qr);
+    ld_vec16(lh, i0, hi, n, full && vec, ls);
+    ld_vec16(dlh, i0, hi, n, full && vec, dl);
+    if (i0 + 32 < i_end) load_q(qn, i0 + 32);
+#ifndef ADP_EMULATE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     // S tile: A[i'=i][kk=d] = q[d][i], B = kf ; dP tile: A = dO[d][i], B = vf
     f32x16 sa, dpa;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sa[r] = dpa[r] = 0.0f;
 #pragma unroll
     for (int s = 0; s < DMAX / 2; ++s)
-      if (D64 || 2 * s < D) {
-        sa = adp_mfma32(ld_col<D64>(qh, n, s, hi, D, qcol, iok), kf[s], sa);
-        dpa = adp_mfma32(ld_col<D64>(doh, n, s, hi, D, qcol, iok), vf[s], dpa);
-      }
-    float ls[16], dl[16];
-    ld_vec16(lh, i0, hi, n, full && vec, ls);
-    ld_vec16(dlh, i0, hi, n, full && vec, dl);
+      if (D64 || 2 * s < D) sa = adp_mfma32(qc[s], kf[s], sa);
+#pragma unroll
+    for (int s = 0; s < DMAX / 2; ++s)
+      if (D64 || 2 * s < D) dpa = adp_mfma32(dc[s], vf[s], dpa);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const bool ok = (full || i0 + acc_row(r, hi) < n) && kok;
@@ -263,19 +306,32 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* q, const 
       sa[r] = p;                                  // P[i][j]
       dpa[r] = p * (dpa[r] - dl[r]) * scale;      // dS[i][j]
     }
+#ifndef ADP_EMULATE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    float dor1[16], qr1[16];
+    if (D64 || 32 < D) {
+      ld_row16<D64>(doh, n, 32 + l31, D, i0, hi, full && vec, dor1);
+      ld_row16<D64>(qh, n, 32 + l31, D, i0, hi, full && vec, qr1);
+    }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      if (D64 || 32 * t < D) {
-        float dor[16], qr[16];
-        ld_row16<D64>(doh, n, 32 * t + l31, D, i0, hi, full && vec, dor);
-        ld_row16<D64>(qh, n, 32 * t + l31, D, i0, hi, full && vec, qr);
+    for (int s = 0; s < 16; ++s) {
+      dva[0] = adp_mfma32(dor[s], sa[s], dva[0]);
+      dka[0] = adp_mfma32(qr[s], dpa[s], dka[0]);
+    }
+    if (D64 || 32 < D) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          dva[t] = adp_mfma32(dor[s], sa[s], dva[t]);
-          dka[t] = adp_mfma32(qr[s], dpa[s], dka[t]);
-        }
+      for (int s = 0; s < 16; ++s) {
+        dva[1] = adp_mfma32(dor1[s], sa[s], dva[1]);
+        dka[1] = adp_mfma32(qr1[s], dpa[s], dka[1]);
       }
     }
+  };
+  float qa[DMAX / 2], qb[DMAX / 2];
+  if (i_beg < i_end) load_q(qa, i_beg);
+  for (int i0 = i_beg; i0 < i_end; i0 += 64) {
+    tile(qa, qb, i0);
+    if (i0 + 32 < i_end) tile(qb, qa, i0 + 32);
   }
   float* dkh = (nsplit > 1 ? dk + sp * pstride : dk) + b * kvbs + h * (int64_t)D * m;
   float* dvh = (nsplit > 1 ? dv + sp * pstride : dv) + b * kvbs + h * (int64_t)D * m;
@@ -343,23 +399,31 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* q, const f
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqa[t][r] = 0.0f;
 
-  for (int j0 = 0; j0 < m; j0 += 32) {
+  // K / V column fragments (A operands of S^T and dP^T) are requested one tile ahead into the other register set
+  auto load_c = [&](float (&kc)[DMAX / 2], float (&vc)[DMAX / 2], int j0) {
+    ld_cols<D64>(kh, m, hi, l31, D, j0, j0 + 32 <= m, kc);
+    ld_cols<D64>(vh, m, hi, l31, D, j0, j0 + 32 <= m, vc);
+  };
+  auto tile = [&](const float (&kc)[DMAX / 2], const float (&vc)[DMAX / 2], float (&kn)[DMAX / 2],
+                  float (&vn)[DMAX / 2], int j0) {
     const bool full = j0 + 32 <= m;
-    const bool kok = j0 + l31 < m;
-    const int kcol = hi * m + (kok ? j0 + l31 : m - 1);
+    float kr[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (D64 || 32 * t < D) ld_row16<D64>(kh, m, 32 * t + l31, D, j0, hi, full && vec, kr[t]);
+    if (j0 + 32 < m) load_c(kn, vn, j0 + 32);
+#ifndef ADP_EMULATE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     f32x16 st, dpt;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = dpt[r] = 0.0f;
 #pragma unroll
     for (int s = 0; s < DMAX / 2; ++s)
       if (D64 || 2 * s < D) {
-        st = adp_mfma32(ld_col<D64>(kh, m, s, hi, D, kcol, kok), qf[s], st);    // S^T[j][i]
-        dpt = adp_mfma32(ld_col<D64>(vh, m, s, hi, D, kcol, kok), df[s], dpt);  // dP^T[j][i] = sum_d v[d][j] dO[d][i]
+        st = adp_mfma32(kc[s], qf[s], st);    // S^T[j][i]
+        dpt = adp_mfma32(vc[s], df[s], dpt);  // dP^T[j][i] = sum_d v[d][j] dO[d][i]
       }
-    float kr[2][16];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      if (D64 || 32 * t < D) ld_row16<D64>(kh, m, 32 * t + l31, D, j0, hi, full && vec, kr[t]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const bool ok = (full || j0 + acc_row(r, hi) < m) && qok;
@@ -373,6 +437,12 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* q, const f
         for (int s = 0; s < 16; ++s) dqa[t] = adp_mfma32(kr[t][s], dpt[s], dqa[t]);
       }
     }
+  };
+  float ka[DMAX / 2], va[DMAX / 2], kb[DMAX / 2], vb[DMAX / 2];
+  load_c(ka, va, 0);
+  for (int j0 = 0; j0 < m; j0 += 64) {
+    tile(ka, va, kb, vb, j0);
+    if (j0 + 32 < m) tile(kb, vb, ka, va, j0 + 32);
   }
   float* dqh = dq + b * qbs + h * (int64_t)D * n;
 #pragma unroll
@@ -387,8 +457,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* q, const f
 // query split of the key-major pass: enough waves to cover the chip when there are few key tiles
 int64_t kv_nsplit(int64_t B, int64_t H, int64_t n, int64_t m) {
   const int64_t ktiles = (m + 31) / 32, qtiles = (n + 31) / 32;
-  int64_t ns = 1024 / (B * H * ktiles);          // target >= ~1024 waves (4 per CU)
-  if (ns > qtiles / 2) ns = qtiles / 2;          // at least two query tiles per wave
+  int64_t ns = 512 / (B * H * ktiles);           // target >= ~512 waves (2 per CU); every split costs a partial copy
+  if (ns > qtiles / 4) ns = qtiles / 4;          // at least four query tiles per wave
   if (ns > 64) ns = 64;
   if (ns < 1) ns = 1;
   return ns;
