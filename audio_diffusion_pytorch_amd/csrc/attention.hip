@@ -457,9 +457,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* q, const f
 // query split of the key-major pass: enough waves to cover the chip when there are few key tiles
 int64_t kv_nsplit(int64_t B, int64_t H, int64_t n, int64_t m) {
   const int64_t ktiles = (m + 31) / 32, qtiles = (n + 31) / 32;
-  int64_t ns = 512 / (B * H * ktiles);           // target >= ~512 waves (2 per CU); every split costs a partial copy
-  if (ns > qtiles / 4) ns = qtiles / 4;          // at least four query tiles per wave
-  if (ns > 64) ns = 64;
+  int64_t ns = 1024 / (B * H * ktiles);          // target ~1024 waves (4 per CU) ...
+  if (ns > qtiles / 4) ns = qtiles / 4;          // ... of at least four query tiles each,
+  if (ns > 32) ns = 32;                          // and a bounded number of partial copies to sum
   if (ns < 1) ns = 1;
   return ns;
 }

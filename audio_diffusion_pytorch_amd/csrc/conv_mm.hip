@@ -1,5 +1,6 @@
 // Dispatch of the implicit-GEMM Conv1d family (kernel: conv_mm_impl.h; one translation unit per block tile:
 // conv_mm_m64.hip, conv_mm_m32.hip).
+#include <stdlib.h>
 #include "adp_rt.h"
 #include "adp.h"
 #include "conv_internal.h"
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(adp_conv_desc d
 // has 64 tiles of 32 x 64) the reduction over input channels is cut into 2 / 4 / 8 slices run by separate
 // workgroups (>= 4 chunks of 32 channels each), combined by conv_splitk_reduce_kernel (deterministic order).
 int64_t adp_conv_mm_ksplit(const adp_conv_desc& d) {
-  if (d.store != 0) return 1;  // pixel-shuffle / pooled stores keep their in-kernel epilogue
+  static const bool off = getenv("ADP_MM_NO_KSPLIT") != nullptr;  // A/B switch for kernel work
+  if (off || d.store != 0) return 1;  // pixel-shuffle / pooled stores keep their in-kernel epilogue
   const int64_t bm = mm_use64(d) ? 64 : 32;
   const int64_t blocks = (d.M / bm) * adp_cdiv(d.N, 64) * d.B;
   const int64_t nchunks = d.R / (d.stride == 4 ? 16 : MM_BKT);

@@ -34,6 +34,7 @@
 //   * the 1-D grid is decoded XCD-aware: workgroup id -> XCD id%8 (round-robin dispatch), so ids are permuted
 //     to give each XCD a contiguous range of weight row tiles; its 4 MiB L2 then holds 1/8 of the weights.
 #pragma once
+#include <stdlib.h>
 #include "adp_rt.h"
 #include "adp.h"
 #include "conv_internal.h"
@@ -46,6 +47,9 @@ constexpr int MM_BN = 64;         // output positions per block
 // loaders' critical path, so those variants get twice the loaders -- except the one-chunk 32-row blocks of the
 // HBM-bound shallow layers, where more resident blocks per CU matter more (measured: depth 1, 54 vs 63 us)
 constexpr int mm_nld(int PRO, int BM, int PD) { return (PRO == 1 && !(BM == 32 && PD == 1)) ? 8 : 4; }
+// K groups (MMA wave groups that split the channels of a staged chunk): 8 channels each up to BKT = 32; a 64-channel
+// chunk (half the barriers per K) keeps 4 groups of 16 channels
+constexpr int mm_nkg(int BKT) { return BKT >= 32 ? 4 : BKT / 8; }
 
 // four consecutive virtual positions u0..u0+3 (u0 % 4 == 0) of a row upsampled by UP: 4 / 2 / 1 source floats
 template <int UP>
@@ -78,10 +82,11 @@ struct cmax {
 // UP: nearest-upsample factor folded into the X loader (UpsampleItem: the [B, C, L*UP] intermediate is never
 // materialised); BKT: channels per staged chunk; PD: loader prefetch distance in chunks (register stages).
 template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD>
-__global__ __launch_bounds__(((BM / 32) * (BKT / 8) + mm_nld(PRO, BM, PD)) * 64) void conv_mm_kernel(adp_conv_desc d,
-                                                                                                   int KS) {
+__global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 64) void conv_mm_kernel(adp_conv_desc d,
+                                                                                                    int KS) {
   constexpr int MM_NLD = mm_nld(PRO, BM, PD);
-  constexpr int BN = MM_BN, NKG = BKT / 8, NQM = BM / 32;
+  constexpr int BN = MM_BN, NKG = mm_nkg(BKT), NQM = BM / 32;
+  constexpr int CPK = BKT / NKG;                    // channels of a chunk one K group multiplies (8 or 16)
   constexpr int NMMA = NQM * NKG;                   // MMA waves
   constexpr int NLT = MM_NLD * 64;                  // loader threads
   constexpr int QK = BKT * KT;
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(((BM / 32) * (BKT / 8) + mm_nld(PRO, BM, PD)) * 64)
   constexpr int NA4 = (AROWS * AQ + NLT - 1) / NLT, NX4 = (BKT * XQ + NLT - 1) / NLT;
   constexpr int RED = NMMA * 2048;                   // every MMA wave parks its two accumulator tiles
   constexpr int SM = cmax<2 * (A_ELEMS + X_ELEMS), RED>::v;
-  static_assert(BKT % 8 == 0 && NKG >= 1 && NKG <= 4, "8 channels per K group");
+  static_assert(BKT % 8 == 0 && NKG >= 1 && NKG <= 4 && CPK % 8 == 0, "8 or 16 channels per K group");
   __shared__ __attribute__((aligned(16))) float smem[SM];
   __shared__ float Pa[PRO == 1 ? MM_PRO_RMAX : 1], Pb[PRO == 1 ? MM_PRO_RMAX : 1];
 
@@ -222,42 +227,45 @@ __global__ __launch_bounds__(((BM / 32) * (BKT / 8) + mm_nld(PRO, BM, PD)) * 64)
   const int xfrag = 4 * hi * XSP + l31 * S + 4 - pad;                 // + ni*32*S + (ci + c) * XSP + t * dil
   const int afrag = TR ? 4 * hi * AS + (wm0 + l31) * KT                // + (ci + c) * AS + (KT - 1 - t)
                        : (wm0 + l31) * AS + 4 * hi * KT;               // + ci * KT + (c * KT + t)
-  const int ci = kg * 8;
   if (PRO == 1) __syncthreads();
   for (int c = 0; c < nrounds; ++c) {
     __syncthreads();  // B_c: chunk c is in LDS[c & 1]
     if (c < nchunks) {
       const float* Ab = smem + (c & 1) * (A_ELEMS + X_ELEMS);
       const float* Xb = Ab + A_ELEMS;
-      if (!TR) {
-        float av[4 * KT];
-        const float* ap = Ab + afrag + ci * KT;
 #pragma unroll
-        for (int j = 0; j < KT; ++j) {
-          const f32x4 q = *reinterpret_cast<const f32x4*>(ap + 4 * j);
+      for (int sub = 0; sub < CPK / 8; ++sub) {
+        const int ci = kg * CPK + sub * 8;
+        if (!TR) {
+          float av[4 * KT];
+          const float* ap = Ab + afrag + ci * KT;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) av[4 * j + k] = q[k];
+          for (int j = 0; j < KT; ++j) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(ap + 4 * j);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) av[4 * j + k] = q[k];
+          }
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+              const float x0 = Xb[xfrag + (ci + cc) * XSP + t * dil];
+              const float x1 = Xb[xfrag + 32 * S + (ci + cc) * XSP + t * dil];
+              acc[0] = adp_mfma32(av[cc * KT + t], x0, acc[0]);
+              acc[1] = adp_mfma32(av[cc * KT + t], x1, acc[1]);
+            }
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+              const float a = Ab[afrag + (ci + cc) * AS + (KT - 1 - t)];
+              const float x0 = Xb[xfrag + (ci + cc) * XSP + t * dil];
+              const float x1 = Xb[xfrag + 32 * S + (ci + cc) * XSP + t * dil];
+              acc[0] = adp_mfma32(a, x0, acc[0]);
+              acc[1] = adp_mfma32(a, x1, acc[1]);
+            }
         }
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-          for (int t = 0; t < KT; ++t) {
-            const float x0 = Xb[xfrag + (ci + cc) * XSP + t * dil];
-            const float x1 = Xb[xfrag + 32 * S + (ci + cc) * XSP + t * dil];
-            acc[0] = adp_mfma32(av[cc * KT + t], x0, acc[0]);
-            acc[1] = adp_mfma32(av[cc * KT + t], x1, acc[1]);
-          }
-      } else {
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-          for (int t = 0; t < KT; ++t) {
-            const float a = Ab[afrag + (ci + cc) * AS + (KT - 1 - t)];
-            const float x0 = Xb[xfrag + (ci + cc) * XSP + t * dil];
-            const float x1 = Xb[xfrag + 32 * S + (ci + cc) * XSP + t * dil];
-            acc[0] = adp_mfma32(a, x0, acc[0]);
-            acc[1] = adp_mfma32(a, x1, acc[1]);
-          }
       }
     }
   }
@@ -336,7 +344,7 @@ int launch_mm(const adp_conv_desc& d, void* stream) {
   const int64_t blocks = (d.M / BM) * adp_cdiv(d.N, MM_BN) * d.B;
   const int KS = d.ws ? (int)adp_conv_mm_ksplit(d) : 1;
   ADP_LAUNCH((conv_mm_kernel<BM, KT, S, UP, TR, PRO, BKT, PD>), dim3((unsigned)blocks, (unsigned)KS),
-             dim3(((BM / 32) * (BKT / 8) + mm_nld(PRO, BM, PD)) * 64), stream, d, KS);
+             dim3(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 64), stream, d, KS);
   return ADP_LAUNCH_OK();
 }
 
@@ -344,7 +352,8 @@ int launch_mm(const adp_conv_desc& d, void* stream) {
 template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT>
 int launch_pd(const adp_conv_desc& d, void* stream) {
   const int64_t KS = d.ws ? adp_conv_mm_ksplit(d) : 1;
-  if (d.R / BKT / KS >= 4) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 2>(d, stream);
+  // (a 64-channel chunk already is two 32-channel register stages; a second one does not fit the register file)
+  if (BKT < 64 && d.R / BKT / KS >= 4) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 2>(d, stream);
   return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1>(d, stream);
 }
 

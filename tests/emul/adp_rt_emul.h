@@ -245,6 +245,13 @@ static inline T __shfl(T v, int src, int width = 64) {
   return adp_emul::shfl_idx(v, (l / width) * width + (src % width));
 }
 
+// wave vote (all 64 lanes active)
+static inline int __all(int pred) {
+  int v = pred != 0;
+  for (int o = 32; o >= 1; o >>= 1) v &= __shfl_xor(v, o);
+  return v;
+}
+
 // v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)
 static inline f32x16 adp_mfma32(float a, float b, f32x16 c) {
   const float *A, *B;
