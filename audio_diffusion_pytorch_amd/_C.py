@@ -30,7 +30,7 @@ class ConvDesc(Structure):
                                         "res", "out", "out_pre")] + \
                [(n, c_int64) for n in ("B", "R", "R1", "Lin", "M", "N", "KT", "stride", "dil", "pad", "up",
                                        "transposed", "prologue", "groups", "store", "sp", "e_bstride")] + \
-               [("ws", c_void_p)]
+               [("ws", c_void_p), ("gn_part", c_void_p)]
 
 
 class WgradDesc(Structure):
@@ -45,6 +45,7 @@ SIGNATURES = {
     "adp_launch_trace": (I, [I, ctypes.c_char_p, I]),
     "adp_launch_times": (I, [P, I]),
     "adp_conv1d_ws_bytes": (I, [POINTER(ConvDesc)]),
+    "adp_conv1d_gn_entries": (I, [POINTER(ConvDesc)]),
     "adp_conv1d": (c_int, [POINTER(ConvDesc), P]),
     "adp_conv1d_tile": (I, [POINTER(ConvDesc)]),
     "adp_conv1d_wgrad_ws_bytes": (I, [POINTER(WgradDesc)]),
@@ -52,11 +53,15 @@ SIGNATURES = {
     "adp_gn_stats_ws_bytes": (I, [I, I, I, I]),
     "adp_gn_stats": (c_int, [P, I, I, I, I, F, P, P, P]),
     "adp_gn_stats_act": (c_int, [P, I, I, I, I, F, P, P, P, P, P, P]),
+    "adp_gn_finalize": (c_int, [P, I, I, I, I, F, P, P]),
+    "adp_gn_act": (c_int, [P, P, P, P, I, I, I, I, P, P]),
     "adp_row_nsplit": (I, [I, I]),
     "adp_gn_silu_bwd_reduce": (c_int, [P, P, P, P, P, I, I, I, I, I, P, P]),
     "adp_gn_silu_bwd_apply": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, I, P]),
     "adp_gn_param_grad": (c_int, [P, I, I, I, P, P, I, P]),
     "adp_modulation_fwd": (c_int, [P, P, I, I, I, I, F, P, P, P]),
+    "adp_modulation_gn_entries": (I, [I, I, I]),
+    "adp_modulation_fwd_gn": (c_int, [P, P, I, I, I, I, F, P, P, P, P]),
     "adp_chan_ln_bwd_ws_bytes": (I, [I, I, I]),
     "adp_modulation_bwd": (c_int, [P, P, P, I, P, I, I, I, P, P, I, P, P]),
     "adp_ln_stats": (c_int, [P, I, I, I, F, P, P]),

@@ -869,6 +869,16 @@ extern "C" int64_t adp_conv1d_ws_bytes(const adp_conv_desc* dp) {
   return ks > 1 ? ks * d.B * d.M * d.N * (int64_t)sizeof(float) : 0;
 }
 
+extern "C" int64_t adp_conv1d_gn_entries(const adp_conv_desc* dp) {
+  if (!dp) return ADP_ERR_NULL;
+  const adp_conv_desc& d = *dp;
+  if (d.B <= 0 || d.R <= 0 || d.M <= 0 || d.N <= 0 || d.Lin <= 0) return ADP_ERR_SHAPE;
+  if (d.store != 0) return 0;
+  if (adp_conv_stream_eligible(d)) return adp_conv_stream_gn_entries(d);
+  if (adp_conv_mm_eligible(d)) return adp_conv_mm_ksplit(d) > 1 ? 0 : adp_cdiv(d.N, 64);  // one slice per 64-position tile
+  return 0;
+}
+
 // which tile the dispatcher picks for this problem: BM * 1000 + BN (introspection for profiling / roofline reports)
 extern "C" int64_t adp_conv1d_tile(const adp_conv_desc* dp) {
   if (!dp) return ADP_ERR_NULL;

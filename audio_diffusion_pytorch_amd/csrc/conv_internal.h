@@ -19,6 +19,7 @@ int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, fl
 // conv_stream.hip: persistent streaming kernel for the HBM-bound 32 -> 32 channel kernel-3 ConvBlock convs (depth 1)
 bool adp_conv_stream_eligible(const adp_conv_desc& d);
 int adp_conv_stream(const adp_conv_desc& d, void* stream);
+int64_t adp_conv_stream_gn_entries(const adp_conv_desc& d);  // GroupNorm partial slices per output row (gn_part)
 
 // conv_direct.hip: VALU direct convolution for the narrow (2-8 channel) ends of the U-Net
 bool adp_conv_direct_eligible(const adp_conv_desc& d);

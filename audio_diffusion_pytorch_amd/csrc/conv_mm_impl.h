@@ -287,6 +287,7 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
   // ---- epilogue (same contract as adp_conv1d's generic kernel)
   const int sp = (int)d.sp;
   const int64_t ebs = d.e_bstride ? d.e_bstride : M;
+  float vfin[2][RPW];  // final output values of this lane (GroupNorm partial statistics below)
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int n = n0 + ni * 32 + l31;
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
           if (d.res) v += d.res[o];
           d.out[o] = v;
         }
+        vfin[ni][rr] = ok ? v : 0.0f;
       } else if (d.store == 1) {
         if (ok) {
           const int64_t o = ((int64_t)b * (M / sp) + m / sp) * ((int64_t)N * sp) + (int64_t)n * sp + (m % sp);
@@ -334,6 +336,31 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
           if (d.res) v += d.res[o];
           d.out[o] = v;
         }
+      }
+    }
+  }
+  // ---- GroupNorm partial statistics of the tile just stored (store 0, no K split): per output row (mean, M2, count)
+  // over the tile's <= 64 positions = the 32 lanes of a half-wave x 2 accumulator tiles; two passes in registers
+  if (d.gn_part != nullptr && KS == 1 && d.store == 0) {
+    const int cntv = (N - n0) < BN ? (N - n0) : BN;
+    const bool ok0 = n0 + l31 < N, ok1 = n0 + 32 + l31 < N;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      float sv = vfin[0][rr] + vfin[1][rr];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) sv += __shfl_xor(sv, o, 64);
+      const float mean = sv / (float)cntv;
+      const float d0 = ok0 ? vfin[0][rr] - mean : 0.0f, d1 = ok1 ? vfin[1][rr] - mean : 0.0f;
+      float qv = d0 * d0 + d1 * d1;
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) qv += __shfl_xor(qv, o, 64);
+      if (l31 == 0) {
+        const int r = kg * RPW + rr;
+        const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float* e = d.gn_part + (((int64_t)b * M + m) * ntn + nt) * 3;
+        e[0] = mean;
+        e[1] = qv;
+        e[2] = (float)cntv;
       }
     }
   }

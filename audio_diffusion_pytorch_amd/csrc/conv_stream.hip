@@ -28,14 +28,16 @@ constexpr int ST_XQ = ST_XS / 4;
 constexpr int ST_NX4 = (ST_C * ST_XQ + 255) / 256;  // staging quads per loader thread
 
 template <bool TR, int PRO>
-__global__ __launch_bounds__(512) void conv_stream32_kernel(adp_conv_desc d, int tiles_per_b, int total_tiles) {
+__global__ __launch_bounds__(512) void conv_stream32_kernel(adp_conv_desc d, int tiles_per_b, int wpb) {
   __shared__ __attribute__((aligned(16))) float smem[2 * ST_C * ST_XS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
   const int L = (int)d.Lin;
-  // contiguous tile range of this workgroup
-  const int t_beg = (int)(((int64_t)blockIdx.x * total_tiles) / gridDim.x);
-  const int t_end = (int)(((int64_t)(blockIdx.x + 1) * total_tiles) / gridDim.x);
+  // contiguous tile range of this workgroup, inside ONE batch element (wpb workgroups per batch element): the
+  // GroupNorm partial statistics of the output are then one entry per (workgroup, MMA wave) of that element
+  const int wb = blockIdx.x / wpb, wi = blockIdx.x - wb * wpb;
+  const int t_beg = wb * tiles_per_b + (int)(((int64_t)wi * tiles_per_b) / wpb);
+  const int t_end = wb * tiles_per_b + (int)(((int64_t)(wi + 1) * tiles_per_b) / wpb);
   const int niter = t_end - t_beg;
   const int nrounds = (niter + 1) & ~1;  // the loaders run two tiles per loop trip; a ghost iteration pads odd counts
 
@@ -127,6 +129,10 @@ __global__ __launch_bounds__(512) void conv_stream32_kernel(adp_conv_desc d, int
   for (int r = 0; r < 16; ++r) bias[r] = d.bias ? d.bias[(r & 3) + 8 * (r >> 2) + 4 * hi] : 0.0f;
   const int xfrag = 4 * hi * ST_XS + 64 * wave + l31 + 4 - 1;  // + ni*32 + (8g + c) * XS + t
   const bool has_res = d.res != nullptr;
+  const bool want_gn = d.gn_part != nullptr;
+  float gs[16], gq[16];  // per-lane running sum / sum of squares of this wave's output rows (GroupNorm partials)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) gs[r] = gq[r] = 0.0f;
 #ifndef ADP_EMULATE
   // Make the weight / bias loads complete HERE.  Otherwise the first MFMA of the loop body is the first use of
   // registers that are pending on the loop-entry path only, and the compiler covers it with s_waitcnt vmcnt(0) on
@@ -189,6 +195,32 @@ __global__ __launch_bounds__(512) void conv_stream32_kernel(adp_conv_desc d, int
       }
       d.out[obase + (int64_t)m * L] = v0;
       d.out[obase + (int64_t)m * L + 32] = v1;
+      if (want_gn) {
+        gs[r] += v0 + v1;
+        gq[r] = fmaf(v0, v0, fmaf(v1, v1, gq[r]));
+      }
+    }
+  }
+  if (want_gn && niter > 0) {
+    // one (mean, M2, count) entry per output row for the 64 * niter positions this wave produced
+    const float cnt = 64.0f * (float)niter;
+    const int E = wpb * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float sv = gs[r], qv = gq[r];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {
+        sv += __shfl_xor(sv, o, 64);
+        qv += __shfl_xor(qv, o, 64);
+      }
+      if (l31 == 0) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float mean = sv / cnt;
+        float* e = d.gn_part + (((int64_t)wb * ST_C + m) * E + wi * 4 + wave) * 3;
+        e[0] = mean;
+        e[1] = fmaxf(qv - sv * mean, 0.0f);
+        e[2] = cnt;
+      }
     }
   }
 }
@@ -207,10 +239,22 @@ bool adp_conv_stream_eligible(const adp_conv_desc& d) {
   return true;
 }
 
+// workgroups per batch element: about one persistent workgroup per CU in total, each inside one batch element
+static int stream_wpb(const adp_conv_desc& d) {
+  const int tiles_per_b = (int)(d.N / ST_TN);
+  int wpb = (int)(256 / d.B);
+  if (wpb < 1) wpb = 1;
+  if (wpb > tiles_per_b) wpb = tiles_per_b;
+  return wpb;
+}
+
+int64_t adp_conv_stream_gn_entries(const adp_conv_desc& d) { return (int64_t)stream_wpb(d) * 4; }
+
 int adp_conv_stream(const adp_conv_desc& d, void* stream) {
   const int tiles_per_b = (int)(d.N / ST_TN);
-  const int total = (int)d.B * tiles_per_b;
-  const int grid = total < 256 ? total : 256;  // one persistent workgroup per CU
+  const int wpb = stream_wpb(d);
+  const int total = wpb;                       // (kernel argument: workgroups per batch element)
+  const int grid = (int)d.B * wpb;
   if (d.transposed) {
     if (d.prologue == 1)
       ADP_LAUNCH((conv_stream32_kernel<true, 1>), dim3((unsigned)grid), dim3(512), stream, d, tiles_per_b, total);

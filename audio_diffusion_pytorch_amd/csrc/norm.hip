@@ -121,6 +121,52 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, const flo
   }
 }
 
+// ---- statistics from producer-side partials: part[((b*C + c)*E + e)*3] = (mean, M2, count) ---------------------------
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* part, int64_t C, int64_t E, int64_t G, float eps,
+                                                          float* stats) {
+  __shared__ float sh[4];
+  const int64_t bg = blockIdx.x, b = bg / G, g = bg % G, Cg = C / G;
+  const float* p = part + ((b * C + g * Cg) * E) * 3;  // the group's Cg * E entries are contiguous
+  const int64_t cnt = Cg * E;
+  float s = 0.0f, n = 0.0f;
+  for (int64_t i = threadIdx.x; i < cnt; i += 256) {
+    s = fmaf(p[i * 3], p[i * 3 + 2], s);
+    n += p[i * 3 + 2];
+  }
+  s = adp_block_sum<4>(s, sh);
+  n = adp_block_sum<4>(n, sh);
+  const float mean = s / n;
+  float q = 0.0f;
+  for (int64_t i = threadIdx.x; i < cnt; i += 256) {
+    const float dm = p[i * 3] - mean;
+    q += p[i * 3 + 1] + p[i * 3 + 2] * dm * dm;
+  }
+  q = adp_block_sum<4>(q, sh);
+  if (threadIdx.x == 0) {
+    stats[bg * 2] = mean;
+    stats[bg * 2 + 1] = 1.0f / sqrtf(q / n + eps);
+  }
+}
+
+// a = SiLU(GroupNorm(x)) from finished statistics; one workgroup = 1024 elements of one (b, c) row
+__global__ __launch_bounds__(256) void gn_act_kernel(const float* x, const float* stats, const float* gamma,
+                                                     const float* beta, int64_t C, int64_t L, int64_t G, float* a) {
+  const int64_t row = blockIdx.y, b = row / C, c = row % C, g = c / (C / G);
+  const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+  const float pa = gamma[c] * rstd, pb = beta[c] - mean * pa;
+  const int64_t l0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const float* xr = x + row * L;
+  float* ar = a + row * L;
+  if (l0 + 3 < L && (L & 3) == 0) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(xr + l0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = adp_silu_fast(fmaf(v[j], pa, pb));
+    *reinterpret_cast<f32x4*>(ar + l0) = v;
+  } else {
+    for (int64_t l = l0; l < L && l < l0 + 4; ++l) ar[l] = adp_silu_fast(fmaf(xr[l], pa, pb));
+  }
+}
+
 // ---- backward of y = SiLU(GN(x)) ------------------------------------------------------------------------
 // ab[b, c, split, {A,B}] : A = sum ds*xhat, B = sum ds over the split's slice of L, ds = dact * silu'(h)
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* x, const float* dact, const float* stats,
@@ -225,7 +271,7 @@ template <int TL, int NT, int VPT>
 __global__ __launch_bounds__(NT) void chan_ln_fwd_kernel(const float* x, const float* ss, int64_t bstride, int C, int L,
                                                          float eps, float* y, float* stats, const float* gam,
                                                          const float* bet, const float* gam2, const float* bet2,
-                                                         float* y2) {
+                                                         float* y2, float* gn_part) {
   constexpr int CG = NT / TL, NW = NT / 64, GPW = 64 / TL;  // channel groups, waves, channel groups per wave
   __shared__ float red[NW][TL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -285,10 +331,30 @@ __global__ __launch_bounds__(NT) void chan_ln_fwd_kernel(const float* x, const f
     return;
   }
   const float* sb = ss + b * bstride;
+  const int ntl = (L + TL - 1) / TL;
+  const int cntp = (L - (int)blockIdx.x * TL) < TL ? (L - (int)blockIdx.x * TL) : TL;  // valid positions of this tile
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int c = cg + i * CG;
-    if (valid && c < C) yb[(int64_t)c * L] = fmaf((v[i] - mean) * rstd, 1.0f + sb[c], sb[C + c]);
+    const float yv = (valid && c < C) ? fmaf((v[i] - mean) * rstd, 1.0f + sb[c], sb[C + c]) : 0.0f;
+    if (valid && c < C) yb[(int64_t)c * L] = yv;
+    if (gn_part != nullptr) {
+      // per-channel (mean, M2) of y over this tile's positions: the TL lanes p = 0..TL-1 of this channel group
+      float sy = yv;
+#pragma unroll
+      for (int o = 1; o < TL; o <<= 1) sy += __shfl_xor(sy, o, 64);
+      const float my = sy / (float)cntp;
+      const float dy = valid ? yv - my : 0.0f;
+      float qy = dy * dy;
+#pragma unroll
+      for (int o = 1; o < TL; o <<= 1) qy += __shfl_xor(qy, o, 64);
+      if (p == 0 && c < C) {
+        float* e = gn_part + (((int64_t)b * C + c) * ntl + blockIdx.x) * 3;
+        e[0] = my;
+        e[1] = qy;
+        e[2] = (float)cntp;
+      }
+    }
   }
 }
 
@@ -380,25 +446,26 @@ constexpr int64_t LN_CMAX = 1024;
 
 int launch_ln_fwd(const float* x, const float* ss, int64_t bstride, int64_t B, int64_t C, int64_t L, float eps, float* y,
                   float* stats, void* stream, const float* gam = nullptr, const float* bet = nullptr,
-                  const float* gam2 = nullptr, const float* bet2 = nullptr, float* y2 = nullptr) {
+                  const float* gam2 = nullptr, const float* bet2 = nullptr, float* y2 = nullptr,
+                  float* gn_part = nullptr) {
   const LnCfg k = ln_cfg(C, B, L);
   dim3 grid((unsigned)adp_cdiv(L, k.tl), (unsigned)B);
   if (k.tl == 8)
-    ADP_LAUNCH((chan_ln_fwd_kernel<8, 1024, 8>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
+    ADP_LAUNCH((chan_ln_fwd_kernel<8, 1024, 8>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2, gn_part);
   else if (k.tl == 4)
-    ADP_LAUNCH((chan_ln_fwd_kernel<4, 1024, 4>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
+    ADP_LAUNCH((chan_ln_fwd_kernel<4, 1024, 4>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2, gn_part);
   else if (k.tl == 64 && C <= 8)
-    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 2>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
+    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 2>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2, gn_part);
   else if (k.tl == 64 && C <= 32)
-    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 8>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
+    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 8>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2, gn_part);
   else if (k.tl == 64)
-    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 16>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
+    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 16>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2, gn_part);
   else if (k.tl == 32 && k.nt == 256)
-    ADP_LAUNCH((chan_ln_fwd_kernel<32, 256, 16>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
+    ADP_LAUNCH((chan_ln_fwd_kernel<32, 256, 16>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2, gn_part);
   else if (k.tl == 32)
-    ADP_LAUNCH((chan_ln_fwd_kernel<32, 1024, 8>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
+    ADP_LAUNCH((chan_ln_fwd_kernel<32, 1024, 8>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2, gn_part);
   else
-    ADP_LAUNCH((chan_ln_fwd_kernel<16, 1024, 16>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
+    ADP_LAUNCH((chan_ln_fwd_kernel<16, 1024, 16>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2, gn_part);
   return ADP_LAUNCH_OK();
 }
 
@@ -557,6 +624,38 @@ extern "C" int adp_modulation_fwd(const float* x, const float* ss, int64_t ss_bs
   if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
   if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
   return launch_ln_fwd(x, ss, ss_bstride, B, C, L, eps, y, stats, stream);
+}
+
+extern "C" int64_t adp_modulation_gn_entries(int64_t B, int64_t C, int64_t L) {
+  if (B <= 0 || C <= 0 || L <= 0) return ADP_ERR_SHAPE;
+  if (C > LN_CMAX) return 0;
+  return adp_cdiv(L, ln_cfg(C, B, L).tl);
+}
+
+extern "C" int adp_modulation_fwd_gn(const float* x, const float* ss, int64_t ss_bstride, int64_t B, int64_t C,
+                                     int64_t L, float eps, float* y, float* stats, float* gn_part, void* stream) {
+  if (!x || !ss || !y || !stats || !gn_part) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
+  if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
+  return launch_ln_fwd(x, ss, ss_bstride, B, C, L, eps, y, stats, stream, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       gn_part);
+}
+
+extern "C" int adp_gn_finalize(const float* part, int64_t B, int64_t C, int64_t E, int64_t G, float eps, float* stats,
+                               void* stream) {
+  if (!part || !stats) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || E <= 0 || G <= 0 || C % G) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(gn_finalize_kernel, dim3((unsigned)(B * G)), dim3(256), stream, part, C, E, G, eps, stats);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_gn_act(const float* x, const float* stats, const float* gamma, const float* beta, int64_t B,
+                          int64_t C, int64_t L, int64_t G, float* act, void* stream) {
+  if (!x || !stats || !gamma || !beta || !act) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || L <= 0 || G <= 0 || C % G || B * C > 65535) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(gn_act_kernel, dim3((unsigned)adp_cdiv(L, 1024), (unsigned)(B * C)), dim3(256), stream, x, stats, gamma,
+             beta, C, L, G, act);
+  return ADP_LAUNCH_OK();
 }
 
 extern "C" int adp_ln_stats(const float* x, int64_t B, int64_t C, int64_t L, float eps, float* stats, void* stream) {

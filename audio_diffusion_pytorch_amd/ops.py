@@ -30,8 +30,10 @@ def conv1d(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int =
            pro_stats: Optional[Tensor] = None, pro_gamma: Optional[Tensor] = None, pro_beta: Optional[Tensor] = None,
            groups: int = 1, e_scale: Optional[Tensor] = None, e_bstride: int = 0, res: Optional[Tensor] = None,
            store: int = 0, sp: int = 1, N: Optional[int] = None, out: Optional[Tensor] = None,
-           out_pre: Optional[Tensor] = None) -> Tensor:
-    """Fused implicit-GEMM conv (adp_conv1d).  w: [M, R, KT] (or [R, M, KT] when transposed)."""
+           out_pre: Optional[Tensor] = None, gn: Optional["GnPart"] = None) -> Tensor:
+    """Fused implicit-GEMM conv (adp_conv1d).  w: [M, R, KT] (or [R, M, KT] when transposed).
+    `gn`: a GnPart to fill with the GroupNorm partial statistics of the output (left empty when the dispatched kernel
+    family cannot produce them; the consumer then runs adp_gn_stats)."""
     B, R1, Lin = x.shape
     R = R1 + (x2.shape[1] if x2 is not None else 0)
     if transposed:
@@ -53,11 +55,17 @@ def conv1d(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int =
         assert tuple(out.shape) == oshape, (out.shape, oshape)
     d = ConvDesc(ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(pro_stats), ptr(pro_gamma), ptr(pro_beta), ptr(e_scale),
                  ptr(res), ptr(out), ptr(out_pre), B, R, R1, Lin, M, N, KT, stride, dil, pad, up, int(transposed), prologue, groups,
-                 store, sp, e_bstride, None)
+                 store, sp, e_bstride, None, None)
     need = _C.query("adp_conv1d_ws_bytes", byref(d))
     if need > 0:  # split-K partial tiles (small grids: the deep layers at batch 1)
         ws = _ws(need, x)
         d.ws = ptr(ws)
+    if gn is not None:
+        E = _C.query("adp_conv1d_gn_entries", byref(d))
+        if E > 0:
+            gn.part = torch.empty((B, M, E, 3), dtype=torch.float32, device=x.device)
+            gn.of = out
+            d.gn_part = ptr(gn.part)
     if _C.PROFILE is not None:  # algorithmic work of this launch: A_in + A_out (+A_res) + weights
         _C.tag(flops=2 * B * M * N * R * KT,
                bytes=4 * (B * R * Lin + out.numel() + w.numel() + (res.numel() if res is not None else 0)),
@@ -87,6 +95,37 @@ def conv1d_wgrad(x: Tensor, dy: Tensor, KT: int, *, stride: int = 1, dil: int = 
                shape=f"B{B} R{R} M{M} N{N} KT{KT} s{stride} up{up} pro{prologue}")
     _C.call("adp_conv1d_wgrad", byref(d), _C.stream())
     return dw, dbias
+
+
+class GnPart:
+    """GroupNorm partial statistics [B, C, E, 3] = (mean, M2, count) per row slice, written by the kernel that
+    PRODUCED tensor `of` (conv / Modulation epilogue), so that the consuming GroupNorm needs no pass of its own."""
+    __slots__ = ("part", "of")
+
+    def __init__(self):
+        self.part: Optional[Tensor] = None
+        self.of: Optional[Tensor] = None
+
+    def covers(self, x: Tensor) -> bool:
+        return self.part is not None and self.of is x
+
+
+def gn_finalize(part: Tensor, groups: int, eps: float = GN_EPS) -> Tensor:
+    """stats [B, G, 2] from producer-side partials (adp_gn_finalize)."""
+    B, C, E, _ = part.shape
+    stats = torch.empty((B, groups, 2), dtype=torch.float32, device=part.device)
+    _C.tag(bytes=4 * part.numel(), shape=f"B{B} C{C} E{E}")
+    _C.call("adp_gn_finalize", ptr(part), B, C, E, groups, eps, ptr(stats), _C.stream())
+    return stats
+
+
+def gn_act(x: Tensor, stats: Tensor, groups: int, gamma: Tensor, beta: Tensor) -> Tensor:
+    """SiLU(GroupNorm(x)) materialised from finished statistics (adp_gn_act)."""
+    B, C, L = x.shape
+    act = torch.empty_like(x)
+    _C.tag(bytes=8 * x.numel(), shape=f"B{B} C{C} L{L}")
+    _C.call("adp_gn_act", ptr(x), ptr(stats), ptr(gamma), ptr(beta), B, C, L, groups, ptr(act), _C.stream())
+    return act
 
 
 def gn_stats(x: Tensor, groups: int, eps: float = GN_EPS, out: Optional[Tensor] = None) -> Tensor:
@@ -134,15 +173,23 @@ def gn_silu_bwd(x: Tensor, dact: Tensor, stats: Tensor, gamma: Tensor, beta: Ten
 
 
 def modulation_fwd(x: Tensor, ss: Tensor, ss_bstride: int, eps: float = LN_EPS, y: Optional[Tensor] = None,
-                   stats: Optional[Tensor] = None):
-    """ss: 1-D view whose element [b*ss_bstride + c] is scale and [b*ss_bstride + C + c] is shift."""
+                   stats: Optional[Tensor] = None, gn: Optional[GnPart] = None):
+    """ss: 1-D view whose element [b*ss_bstride + c] is scale and [b*ss_bstride + C + c] is shift.
+    `gn`: filled with the GroupNorm partial statistics of y (the next ResnetItem's first GroupNorm input)."""
     B, C, L = x.shape
     if y is None:
         y = torch.empty_like(x)
     if stats is None:
         stats = torch.empty((B, L, 2), dtype=torch.float32, device=x.device)
     _C.tag(bytes=8 * x.numel(), shape=f"B{B} C{C} L{L}")
-    _C.call("adp_modulation_fwd", ptr(x), ptr(ss), ss_bstride, B, C, L, eps, ptr(y), ptr(stats), _C.stream())
+    E = _C.query("adp_modulation_gn_entries", B, C, L) if gn is not None else 0
+    if E > 0:
+        gn.part = torch.empty((B, C, E, 3), dtype=torch.float32, device=x.device)
+        gn.of = y
+        _C.call("adp_modulation_fwd_gn", ptr(x), ptr(ss), ss_bstride, B, C, L, eps, ptr(y), ptr(stats), ptr(gn.part),
+                _C.stream())
+    else:
+        _C.call("adp_modulation_fwd", ptr(x), ptr(ss), ss_bstride, B, C, L, eps, ptr(y), ptr(stats), _C.stream())
     return y, stats
 
 

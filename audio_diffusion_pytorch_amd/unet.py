@@ -302,6 +302,7 @@ class _Run:
         self.tape: List = []           # list of callables g -> g_prev
         self.grads: Dict[str, Tensor] = {}
         self.pnames = {id(p): n for n, p in net.named_parameters()}
+        self.gn: Optional[ops.GnPart] = None  # GroupNorm partial statistics of the tensor produced last (if any)
 
     # -- gradient destination views -------------------------------------------------------
     def g(self, p: nn.Parameter) -> Tensor:
@@ -372,15 +373,34 @@ class _Run:
         off, nout = self.net.bank_slices[key]
         return self.ss_all.view(-1)[off:], (self.dss_all.view(-1)[off:] if self.need_grad else None)
 
+    # -- GroupNorm statistics: from the producer's epilogue partials when the producing kernel wrote them --------
+    def gn_stats_of(self, x: Tensor) -> Tensor:
+        """stats [B, G, 2] of x: one tiny launch over the partials its producer left (conv / Modulation epilogue),
+        else the two-launch statistics pass over the tensor."""
+        G = self.net.groups
+        if self.gn is not None and self.gn.covers(x):
+            return ops.gn_finalize(self.gn.part, G)
+        return ops.gn_stats(x, G)
+
+    def gn_stats_act_of(self, x: Tensor, gnp):
+        """(stats, SiLU(GroupNorm(x)) materialised) for the wide layers."""
+        G = self.net.groups
+        if self.gn is not None and self.gn.covers(x):
+            st = ops.gn_finalize(self.gn.part, G)
+            return st, ops.gn_act(x, st, G, gnp.weight, gnp.bias)
+        return ops.gn_stats_act(x, G, gnp.weight, gnp.bias)
+
     # -- items ----------------------------------------------------------------------------
     def resnet(self, p, x: Tensor) -> Tensor:
         G = self.net.groups
         if x.shape[1] >= ACT_MATERIALIZE_MIN_C:
             return self.resnet_wide(p, x)
-        st1 = ops.gn_stats(x, G)
+        st1 = self.gn_stats_of(x)
+        self.gn = ops.GnPart()
         h1 = ops.conv1d(x, p.conv1.weight, p.conv1.bias, pad=1, prologue=1, pro_stats=st1, pro_gamma=p.gn1.weight,
-                        pro_beta=p.gn1.bias, groups=G)
-        st2 = ops.gn_stats(h1, G)
+                        pro_beta=p.gn1.bias, groups=G, gn=self.gn)
+        st2 = self.gn_stats_of(h1)
+        self.gn = None
         y = ops.conv1d(h1, p.conv2.weight, p.conv2.bias, pad=1, prologue=1, pro_stats=st2, pro_gamma=p.gn2.weight,
                        pro_beta=p.gn2.bias, groups=G, res=x)
         if self.need_grad:
@@ -404,9 +424,11 @@ class _Run:
         the statistics' second stage instead of being recomputed by each of the 8-16 conv / weight-gradient
         workgroups that stage a tile of it (the tensors are 2-8 MB here; see gn_apply_kernel in csrc/norm.hip)."""
         G = self.net.groups
-        st1, a1 = ops.gn_stats_act(x, G, p.gn1.weight, p.gn1.bias)
-        h1 = ops.conv1d(a1, p.conv1.weight, p.conv1.bias, pad=1)
-        st2, a2 = ops.gn_stats_act(h1, G, p.gn2.weight, p.gn2.bias)
+        st1, a1 = self.gn_stats_act_of(x, p.gn1)
+        self.gn = ops.GnPart()
+        h1 = ops.conv1d(a1, p.conv1.weight, p.conv1.bias, pad=1, gn=self.gn)
+        st2, a2 = self.gn_stats_act_of(h1, p.gn2)
+        self.gn = None
         y = ops.conv1d(a2, p.conv2.weight, p.conv2.bias, pad=1, res=x)
         if self.need_grad:
             def bwd(gy):
@@ -422,10 +444,11 @@ class _Run:
             self.tape.append((bwd, None))
         return y
 
-    def modulation(self, key, x: Tensor) -> Tensor:
+    def modulation(self, key, x: Tensor, feeds_resnet: bool = False) -> Tensor:
         ss, dss = self.ss(key)
         NT = self.net.bank_total
-        y, stats = ops.modulation_fwd(x, ss, NT)
+        self.gn = ops.GnPart() if feeds_resnet else None  # the next ResnetItem's first GroupNorm reads y
+        y, stats = ops.modulation_fwd(x, ss, NT, gn=self.gn)
         if self.need_grad:
             self.tape.append((lambda gy: ops.modulation_bwd(x, gy, ss, NT, stats, dss, NT), None))
         return y
@@ -455,11 +478,16 @@ class _Run:
         return attn_host.attention_item(self, p, x, context)
 
     def run_items(self, d: int, which: str, mods, x: Tensor, embedding, channels) -> Tensor:
-        for i, (t, p) in enumerate(zip(self.net.item_types[d], mods)):
+        types = self.net.item_types[d]
+        deepest = d == len(self.net.blocks) - 1
+        for i, (t, p) in enumerate(zip(types, mods)):
             if t == ITEM_RESNET:
                 x = self.resnet(p, x)
             elif t == ITEM_MODULATION:
-                x = self.modulation((d, which, i), x)
+                # the consumer of this item's output: the next item, or (last down item of the deepest block) the
+                # first up item
+                nxt = types[i + 1] if i + 1 < len(types) else (types[0] if (which == "down" and deepest) else None)
+                x = self.modulation((d, which, i), x, feeds_resnet=(nxt == ITEM_RESNET))
             elif t == ITEM_INJECT:
                 assert channels is not None and channels[d] is not None, f"Missing context `channels` at depth {d}"
                 x = self.inject(p, x, channels[d], self.ctx_index[d])
@@ -485,13 +513,14 @@ class _Run:
             assert x2 is None
             skip = x
         wd = blk.down.weight
+        self.gn = ops.GnPart()  # the first item of every depth is a ResnetItem: its GroupNorm reads h0
         if native:
             xs = x2s = None
-            h0 = ops.conv1d(x, wd, blk.down.bias, stride=f, x2=x2)
+            h0 = ops.conv1d(x, wd, blk.down.bias, stride=f, x2=x2, gn=self.gn)
         else:  # Conv1d(kernel = stride = f) == 1x1 conv over the space-to-depth view of its input
             xs = ops.unshuffle(x, f)
             x2s = ops.unshuffle(x2, f) if x2 is not None else None
-            h0 = ops.conv1d(xs, wd.view(wd.shape[0], -1, 1), blk.down.bias, x2=x2s)
+            h0 = ops.conv1d(xs, wd.view(wd.shape[0], -1, 1), blk.down.bias, x2=x2s, gn=self.gn)
         tape_mark_down = len(self.tape)
         h = self.run_items(d, "down", blk.items_down, h0, embedding, channels)
         h = self.block(d + 1, h, None, embedding, channels, True)
@@ -502,8 +531,11 @@ class _Run:
             sc, dsc = self.ss((d, "skip"))
             u = torch.empty((x.shape[0], blk.out_ch, h.shape[2] * f), dtype=torch.float32, device=x.device) \
                 if self.need_grad else None
-            y = ops.conv1d(h, blk.up.weight, blk.up.bias, pad=1, up=f, e_scale=sc, e_bstride=NT, res=skip, out_pre=u)
+            self.gn = ops.GnPart() if d > 0 else None  # the outer depth's first up item (a ResnetItem) reads y
+            y = ops.conv1d(h, blk.up.weight, blk.up.bias, pad=1, up=f, e_scale=sc, e_bstride=NT, res=skip, out_pre=u,
+                           gn=self.gn)
         else:
+            self.gn = None
             # SkipCat: y = Conv1x1(cat[skip * 2^-1/2, u]) -- the concat is the conv's two input pointers
             u = ops.conv1d(h, blk.up.weight, blk.up.bias, pad=1, up=f)
             skip_s = ops.axpby(SKIP_CAT_SCALE, skip)

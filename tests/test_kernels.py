@@ -605,6 +605,52 @@ def test_attention_fwd_bwd(dev, B, H, D, n, m):
     assert rel_err(dkv, dkv_ref) < TOL
 
 
+@pytest.mark.parametrize("B,R,M,L,KT,stride,up", [
+    (2, 32, 64, 200, 3, 1, 1),     # conv_mm, ragged last tile
+    (1, 64, 32, 128, 1, 1, 1),     # conv_mm 1x1
+    (2, 32, 32, 512, 3, 1, 1),     # conv_stream32 (persistent, per-workgroup slices)
+    (3, 32, 32, 1280, 3, 1, 1),    # conv_stream32, batch that does not divide the CU count
+    (1, 32, 64, 256, 4, 4, 1),     # DownsampleItem (kernel = stride = 4)
+    (1, 64, 32, 96, 3, 1, 2),      # UpsampleItem loader with the SkipModulate epilogue
+])
+def test_groupnorm_statistics_from_conv_epilogue(dev, B, R, M, L, KT, stride, up):
+    """adp_conv_desc.gn_part: the conv epilogue's per-row (mean, M2, count) slices + adp_gn_finalize reproduce
+    adp_gn_stats of the output tensor (so the consumer GroupNorm needs no statistics pass), also with the residual /
+    e_scale epilogue terms folded in; and adp_gn_act matches the fused statistics+activation path."""
+    G = 8
+    pad = 1 if KT == 3 else 0
+    x, w, b = rnd(B, R, L, seed=1), rnd(M, R, KT, seed=2, scale=0.3), rnd(M, seed=3)
+    N = ops.conv_out_len(L, KT, stride, 1, pad, up)
+    res, sc = rnd(B, M, N, seed=4) + 0.5, rnd(B * M, seed=5)
+    gn = ops.GnPart()
+    out = ops.conv1d(x.to(dev), w.to(dev), b.to(dev), stride=stride, pad=pad, up=up, e_scale=sc.to(dev) if up > 1 else None,
+                     res=res.to(dev), gn=gn)
+    assert gn.part is not None and gn.covers(out), "this shape is meant to produce epilogue statistics"
+    assert gn.part.shape[:2] == (B, M) and torch.isfinite(gn.part).all()
+    assert gn.part[..., 2].sum(dim=2).eq(N).all()        # the slices of every row cover each position exactly once
+    st = ops.gn_finalize(gn.part, G)
+    ref = ops.gn_stats(out, G)
+    assert rel_err(st[..., 0], ref[..., 0]) < 1e-4 or (st[..., 0] - ref[..., 0]).abs().max() < 1e-5
+    assert rel_err(st[..., 1], ref[..., 1]) < 1e-5
+    gamma, beta = rnd(M, seed=6) * 0.5 + 1, rnd(M, seed=7) * 0.1
+    act = ops.gn_act(out, st, G, gamma.to(dev), beta.to(dev))
+    assert rel_err(act, ref_gn_silu(out.cpu(), G, gamma, beta)) < TOL
+
+
+@pytest.mark.parametrize("B,C,L", [(2, 8, 300), (1, 32, 130), (2, 64, 96), (1, 128, 70), (1, 256, 40), (2, 512, 24),
+                                   (1, 1024, 20)])
+def test_groupnorm_statistics_from_modulation(dev, B, C, L):
+    """adp_modulation_fwd_gn: the Modulation kernel also reports the GroupNorm partial statistics of its output."""
+    x, ss = rnd(B, C, L, seed=1) * 1.5 + 0.3, rnd(B * 2 * C, seed=2) * 0.3
+    gn = ops.GnPart()
+    y, _ = ops.modulation_fwd(x.to(dev), ss.to(dev), 2 * C, gn=gn)
+    y0, _ = ops.modulation_fwd(x.to(dev), ss.to(dev), 2 * C)
+    assert gn.covers(y) and torch.equal(y.cpu(), y0.cpu())
+    assert gn.part[..., 2].sum(dim=2).eq(L).all()
+    st, ref = ops.gn_finalize(gn.part, 8), ops.gn_stats(y, 8)
+    assert (st[..., 0] - ref[..., 0]).abs().max() < 1e-5 and rel_err(st[..., 1], ref[..., 1]) < 1e-5
+
+
 @pytest.mark.parametrize("B,C,L,G", [(2, 16, 300, 8), (1, 64, 1030, 8), (2, 512, 24, 8)])
 def test_gn_stats_act(dev, B, C, L, G):
     """adp_gn_stats_act: statistics + materialised SiLU(GroupNorm(x)) (the wide-layer path)."""

@@ -183,7 +183,7 @@ def _conv_desc(dev, B=1, R=8, M=8, L=64, KT=3, **over):
     out = torch.empty(2, 64, 64).to(dev)
     f = dict(x=x.data_ptr(), x2=None, w=w.data_ptr(), bias=None, pro_stats=None, pro_gamma=None, pro_beta=None,
              e_scale=None, res=None, out=out.data_ptr(), out_pre=None, B=B, R=R, R1=R, Lin=L, M=M, N=L, KT=KT, stride=1,
-             dil=1, pad=1, up=1, transposed=0, prologue=0, groups=1, store=0, sp=1, e_bstride=0, ws=None)
+             dil=1, pad=1, up=1, transposed=0, prologue=0, groups=1, store=0, sp=1, e_bstride=0, ws=None, gn_part=None)
     f.update(over)
     d = ConvDesc(*[f[n] for n, _ in ConvDesc._fields_])
     d._keep = (x, w, out)
