@@ -54,14 +54,13 @@ SIGNATURES = {
     "adp_gn_stats": (c_int, [P, I, I, I, I, F, P, P, P]),
     "adp_gn_stats_act": (c_int, [P, I, I, I, I, F, P, P, P, P, P, P]),
     "adp_gn_finalize": (c_int, [P, I, I, I, I, F, P, P]),
+    "adp_gn_finalize_act": (c_int, [P, P, I, I, I, I, I, F, P, P, P, P, P]),
     "adp_gn_act": (c_int, [P, P, P, P, I, I, I, I, P, P]),
     "adp_row_nsplit": (I, [I, I]),
     "adp_gn_silu_bwd_reduce": (c_int, [P, P, P, P, P, I, I, I, I, I, P, P]),
     "adp_gn_silu_bwd_apply": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, I, P]),
     "adp_gn_param_grad": (c_int, [P, I, I, I, P, P, I, P]),
     "adp_modulation_fwd": (c_int, [P, P, I, I, I, I, F, P, P, P]),
-    "adp_modulation_gn_entries": (I, [I, I, I]),
-    "adp_modulation_fwd_gn": (c_int, [P, P, I, I, I, I, F, P, P, P, P]),
     "adp_chan_ln_bwd_ws_bytes": (I, [I, I, I]),
     "adp_modulation_bwd": (c_int, [P, P, P, I, P, I, I, I, P, P, I, P, P]),
     "adp_ln_stats": (c_int, [P, I, I, I, F, P, P]),

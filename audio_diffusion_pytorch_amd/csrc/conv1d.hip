@@ -873,7 +873,7 @@ extern "C" int64_t adp_conv1d_gn_entries(const adp_conv_desc* dp) {
   if (!dp) return ADP_ERR_NULL;
   const adp_conv_desc& d = *dp;
   if (d.B <= 0 || d.R <= 0 || d.M <= 0 || d.N <= 0 || d.Lin <= 0) return ADP_ERR_SHAPE;
-  if (d.store != 0) return 0;
+  if (d.store != 0 || d.M % 4 != 0) return 0;
   if (adp_conv_stream_eligible(d)) return adp_conv_stream_gn_entries(d);
   if (adp_conv_mm_eligible(d)) return adp_conv_mm_ksplit(d) > 1 ? 0 : adp_cdiv(d.N, 64);  // one slice per 64-position tile
   return 0;

@@ -339,28 +339,36 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
       }
     }
   }
-  // ---- GroupNorm partial statistics of the tile just stored (store 0, no K split): per output row (mean, M2, count)
-  // over the tile's <= 64 positions = the 32 lanes of a half-wave x 2 accumulator tiles; two passes in registers
+  // ---- GroupNorm partial statistics of the tile just stored (store 0, no K split): one (mean, M2, count) entry per
+  // ROW QUAD (the 4 consecutive output channels a lane holds in accumulator registers 4q .. 4q+3) over the tile's
+  // <= 64 positions: 8 values per lane, then the 32 lanes of the half-wave; two passes in registers.
   if (d.gn_part != nullptr && KS == 1 && d.store == 0) {
     const int cntv = (N - n0) < BN ? (N - n0) : BN;
     const bool ok0 = n0 + l31 < N, ok1 = n0 + 32 + l31 < N;
+    const float fcnt = 4.0f * (float)cntv;
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      float sv = vfin[0][rr] + vfin[1][rr];
+    for (int q = 0; q < RPW / 4; ++q) {
+      float sv = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sv += vfin[0][4 * q + j] + vfin[1][4 * q + j];
 #pragma unroll
       for (int o = 1; o < 32; o <<= 1) sv += __shfl_xor(sv, o, 64);
-      const float mean = sv / (float)cntv;
-      const float d0 = ok0 ? vfin[0][rr] - mean : 0.0f, d1 = ok1 ? vfin[1][rr] - mean : 0.0f;
-      float qv = d0 * d0 + d1 * d1;
+      const float mean = sv / fcnt;
+      float qv = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d0 = ok0 ? vfin[0][4 * q + j] - mean : 0.0f, d1 = ok1 ? vfin[1][4 * q + j] - mean : 0.0f;
+        qv = fmaf(d0, d0, fmaf(d1, d1, qv));
+      }
 #pragma unroll
       for (int o = 1; o < 32; o <<= 1) qv += __shfl_xor(qv, o, 64);
       if (l31 == 0) {
-        const int r = kg * RPW + rr;
-        const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float* e = d.gn_part + (((int64_t)b * M + m) * ntn + nt) * 3;
+        const int r = kg * RPW + 4 * q;
+        const int m = m0 + wm0 + 8 * (r >> 2) + 4 * hi;  // first channel of the quad
+        float* e = d.gn_part + (((int64_t)b * (M / 4) + (m >> 2)) * ntn + nt) * 3;
         e[0] = mean;
         e[1] = qv;
-        e[2] = (float)cntv;
+        e[2] = fcnt;
       }
     }
   }

@@ -202,21 +202,23 @@ __global__ __launch_bounds__(512) void conv_stream32_kernel(adp_conv_desc d, int
     }
   }
   if (want_gn && niter > 0) {
-    // one (mean, M2, count) entry per output row for the 64 * niter positions this wave produced
-    const float cnt = 64.0f * (float)niter;
+    // one (mean, M2, count) entry per ROW QUAD (accumulator registers 4q .. 4q+3 = 4 consecutive channels) for the
+    // 64 * niter positions this wave produced
+    const float cnt = 4.0f * 64.0f * (float)niter;
     const int E = wpb * 4;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float sv = gs[r], qv = gq[r];
+    for (int q = 0; q < 4; ++q) {
+      float sv = gs[4 * q] + gs[4 * q + 1] + gs[4 * q + 2] + gs[4 * q + 3];
+      float qv = gq[4 * q] + gq[4 * q + 1] + gq[4 * q + 2] + gq[4 * q + 3];
 #pragma unroll
       for (int o = 1; o < 32; o <<= 1) {
         sv += __shfl_xor(sv, o, 64);
         qv += __shfl_xor(qv, o, 64);
       }
       if (l31 == 0) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int m = 8 * q + 4 * hi;  // first channel of the quad
         const float mean = sv / cnt;
-        float* e = d.gn_part + (((int64_t)wb * ST_C + m) * E + wi * 4 + wave) * 3;
+        float* e = d.gn_part + (((int64_t)wb * (ST_C / 4) + (m >> 2)) * E + wi * 4 + wave) * 3;
         e[0] = mean;
         e[1] = fmaxf(qv - sv * mean, 0.0f);
         e[2] = cnt;

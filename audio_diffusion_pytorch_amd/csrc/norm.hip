@@ -121,30 +121,72 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, const flo
   }
 }
 
-// ---- statistics from producer-side partials: part[((b*C + c)*E + e)*3] = (mean, M2, count) ---------------------------
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* part, int64_t C, int64_t E, int64_t G, float eps,
-                                                          float* stats) {
-  __shared__ float sh[4];
-  const int64_t bg = blockIdx.x, b = bg / G, g = bg % G, Cg = C / G;
-  const float* p = part + ((b * C + g * Cg) * E) * 3;  // the group's Cg * E entries are contiguous
-  const int64_t cnt = Cg * E;
+// ---- statistics from producer-side partials ------------------------------------------------------------------------
+// part[((b * C/4 + cq) * E + e) * 3 + {0,1,2}] = (mean, M2, count) of slice e of the 4-channel row quad cq of batch
+// element b.  Chan's combination over the (C/G)/4 quads x E slices of a group (contiguous in memory), one wave.
+__device__ __forceinline__ void gn_combine_wave(const float* p, int64_t cnt, int lane, float eps, float& mean,
+                                                float& rstd) {
   float s = 0.0f, n = 0.0f;
-  for (int64_t i = threadIdx.x; i < cnt; i += 256) {
+  for (int64_t i = lane; i < cnt; i += 64) {
     s = fmaf(p[i * 3], p[i * 3 + 2], s);
     n += p[i * 3 + 2];
   }
-  s = adp_block_sum<4>(s, sh);
-  n = adp_block_sum<4>(n, sh);
-  const float mean = s / n;
+  s = adp_wave_sum(s);
+  n = adp_wave_sum(n);
+  mean = s / n;
   float q = 0.0f;
-  for (int64_t i = threadIdx.x; i < cnt; i += 256) {
+  for (int64_t i = lane; i < cnt; i += 64) {
     const float dm = p[i * 3] - mean;
     q += p[i * 3 + 1] + p[i * 3 + 2] * dm * dm;
   }
-  q = adp_block_sum<4>(q, sh);
+  q = adp_wave_sum(q);
+  rstd = 1.0f / sqrtf(q / n + eps);
+}
+
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* part, int64_t C, int64_t E, int64_t G, float eps,
+                                                         float* stats) {
+  const int64_t bg = blockIdx.x, b = bg / G, g = bg % G, Qg = (C / G) / 4;
+  float mean, rstd;
+  gn_combine_wave(part + ((b * (C / 4) + g * Qg) * E) * 3, Qg * E, threadIdx.x, eps, mean, rstd);
   if (threadIdx.x == 0) {
     stats[bg * 2] = mean;
-    stats[bg * 2 + 1] = 1.0f / sqrtf(q / n + eps);
+    stats[bg * 2 + 1] = rstd;
+  }
+}
+
+// Statistics from the producer's partials AND the materialised activation in ONE launch (wide layers, few slices per
+// row): every workgroup (1024 elements of one (b, c) row) combines its group's Cg * E entries itself -- a few
+// hundred at these sizes -- and the first workgroup of each group publishes (mean, rstd) for the backward pass.
+__global__ __launch_bounds__(256) void gn_finalize_act_kernel(const float* x, const float* part, const float* gamma,
+                                                              const float* beta, int64_t C, int64_t L, int64_t G,
+                                                              int64_t E, float eps, float* stats, float* a) {
+  __shared__ float st[2];
+  const int64_t row = blockIdx.y, b = row / C, c = row % C, Cg = C / G, g = c / Cg, bg = b * G + g;
+  if (threadIdx.x < 64) {
+    const int64_t Qg = Cg / 4;
+    float mean, rstd;
+    gn_combine_wave(part + ((b * (C / 4) + g * Qg) * E) * 3, Qg * E, threadIdx.x, eps, mean, rstd);
+    if (threadIdx.x == 0) {
+      st[0] = mean;
+      st[1] = rstd;
+      if (c == g * Cg && blockIdx.x == 0) {
+        stats[bg * 2] = mean;
+        stats[bg * 2 + 1] = rstd;
+      }
+    }
+  }
+  __syncthreads();
+  const float pa = gamma[c] * st[1], pb = beta[c] - st[0] * pa;
+  const int64_t l0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const float* xr = x + row * L;
+  float* ar = a + row * L;
+  if (l0 + 3 < L && (L & 3) == 0) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(xr + l0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = adp_silu_fast(fmaf(v[j], pa, pb));
+    *reinterpret_cast<f32x4*>(ar + l0) = v;
+  } else {
+    for (int64_t l = l0; l < L && l < l0 + 4; ++l) ar[l] = adp_silu_fast(fmaf(xr[l], pa, pb));
   }
 }
 
@@ -271,7 +313,7 @@ template <int TL, int NT, int VPT>
 __global__ __launch_bounds__(NT) void chan_ln_fwd_kernel(const float* x, const float* ss, int64_t bstride, int C, int L,
                                                          float eps, float* y, float* stats, const float* gam,
                                                          const float* bet, const float* gam2, const float* bet2,
-                                                         float* y2, float* gn_part) {
+                                                         float* y2) {
   constexpr int CG = NT / TL, NW = NT / 64, GPW = 64 / TL;  // channel groups, waves, channel groups per wave
   __shared__ float red[NW][TL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -331,30 +373,10 @@ __global__ __launch_bounds__(NT) void chan_ln_fwd_kernel(const float* x, const f
     return;
   }
   const float* sb = ss + b * bstride;
-  const int ntl = (L + TL - 1) / TL;
-  const int cntp = (L - (int)blockIdx.x * TL) < TL ? (L - (int)blockIdx.x * TL) : TL;  // valid positions of this tile
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int c = cg + i * CG;
-    const float yv = (valid && c < C) ? fmaf((v[i] - mean) * rstd, 1.0f + sb[c], sb[C + c]) : 0.0f;
-    if (valid && c < C) yb[(int64_t)c * L] = yv;
-    if (gn_part != nullptr) {
-      // per-channel (mean, M2) of y over this tile's positions: the TL lanes p = 0..TL-1 of this channel group
-      float sy = yv;
-#pragma unroll
-      for (int o = 1; o < TL; o <<= 1) sy += __shfl_xor(sy, o, 64);
-      const float my = sy / (float)cntp;
-      const float dy = valid ? yv - my : 0.0f;
-      float qy = dy * dy;
-#pragma unroll
-      for (int o = 1; o < TL; o <<= 1) qy += __shfl_xor(qy, o, 64);
-      if (p == 0 && c < C) {
-        float* e = gn_part + (((int64_t)b * C + c) * ntl + blockIdx.x) * 3;
-        e[0] = my;
-        e[1] = qy;
-        e[2] = (float)cntp;
-      }
-    }
+    if (valid && c < C) yb[(int64_t)c * L] = fmaf((v[i] - mean) * rstd, 1.0f + sb[c], sb[C + c]);
   }
 }
 
@@ -446,26 +468,25 @@ constexpr int64_t LN_CMAX = 1024;
 
 int launch_ln_fwd(const float* x, const float* ss, int64_t bstride, int64_t B, int64_t C, int64_t L, float eps, float* y,
                   float* stats, void* stream, const float* gam = nullptr, const float* bet = nullptr,
-                  const float* gam2 = nullptr, const float* bet2 = nullptr, float* y2 = nullptr,
-                  float* gn_part = nullptr) {
+                  const float* gam2 = nullptr, const float* bet2 = nullptr, float* y2 = nullptr) {
   const LnCfg k = ln_cfg(C, B, L);
   dim3 grid((unsigned)adp_cdiv(L, k.tl), (unsigned)B);
   if (k.tl == 8)
-    ADP_LAUNCH((chan_ln_fwd_kernel<8, 1024, 8>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2, gn_part);
+    ADP_LAUNCH((chan_ln_fwd_kernel<8, 1024, 8>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
   else if (k.tl == 4)
-    ADP_LAUNCH((chan_ln_fwd_kernel<4, 1024, 4>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2, gn_part);
+    ADP_LAUNCH((chan_ln_fwd_kernel<4, 1024, 4>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
   else if (k.tl == 64 && C <= 8)
-    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 2>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2, gn_part);
+    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 2>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
   else if (k.tl == 64 && C <= 32)
-    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 8>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2, gn_part);
+    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 8>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
   else if (k.tl == 64)
-    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 16>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2, gn_part);
+    ADP_LAUNCH((chan_ln_fwd_kernel<64, 256, 16>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
   else if (k.tl == 32 && k.nt == 256)
-    ADP_LAUNCH((chan_ln_fwd_kernel<32, 256, 16>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2, gn_part);
+    ADP_LAUNCH((chan_ln_fwd_kernel<32, 256, 16>), grid, dim3(256), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
   else if (k.tl == 32)
-    ADP_LAUNCH((chan_ln_fwd_kernel<32, 1024, 8>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2, gn_part);
+    ADP_LAUNCH((chan_ln_fwd_kernel<32, 1024, 8>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
   else
-    ADP_LAUNCH((chan_ln_fwd_kernel<16, 1024, 16>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2, gn_part);
+    ADP_LAUNCH((chan_ln_fwd_kernel<16, 1024, 16>), grid, dim3(1024), stream, x, ss, bstride, (int)C, (int)L, eps, y, stats, gam, bet, gam2, bet2, y2);
   return ADP_LAUNCH_OK();
 }
 
@@ -626,26 +647,21 @@ extern "C" int adp_modulation_fwd(const float* x, const float* ss, int64_t ss_bs
   return launch_ln_fwd(x, ss, ss_bstride, B, C, L, eps, y, stats, stream);
 }
 
-extern "C" int64_t adp_modulation_gn_entries(int64_t B, int64_t C, int64_t L) {
-  if (B <= 0 || C <= 0 || L <= 0) return ADP_ERR_SHAPE;
-  if (C > LN_CMAX) return 0;
-  return adp_cdiv(L, ln_cfg(C, B, L).tl);
-}
-
-extern "C" int adp_modulation_fwd_gn(const float* x, const float* ss, int64_t ss_bstride, int64_t B, int64_t C,
-                                     int64_t L, float eps, float* y, float* stats, float* gn_part, void* stream) {
-  if (!x || !ss || !y || !stats || !gn_part) return ADP_ERR_NULL;
-  if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
-  if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
-  return launch_ln_fwd(x, ss, ss_bstride, B, C, L, eps, y, stats, stream, nullptr, nullptr, nullptr, nullptr, nullptr,
-                       gn_part);
-}
-
 extern "C" int adp_gn_finalize(const float* part, int64_t B, int64_t C, int64_t E, int64_t G, float eps, float* stats,
                                void* stream) {
   if (!part || !stats) return ADP_ERR_NULL;
-  if (B <= 0 || C <= 0 || E <= 0 || G <= 0 || C % G) return ADP_ERR_SHAPE;
-  ADP_LAUNCH(gn_finalize_kernel, dim3((unsigned)(B * G)), dim3(256), stream, part, C, E, G, eps, stats);
+  if (B <= 0 || C <= 0 || E <= 0 || G <= 0 || C % G || (C / G) % 4) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(gn_finalize_kernel, dim3((unsigned)(B * G)), dim3(64), stream, part, C, E, G, eps, stats);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_gn_finalize_act(const float* x, const float* part, int64_t B, int64_t C, int64_t L, int64_t E,
+                                   int64_t G, float eps, const float* gamma, const float* beta, float* stats,
+                                   float* act, void* stream) {
+  if (!x || !part || !gamma || !beta || !stats || !act) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || L <= 0 || E <= 0 || G <= 0 || C % G || (C / G) % 4 || B * C > 65535) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(gn_finalize_act_kernel, dim3((unsigned)adp_cdiv(L, 1024), (unsigned)(B * C)), dim3(256), stream, x, part,
+             gamma, beta, C, L, G, E, eps, stats, act);
   return ADP_LAUNCH_OK();
 }
 

@@ -63,7 +63,7 @@ def conv1d(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int =
     if gn is not None:
         E = _C.query("adp_conv1d_gn_entries", byref(d))
         if E > 0:
-            gn.part = torch.empty((B, M, E, 3), dtype=torch.float32, device=x.device)
+            gn.part = torch.empty((B, M // 4, E, 3), dtype=torch.float32, device=x.device)
             gn.of = out
             d.gn_part = ptr(gn.part)
     if _C.PROFILE is not None:  # algorithmic work of this launch: A_in + A_out (+A_res) + weights
@@ -98,8 +98,8 @@ def conv1d_wgrad(x: Tensor, dy: Tensor, KT: int, *, stride: int = 1, dil: int = 
 
 
 class GnPart:
-    """GroupNorm partial statistics [B, C, E, 3] = (mean, M2, count) per row slice, written by the kernel that
-    PRODUCED tensor `of` (conv / Modulation epilogue), so that the consuming GroupNorm needs no pass of its own."""
+    """GroupNorm partial statistics [B, C/4, E, 3] = (mean, M2, count) per slice of a 4-channel row quad, written by
+    the kernel that PRODUCED tensor `of` (conv epilogue), so that the consuming GroupNorm needs no pass of its own."""
     __slots__ = ("part", "of")
 
     def __init__(self):
@@ -112,11 +112,24 @@ class GnPart:
 
 def gn_finalize(part: Tensor, groups: int, eps: float = GN_EPS) -> Tensor:
     """stats [B, G, 2] from producer-side partials (adp_gn_finalize)."""
-    B, C, E, _ = part.shape
+    B, CQ, E, _ = part.shape
+    C = CQ * 4
     stats = torch.empty((B, groups, 2), dtype=torch.float32, device=part.device)
     _C.tag(bytes=4 * part.numel(), shape=f"B{B} C{C} E{E}")
     _C.call("adp_gn_finalize", ptr(part), B, C, E, groups, eps, ptr(stats), _C.stream())
     return stats
+
+
+def gn_finalize_act(x: Tensor, part: Tensor, groups: int, gamma: Tensor, beta: Tensor, eps: float = GN_EPS):
+    """(stats, SiLU(GroupNorm(x))) from producer-side partials in one launch (adp_gn_finalize_act)."""
+    B, C, L = x.shape
+    E = part.shape[2]
+    stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+    act = torch.empty_like(x)
+    _C.tag(bytes=8 * x.numel(), shape=f"B{B} C{C} L{L} E{E}")
+    _C.call("adp_gn_finalize_act", ptr(x), ptr(part), B, C, L, E, groups, eps, ptr(gamma), ptr(beta), ptr(stats),
+            ptr(act), _C.stream())
+    return stats, act
 
 
 def gn_act(x: Tensor, stats: Tensor, groups: int, gamma: Tensor, beta: Tensor) -> Tensor:
@@ -173,23 +186,15 @@ def gn_silu_bwd(x: Tensor, dact: Tensor, stats: Tensor, gamma: Tensor, beta: Ten
 
 
 def modulation_fwd(x: Tensor, ss: Tensor, ss_bstride: int, eps: float = LN_EPS, y: Optional[Tensor] = None,
-                   stats: Optional[Tensor] = None, gn: Optional[GnPart] = None):
-    """ss: 1-D view whose element [b*ss_bstride + c] is scale and [b*ss_bstride + C + c] is shift.
-    `gn`: filled with the GroupNorm partial statistics of y (the next ResnetItem's first GroupNorm input)."""
+                   stats: Optional[Tensor] = None):
+    """ss: 1-D view whose element [b*ss_bstride + c] is scale and [b*ss_bstride + C + c] is shift."""
     B, C, L = x.shape
     if y is None:
         y = torch.empty_like(x)
     if stats is None:
         stats = torch.empty((B, L, 2), dtype=torch.float32, device=x.device)
     _C.tag(bytes=8 * x.numel(), shape=f"B{B} C{C} L{L}")
-    E = _C.query("adp_modulation_gn_entries", B, C, L) if gn is not None else 0
-    if E > 0:
-        gn.part = torch.empty((B, C, E, 3), dtype=torch.float32, device=x.device)
-        gn.of = y
-        _C.call("adp_modulation_fwd_gn", ptr(x), ptr(ss), ss_bstride, B, C, L, eps, ptr(y), ptr(stats), ptr(gn.part),
-                _C.stream())
-    else:
-        _C.call("adp_modulation_fwd", ptr(x), ptr(ss), ss_bstride, B, C, L, eps, ptr(y), ptr(stats), _C.stream())
+    _C.call("adp_modulation_fwd", ptr(x), ptr(ss), ss_bstride, B, C, L, eps, ptr(y), ptr(stats), _C.stream())
     return y, stats
 
 

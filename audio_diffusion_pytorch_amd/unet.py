@@ -278,6 +278,8 @@ class UNetV0Net(nn.Module):
 NATIVE_FACTORS = (1, 2, 4)      # down/upsample factors with dedicated conv kernel variants
 SKIP_CAT_SCALE = 2 ** -0.5      # a_unet SkipCat / MergeCat: cat[skip * scale, x]
 POISON_GRADS = os.environ.get("ADP_DEBUG_POISON", "0") == "1"
+# GroupNorm statistics from the producing conv's epilogue (1) or from a pass over the tensor (0); A/B switch
+GN_EPILOGUE = int(os.environ.get("ADP_GN_EPILOGUE", "1"))
 
 
 def _grad_buffer(shape, device) -> Tensor:
@@ -386,7 +388,10 @@ class _Run:
         """(stats, SiLU(GroupNorm(x)) materialised) for the wide layers."""
         G = self.net.groups
         if self.gn is not None and self.gn.covers(x):
-            st = ops.gn_finalize(self.gn.part, G)
+            part = self.gn.part
+            if (x.shape[1] // G // 4) * part.shape[2] <= 1024:  # few entries per group: one launch does both
+                return ops.gn_finalize_act(x, part, G, gnp.weight, gnp.bias)
+            st = ops.gn_finalize(part, G)
             return st, ops.gn_act(x, st, G, gnp.weight, gnp.bias)
         return ops.gn_stats_act(x, G, gnp.weight, gnp.bias)
 
@@ -396,7 +401,7 @@ class _Run:
         if x.shape[1] >= ACT_MATERIALIZE_MIN_C:
             return self.resnet_wide(p, x)
         st1 = self.gn_stats_of(x)
-        self.gn = ops.GnPart()
+        self.gn = ops.GnPart() if GN_EPILOGUE else None
         h1 = ops.conv1d(x, p.conv1.weight, p.conv1.bias, pad=1, prologue=1, pro_stats=st1, pro_gamma=p.gn1.weight,
                         pro_beta=p.gn1.bias, groups=G, gn=self.gn)
         st2 = self.gn_stats_of(h1)
@@ -425,7 +430,7 @@ class _Run:
         workgroups that stage a tile of it (the tensors are 2-8 MB here; see gn_apply_kernel in csrc/norm.hip)."""
         G = self.net.groups
         st1, a1 = self.gn_stats_act_of(x, p.gn1)
-        self.gn = ops.GnPart()
+        self.gn = ops.GnPart() if GN_EPILOGUE else None
         h1 = ops.conv1d(a1, p.conv1.weight, p.conv1.bias, pad=1, gn=self.gn)
         st2, a2 = self.gn_stats_act_of(h1, p.gn2)
         self.gn = None
@@ -444,11 +449,13 @@ class _Run:
             self.tape.append((bwd, None))
         return y
 
-    def modulation(self, key, x: Tensor, feeds_resnet: bool = False) -> Tensor:
+    def modulation(self, key, x: Tensor) -> Tensor:
         ss, dss = self.ss(key)
         NT = self.net.bank_total
-        self.gn = ops.GnPart() if feeds_resnet else None  # the next ResnetItem's first GroupNorm reads y
-        y, stats = ops.modulation_fwd(x, ss, NT, gn=self.gn)
+        # (Modulation-side GroupNorm partials were measured and rejected: the per-channel lane reductions cost the
+        # kernel more than the statistics launch they save -- tools/rejected/README.md)
+        self.gn = None
+        y, stats = ops.modulation_fwd(x, ss, NT)
         if self.need_grad:
             self.tape.append((lambda gy: ops.modulation_bwd(x, gy, ss, NT, stats, dss, NT), None))
         return y
@@ -478,16 +485,11 @@ class _Run:
         return attn_host.attention_item(self, p, x, context)
 
     def run_items(self, d: int, which: str, mods, x: Tensor, embedding, channels) -> Tensor:
-        types = self.net.item_types[d]
-        deepest = d == len(self.net.blocks) - 1
-        for i, (t, p) in enumerate(zip(types, mods)):
+        for i, (t, p) in enumerate(zip(self.net.item_types[d], mods)):
             if t == ITEM_RESNET:
                 x = self.resnet(p, x)
             elif t == ITEM_MODULATION:
-                # the consumer of this item's output: the next item, or (last down item of the deepest block) the
-                # first up item
-                nxt = types[i + 1] if i + 1 < len(types) else (types[0] if (which == "down" and deepest) else None)
-                x = self.modulation((d, which, i), x, feeds_resnet=(nxt == ITEM_RESNET))
+                x = self.modulation((d, which, i), x)
             elif t == ITEM_INJECT:
                 assert channels is not None and channels[d] is not None, f"Missing context `channels` at depth {d}"
                 x = self.inject(p, x, channels[d], self.ctx_index[d])
@@ -513,7 +515,7 @@ class _Run:
             assert x2 is None
             skip = x
         wd = blk.down.weight
-        self.gn = ops.GnPart()  # the first item of every depth is a ResnetItem: its GroupNorm reads h0
+        self.gn = ops.GnPart() if GN_EPILOGUE else None  # the first item of every depth is a ResnetItem (GroupNorm of h0)
         if native:
             xs = x2s = None
             h0 = ops.conv1d(x, wd, blk.down.bias, stride=f, x2=x2, gn=self.gn)
@@ -531,7 +533,7 @@ class _Run:
             sc, dsc = self.ss((d, "skip"))
             u = torch.empty((x.shape[0], blk.out_ch, h.shape[2] * f), dtype=torch.float32, device=x.device) \
                 if self.need_grad else None
-            self.gn = ops.GnPart() if d > 0 else None  # the outer depth's first up item (a ResnetItem) reads y
+            self.gn = ops.GnPart() if (d > 0 and GN_EPILOGUE) else None  # the outer depth's first up ResnetItem reads y
             y = ops.conv1d(h, blk.up.weight, blk.up.bias, pad=1, up=f, e_scale=sc, e_bstride=NT, res=skip, out_pre=u,
                            gn=self.gn)
         else:

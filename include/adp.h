@@ -83,9 +83,10 @@ typedef struct adp_conv_desc {
   float* ws;               /* scratch of adp_conv1d_ws_bytes(d) bytes (NULL when that is 0): cross-workgroup split-K
                               partial tiles of small-grid problems (batch-1 deep layers) */
   float* gn_part;          /* optional: GroupNorm partial statistics of the OUTPUT tensor, written by the epilogue:
-                              gn_part[((b*M + m)*E + e)*3 + {0,1,2}] = (mean, M2, count) of the e-th slice of row (b, m),
-                              E = adp_conv1d_gn_entries(d) (0: this shape / kernel family cannot, pass NULL).  The
-                              consumer's GroupNorm then needs no pass of its own over the tensor: adp_gn_finalize. */
+                              gn_part[((b*M/4 + q)*E + e)*3 + {0,1,2}] = (mean, M2, count) of the e-th slice of the
+                              4-channel row quad q of batch element b, E = adp_conv1d_gn_entries(d) (0: this shape /
+                              kernel family cannot, pass NULL).  The consumer's GroupNorm then needs no pass of its
+                              own over the tensor: adp_gn_finalize. */
 } adp_conv_desc;
 
 /* Scratch the launch wants (0 for most shapes).  With ws == NULL the call still succeeds on the unsplit path. */
@@ -135,11 +136,15 @@ int adp_gn_stats(const float* x, int64_t B, int64_t C, int64_t L, int64_t G, flo
 int adp_gn_stats_act(const float* x, int64_t B, int64_t C, int64_t L, int64_t G, float eps, const float* gamma,
                      const float* beta, float* stats, float* act, float* ws, void* stream);
 
-/* GroupNorm statistics from producer-side partials (conv / Modulation epilogues): part[((b*C + c)*E + e)*3 + {0,1,2}] =
- * (mean, M2, count) of slice e of row (b, c); Chan's combination over the C/G rows x E slices of each group, one
- * workgroup per (b, g).  stats as adp_gn_stats.  Replaces the statistics pass over the activation tensor. */
+/* GroupNorm statistics from producer-side partials (conv epilogues): part[((b*C/4 + q)*E + e)*3 + {0,1,2}] =
+ * (mean, M2, count) of slice e of row quad q; Chan's combination over the (C/G)/4 quads x E slices of each group, one
+ * wave per (b, g); (C/G) % 4 == 0.  stats as adp_gn_stats.  Replaces the statistics pass over the activation. */
 int adp_gn_finalize(const float* part, int64_t B, int64_t C, int64_t E, int64_t G, float eps, float* stats,
                     void* stream);
+/* adp_gn_finalize + adp_gn_act in ONE launch for rows with few slices (wide layers fed by a conv epilogue): every
+ * workgroup combines its group's C/G * E partial entries itself. */
+int adp_gn_finalize_act(const float* x, const float* part, int64_t B, int64_t C, int64_t L, int64_t E, int64_t G,
+                        float eps, const float* gamma, const float* beta, float* stats, float* act, void* stream);
 /* act[b,c,l] = SiLU((x - mean) * rstd * gamma[c] + beta[c]) from finished statistics (the wide-layer path of
  * adp_gn_stats_act when the statistics came from adp_gn_finalize). */
 int adp_gn_act(const float* x, const float* stats, const float* gamma, const float* beta, int64_t B, int64_t C,
@@ -172,11 +177,6 @@ int adp_gn_param_grad(const float* ab, int64_t B, int64_t C, int64_t NS, float* 
  * ------------------------------------------------------------------------------------------ */
 int adp_modulation_fwd(const float* x, const float* ss, int64_t ss_bstride, int64_t B, int64_t C, int64_t L,
                        float eps, float* y, float* stats, void* stream);
-/* Same, and the GroupNorm partial statistics of y (format of adp_conv_desc.gn_part with E = adp_modulation_gn_entries):
- * a ModulationItem's output feeds the next ResnetItem's first GroupNorm (components.py:89-90). */
-int64_t adp_modulation_gn_entries(int64_t B, int64_t C, int64_t L);
-int adp_modulation_fwd_gn(const float* x, const float* ss, int64_t ss_bstride, int64_t B, int64_t C, int64_t L,
-                          float eps, float* y, float* stats, float* gn_part, void* stream);
 /* dx, and dss[b*dss_bstride + {c | C + c}] = {sum_l dy*xhat | sum_l dy} (overwritten).
  * ws: adp_chan_ln_bwd_ws_bytes(B, C, L). */
 int64_t adp_chan_ln_bwd_ws_bytes(int64_t B, int64_t C, int64_t L);
