@@ -16,6 +16,13 @@ constexpr int MM_PRO_RMAX = 1024; // channels whose GroupNorm constants fit the 
 // 64 x 64 block tiles (8 MMA waves + 4 loaders) unless that leaves most of the 256 CUs without a block
 bool mm_use64(const adp_conv_desc& d) {
   if (d.M % 64 != 0) return false;
+  // plain (no prologue) kernel-3 convs of the wide layers: two co-resident 32-row blocks per CU overlap one block's
+  // first-load latency / K-group exchange / epilogue with the other's MFMAs (microbench at batch 4, 32- vs 64-row
+  // tiles: C=256 42.7 vs 46.7 us, C=512 L=1024 68.9 vs 74.2, dgrad C=1024 L=256 61.1 vs 63.4); with the GroupNorm+SiLU
+  // prologue the doubled activation recompute loses instead
+  if (d.prologue == 0 && d.KT == 3 && d.stride == 1 && d.up == 1 && d.R >= 256 &&
+      (d.M / 32) * adp_cdiv(d.N, 64) * d.B >= 512)
+    return false;
   return (d.M / 64) * adp_cdiv(d.N, 64) * d.B >= 200;
 }
 
