@@ -382,7 +382,9 @@ __global__ __launch_bounds__(NT) void chan_ln_fwd_kernel(const float* x, const f
 
 // Backward of y = xhat * mul_c + add_c with mul_c = 1 + ss[b*bstride + c] (gamma == NULL) or gamma[c].
 // dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)), g = dy * mul_c   (+ dres)
-// partial per-channel sums over the tile: ws[b][0][c][tile] = sum dy*xhat, ws[b][1][c][tile] = sum dy
+// partial per-channel sums over the tile: ws[b][0][tile][c] = sum dy*xhat, ws[b][1][tile][c] = sum dy (channel
+// fastest: a workgroup's 2 * C partials are two contiguous runs -- the [c][tile] order scattered them over 2 * C cache
+// lines per workgroup, 6x the algorithmic traffic at C = 1024)
 template <int TL, int NT, int VPT>
 __global__ __launch_bounds__(NT) void chan_ln_bwd_kernel(const float* x, const float* dy, const float* ss,
                                                          int64_t bstride, const float* gamma, const float* stats,
@@ -417,8 +419,8 @@ __global__ __launch_bounds__(NT) void chan_ln_bwd_kernel(const float* x, const f
       pb += __shfl_xor(pb, o, 64);
     }
     if (p == 0 && c < C) {
-      ws[(((int64_t)b * 2 + 0) * C + c) * NTL + tile] = pa;
-      ws[(((int64_t)b * 2 + 1) * C + c) * NTL + tile] = pb;
+      ws[(((int64_t)b * 2 + 0) * NTL + tile) * C + c] = pa;
+      ws[(((int64_t)b * 2 + 1) * NTL + tile) * C + c] = pb;
     }
   }
 #pragma unroll
@@ -543,6 +545,72 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* ws, int64
     const int64_t o = sum_over_b ? row : (row / W) * bstride + (row % W);
     out[o] = accumulate ? out[o] + s : s;
   }
+}
+
+// out[b*bstride + j] (or out[j] summed over b) = sum_t ws[((b*2 + j / C) * NT + t) * C + j % C], j < 2 C: second stage of
+// chan_ln_bwd_kernel's per-tile channel sums.  One workgroup = 64 outputs x 16 tile groups: lanes run along the
+// channels (coalesced), the 16 waves stride the tiles (short serial chains), LDS combines the groups in a fixed order.
+__global__ __launch_bounds__(1024) void reduce_tiles_kernel(const float* ws, int64_t B, int64_t C, int64_t NT,
+                                                            int64_t bstride, int sum_over_b, int accumulate,
+                                                            float* out) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int64_t W = 2 * C;
+  const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t bb = blockIdx.y;                       // batch element (0 when summing over the batch)
+  float s = 0.0f;
+  if (j < W) {
+    const int64_t which = j / C, c = j % C;
+    const int64_t b0 = sum_over_b ? 0 : bb, b1 = sum_over_b ? B : bb + 1;
+    for (int64_t b = b0; b < b1; ++b) {
+      const float* p = ws + ((b * 2 + which) * NT) * C + c;
+      for (int64_t t = tg; t < NT; t += 16) s += p[t * C];
+    }
+  }
+  part[tg][lane] = s;
+  __syncthreads();
+  if (tg == 0 && j < W) {
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += part[k][lane];
+    const int64_t o = sum_over_b ? j : bb * bstride + j;
+    out[o] = accumulate ? out[o] + v : v;
+  }
+}
+
+// same sums, one WAVE per (b, j) with the lanes striding the tiles: for the narrow layers (few channels, thousands of
+// tiles), where a thread per output would walk the tiles serially
+__global__ __launch_bounds__(256) void reduce_tiles_wave_kernel(const float* ws, int64_t B, int64_t C, int64_t NT,
+                                                                int64_t bstride, int sum_over_b, int accumulate,
+                                                                float* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t W = 2 * C;
+  const int64_t total = sum_over_b ? W : B * W;
+  if (i >= total) return;
+  const int64_t j = i % W, which = j / C, c = j % C;
+  float s = 0.0f;
+  const int64_t b0 = sum_over_b ? 0 : i / W, b1 = sum_over_b ? B : b0 + 1;
+  for (int64_t b = b0; b < b1; ++b) {
+    const float* p = ws + ((b * 2 + which) * NT) * C + c;
+    for (int64_t t = lane; t < NT; t += 64) s += p[t * C];
+  }
+  s = adp_wave_sum(s);
+  if (lane == 0) {
+    const int64_t o = sum_over_b ? j : b0 * bstride + j;
+    out[o] = accumulate ? out[o] + s : s;
+  }
+}
+
+static void launch_reduce_tiles(const float* ws, int64_t B, int64_t C, int64_t NT, int64_t bstride, int sum_over_b,
+                                int accumulate, float* out, void* stream) {
+  const int64_t total = sum_over_b ? 2 * C : B * 2 * C;
+  if (NT >= 128 && C <= 64)   // narrow + long: a wave per output, lanes over the tiles (the stride-C reads are short)
+    ADP_LAUNCH(reduce_tiles_wave_kernel, dim3((unsigned)adp_cdiv(total, 4)), dim3(256), stream, ws, B, C, NT, bstride,
+               sum_over_b, accumulate, out);
+  else
+    ADP_LAUNCH(reduce_tiles_kernel, dim3((unsigned)adp_cdiv(2 * C, 64), (unsigned)(sum_over_b ? 1 : B)), dim3(1024),
+               stream, ws, B, C, NT, bstride, sum_over_b, accumulate, out);
 }
 
 // ---- SkipModulate backward: dx = scale[b,c] * g ; partial dot(g, x) per (row, split) -------------------------
@@ -705,8 +773,7 @@ extern "C" int adp_modulation_bwd(const float* x, const float* dy, const float* 
   if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
   const int64_t NT = adp_cdiv(L, ln_cfg(C, B, L).tl);
   launch_ln_bwd(x, dy, ss, ss_bstride, (const float*)nullptr, stats, (const float*)nullptr, B, C, L, dx, ws, stream);
-  ADP_LAUNCH(reduce_rows_kernel, dim3((unsigned)adp_cdiv(B * 2 * C, 4)), dim3(256), stream, (const float*)ws, B,
-             2 * C, NT, dss_bstride, 0, 0, dss);
+  launch_reduce_tiles((const float*)ws, B, C, NT, dss_bstride, 0, 0, dss, stream);
   return ADP_LAUNCH_OK();
 }
 
@@ -719,8 +786,7 @@ extern "C" int adp_ln_bwd(const float* x, const float* dxn, const float* stats, 
   const int64_t NT = adp_cdiv(L, ln_cfg(C, B, L).tl);
   launch_ln_bwd(x, dxn, (const float*)nullptr, (int64_t)0, gamma, stats, dres, B, C, L, dx, ws, stream);
   // dgamma_dbeta = [dgamma (C) | dbeta (C)]
-  ADP_LAUNCH(reduce_rows_kernel, dim3((unsigned)adp_cdiv(2 * C, 4)), dim3(256), stream, (const float*)ws, B, 2 * C,
-             NT, (int64_t)0, 1, (int)accumulate, dgamma_dbeta);
+  launch_reduce_tiles((const float*)ws, B, C, NT, (int64_t)0, 1, (int)accumulate, dgamma_dbeta, stream);
   return ADP_LAUNCH_OK();
 }
 

@@ -167,18 +167,18 @@ def gn_silu_bwd(x: Tensor, dact: Tensor, stats: Tensor, gamma: Tensor, beta: Ten
                 dbeta: Optional[Tensor] = None, accumulate: bool = False):
     """Backward of SiLU(GroupNorm(x)): returns (dx [+ dres], dgamma, dbeta)."""
     B, C, L = x.shape
-    NS = _C.query("adp_row_nsplit", B * C, L)
-    ab = torch.empty((B, C, NS, 2), dtype=torch.float32, device=x.device)
-    s = _C.stream()
-    _C.tag(bytes=8 * x.numel(), shape=f"B{B} C{C} L{L}")
-    _C.call("adp_gn_silu_bwd_reduce", ptr(x), ptr(dact), ptr(stats), ptr(gamma), ptr(beta), B, C, L, groups, NS,
-            ptr(ab), s)
     if dx is None:
         dx = torch.empty_like(x)
     if dgamma is None:
         dgamma = torch.empty_like(gamma)
     if dbeta is None:
         dbeta = torch.empty_like(beta)
+    NS = _C.query("adp_row_nsplit", B * C, L)
+    ab = torch.empty((B, C, NS, 2), dtype=torch.float32, device=x.device)
+    s = _C.stream()
+    _C.tag(bytes=8 * x.numel(), shape=f"B{B} C{C} L{L}")
+    _C.call("adp_gn_silu_bwd_reduce", ptr(x), ptr(dact), ptr(stats), ptr(gamma), ptr(beta), B, C, L, groups, NS,
+            ptr(ab), s)
     _C.tag(bytes=(12 + (4 if dres is not None else 0)) * x.numel(), shape=f"B{B} C{C} L{L}")
     _C.call("adp_gn_silu_bwd_apply", ptr(x), ptr(dact), ptr(stats), ptr(gamma), ptr(beta), ptr(ab), ptr(dres), B, C,
             L, groups, NS, ptr(dx), ptr(dgamma), ptr(dbeta), int(accumulate), s)

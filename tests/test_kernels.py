@@ -448,7 +448,7 @@ def test_wgrad_direct_family(dev, B, R, M, L, KT, stride, pad, up):
 
 
 # ------------------------------------------------------------------ GroupNorm+SiLU backward
-@pytest.mark.parametrize("B,C,L,G", [(2, 8, 3000, 8), (2, 32, 130, 8), (1, 64, 40, 8)])
+@pytest.mark.parametrize("B,C,L,G", [(2, 8, 3000, 8), (2, 32, 130, 8), (1, 64, 40, 8), (2, 1024, 128, 8)])
 def test_gn_silu_bwd(dev, B, C, L, G):
     x = (rnd(B, C, L, seed=1) * 1.5 + 0.4).requires_grad_()
     gamma = (rnd(C, seed=2) * 0.5 + 1).requires_grad_()
