@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$C" -o pmc -- \
-    python "$ROOT/bench.py" --steps 2 --warmup 1 --graph 0 --no-cpu-baseline --no-roofline "$@" > "$OUT/$C.log" 2>&1
+    python "$ROOT/bench.py" --steps 2 --warmup 1 --graph 0 --no-cpu-baseline --no-roofline --no-extras "$@" > "$OUT/$C.log" 2>&1
   echo "rc=$?" >> "$OUT/$C.log"
   f=$(find "$OUT/$C" -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && head -4 "$f" > "$OUT/$C.head.txt"; [ -n "$f" ] && python "$ROOT/tools/pmc_summary.py" --reduce "$f" "$OUT/$C.summary.csv"
