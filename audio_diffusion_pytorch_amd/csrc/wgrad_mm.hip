@@ -305,19 +305,29 @@ struct WgPlan {
   int64_t cpb, cps, nsplit;
 };
 
-WgPlan wg_plan(const adp_wgrad_desc& d) {
-  WgPlan p;
-  p.bm = (d.M % 64 == 0 && d.R % 64 == 0 && d.stride != 4) ? 64 : 32;  // stride 4: x rows are 4x wider in LDS
-  p.nkg = 4;
-  const int64_t tiles = (d.M / p.bm) * (d.R / p.bm);
-  p.cpb = adp_cdiv(d.N, WG_BKN);
-  const int64_t total = d.B * p.cpb;
-  // 12-wave workgroups (64x64): one per CU fills the SIMDs; 8-wave workgroups (32x32): about three per CU
-  const int64_t target = (p.bm == 64) ? 256 : 768;
+// Position split of one (m, r) tile grid: ns workgroups per tile, each >= 4 chunks of 64 positions (start-up amortised;
+// the round-1 floor of 8 left the narrow layers on 128 of the 256 CUs at batch 4 and on 32 at batch 1: microbench
+// C=64 37.0 -> 28.1 us at batch 4, 34.7 -> 14.3 us at batch 1).
+static int64_t wg_split(int64_t tiles, int64_t total, int64_t target) {
   int64_t ns = adp_cdiv(target, tiles);
-  if (ns > total / 8) ns = total / 8;  // a workgroup should amortise its start-up over >= 8 chunks
+  if (ns > total / 4) ns = total / 4;
   if (ns > total) ns = total;
   if (ns < 1) ns = 1;
+  return ns;
+}
+
+WgPlan wg_plan(const adp_wgrad_desc& d) {
+  WgPlan p;
+  p.nkg = 4;
+  p.cpb = adp_cdiv(d.N, WG_BKN);
+  const int64_t total = d.B * p.cpb;
+  // 12-wave workgroups (64x64 tiles): one per CU fills the SIMDs; 8-wave workgroups (32x32): about three per CU
+  const bool can64 = d.M % 64 == 0 && d.R % 64 == 0 && d.stride != 4;  // stride 4: x rows are 4x wider in LDS
+  const int64_t t64 = (d.M / 64) * (d.R / 64), t32 = (d.M / 32) * (d.R / 32);
+  const int64_t ns64 = can64 ? wg_split(t64, total, 256) : 0, ns32 = wg_split(t32, total, 768);
+  // 64x64 tiles unless they leave most CUs idle while 32x32 tiles (4x as many, half the staging per workgroup) do not
+  p.bm = (can64 && (t64 * ns64 >= 200 || t32 * ns32 <= 3 * t64 * ns64)) ? 64 : 32;
+  const int64_t ns = p.bm == 64 ? ns64 : ns32;
   p.cps = adp_cdiv(total, ns);
   p.nsplit = adp_cdiv(total, p.cps);
   return p;

@@ -40,8 +40,13 @@ def main():
         t_p = timeit(lambda: ops.conv1d(x, w, bias, pad=1, prologue=1, pro_stats=stats, pro_gamma=gamma, pro_beta=beta,
                                         groups=8))
         t_t = timeit(lambda: ops.conv1d(x, w, None, pad=1, transposed=True))
+        dw, db = torch.empty_like(w), torch.empty_like(bias)
+        t_w = timeit(lambda: ops.conv1d_wgrad(x, res, 3, pad=1, dw=dw, dbias=db))
+        t_wp = timeit(lambda: ops.conv1d_wgrad(x, res, 3, pad=1, prologue=1, pro_stats=stats, pro_gamma=gamma,
+                                               pro_beta=beta, groups=8, dw=dw, dbias=db))
         print(f"C{C:5d} L{L:6d}: fwd {t_f:7.1f} us {fl / t_f / 1e6:6.1f} TF | gn+silu fwd {t_p:7.1f} us {fl / t_p / 1e6:6.1f} TF"
-              f" | dgrad {t_t:7.1f} us {fl / t_t / 1e6:6.1f} TF", flush=True)
+              f" | dgrad {t_t:7.1f} us {fl / t_t / 1e6:6.1f} TF | wgrad {t_w:7.1f} us {fl / t_w / 1e6:6.1f} TF"
+              f" | gn+silu wgrad {t_wp:7.1f} us {fl / t_wp / 1e6:6.1f} TF", flush=True)
 
 
 if __name__ == "__main__":
