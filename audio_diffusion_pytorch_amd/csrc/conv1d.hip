@@ -852,6 +852,7 @@ extern "C" int adp_conv1d(const adp_conv_desc* dp, void* stream) {
   if (d.store == 2 && ((d.sp != 2 && d.sp != 4) || d.N % d.sp != 0 || d.bias)) return ADP_ERR_UNSUPPORTED;
   if (d.B > 65535 || adp_cdiv(d.M, 32) > 65535) return ADP_ERR_SHAPE;
   if (adp_conv_stream_eligible(d)) return adp_conv_stream(d, stream);
+  if (adp_conv_bs_enabled() && adp_conv_bs_eligible(d)) return adp_conv_bs(d, stream);
   if (adp_conv_mm_eligible(d)) return adp_conv_mm(d, stream);
   if (adp_conv_direct_eligible(d)) return adp_conv_direct(d, stream);
   if (d.KT == 1) return dispatch_conv<1, 1>(d, stream);
@@ -864,8 +865,10 @@ extern "C" int64_t adp_conv1d_ws_bytes(const adp_conv_desc* dp) {
   if (!dp) return ADP_ERR_NULL;
   const adp_conv_desc& d = *dp;
   if (d.B <= 0 || d.R <= 0 || d.M <= 0 || d.N <= 0 || d.Lin <= 0) return ADP_ERR_SHAPE;
-  if (adp_conv_stream_eligible(d) || !adp_conv_mm_eligible(d)) return 0;
-  const int64_t ks = adp_conv_mm_ksplit(d);
+  if (adp_conv_stream_eligible(d)) return 0;
+  const bool bs = adp_conv_bs_enabled() && adp_conv_bs_eligible(d);
+  if (!bs && !adp_conv_mm_eligible(d)) return 0;
+  const int64_t ks = bs ? adp_conv_bs_ksplit(d) : adp_conv_mm_ksplit(d);
   return ks > 1 ? ks * d.B * d.M * d.N * (int64_t)sizeof(float) : 0;
 }
 
@@ -875,6 +878,7 @@ extern "C" int64_t adp_conv1d_gn_entries(const adp_conv_desc* dp) {
   if (d.B <= 0 || d.R <= 0 || d.M <= 0 || d.N <= 0 || d.Lin <= 0) return ADP_ERR_SHAPE;
   if (d.store != 0 || d.M % 4 != 0) return 0;
   if (adp_conv_stream_eligible(d)) return adp_conv_stream_gn_entries(d);
+  if (adp_conv_bs_enabled() && adp_conv_bs_eligible(d)) return 0;
   if (adp_conv_mm_eligible(d)) return adp_conv_mm_ksplit(d) > 1 ? 0 : adp_cdiv(d.N, 64);  // one slice per 64-position tile
   return 0;
 }

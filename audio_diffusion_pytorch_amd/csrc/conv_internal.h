@@ -9,6 +9,14 @@ int adp_conv_mm(const adp_conv_desc& d, void* stream);
 int64_t adp_conv_mm_tile(const adp_conv_desc& d);  // NKG * 1000000 + BM * 1000 + BN
 int64_t adp_conv_mm_ksplit(const adp_conv_desc& d);  // cross-workgroup K split the dispatcher picks (1 = none)
 
+int adp_conv_splitk_reduce(const adp_conv_desc& d, int64_t ks, void* stream);  // sum of d.ws partial tiles + epilogue
+
+// conv_bs.hip: the deep kernel-3 convs on the bf16 matrix cores at fp32 accuracy (three-way bf16 split, 6 products)
+bool adp_conv_bs_enabled();
+bool adp_conv_bs_eligible(const adp_conv_desc& d);
+int64_t adp_conv_bs_ksplit(const adp_conv_desc& d);
+int adp_conv_bs(const adp_conv_desc& d, void* stream);
+
 // wgrad_mm.hip: wave-specialised weight gradient of the same convolutions (channels % 32 == 0)
 bool adp_wgrad_mm_eligible(const adp_wgrad_desc& d);
 int64_t adp_wgrad_mm_ws_floats(const adp_wgrad_desc& d);

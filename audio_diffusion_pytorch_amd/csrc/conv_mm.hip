@@ -108,15 +108,17 @@ int64_t adp_conv_mm_tile(const adp_conv_desc& d) {
   return nkg * 1000000 + (mm_use64(d) ? 64064 : 32064);
 }
 
+int adp_conv_splitk_reduce(const adp_conv_desc& d, int64_t ks, void* stream) {
+  const int64_t total = d.B * d.M * d.N;
+  int64_t g = adp_cdiv(total, 1024);
+  if (g > 2048) g = 2048;
+  ADP_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), stream, d, (int)ks);
+  return ADP_LAUNCH_OK();
+}
+
 int adp_conv_mm(const adp_conv_desc& d, void* stream) {
   const int rc = mm_use64(d) ? adp_conv_mm_m64(d, stream) : adp_conv_mm_m32(d, stream);
   const int64_t ks = d.ws ? adp_conv_mm_ksplit(d) : 1;
-  if (rc == ADP_OK && ks > 1) {
-    const int64_t total = d.B * d.M * d.N;
-    int64_t g = adp_cdiv(total, 1024);
-    if (g > 2048) g = 2048;
-    ADP_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), stream, d, (int)ks);
-    return ADP_LAUNCH_OK();
-  }
+  if (rc == ADP_OK && ks > 1) return adp_conv_splitk_reduce(d, ks, stream);
   return rc;
 }

@@ -267,6 +267,58 @@ static inline f32x16 adp_mfma32(float a, float b, f32x16 c) {
   }
   return d;
 }
+// v_mfma_f32_32x32x16_bf16: lane l holds A[l&31][8*(l>>5)+j], B[8*(l>>5)+j][l&31], j = 0..7 (bf16); fp32 accumulate
+struct bf16x8 {
+  uint16_t v[8];
+};
+static inline float adp_emul_bf16(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline f32x16 adp_mfma32_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  int l = adp_emul::lane_id();
+  int col = l & 31;
+  f32x16 d = c;
+  for (int w = 0; w < 4; ++w) {  // one 32-bit exchange per bf16 pair
+    uint32_t aw, bw;
+    memcpy(&aw, &a.v[2 * w], 4);
+    memcpy(&bw, &b.v[2 * w], 4);
+    float af, bf;
+    memcpy(&af, &aw, 4);
+    memcpy(&bf, &bw, 4);
+    const float *A, *B;
+    adp_emul::mfma_exchange(af, bf, A, B);
+    for (int r = 0; r < 16; ++r) {
+      int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      float acc = d[r];
+      for (int kh = 0; kh < 2; ++kh) {
+        uint32_t ua, ub;
+        memcpy(&ua, &A[row + 32 * kh], 4);
+        memcpy(&ub, &B[col + 32 * kh], 4);
+        acc = fmaf(adp_emul_bf16((uint16_t)(ua & 0xffff)), adp_emul_bf16((uint16_t)(ub & 0xffff)), acc);
+        acc = fmaf(adp_emul_bf16((uint16_t)(ua >> 16)), adp_emul_bf16((uint16_t)(ub >> 16)), acc);
+      }
+      d[r] = acc;
+    }
+  }
+  return d;
+}
+struct uint2 {
+  uint32_t x, y;
+};
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+static inline uint32_t __float_as_uint(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+}
+static inline float __uint_as_float(uint32_t u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
 // v_mfma_f32_16x16x4_f32: A[l&15][k=l>>4], B[k=l>>4][l&15]; D: col=l&15, row=(l>>4)*4+r
 static inline f32x4 adp_mfma16(float a, float b, f32x4 c) {
   const float *A, *B;
@@ -294,6 +346,7 @@ static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
 
 static inline void adp_barrier_consume() { adp_emul::sync_block(); }
+static inline void adp_sched_fence() {}
 
 #define ADP_LAUNCH(kern, grid, block, stream, ...) \
   do {                                             \

@@ -78,6 +78,33 @@ def test_conv1d_cross_workgroup_split_k(dev, B, R, M, L, KT, tr):
     assert rel_err(out, ref) < TOL and rel_err(pre, pre_ref) < TOL
 
 
+@pytest.mark.parametrize("B,R,M,L,tr", [(2, 256, 128, 200, False), (1, 512, 256, 128, False), (2, 256, 128, 130, True),
+                                        (1, 1024, 128, 64, True)])
+def test_conv1d_bf16_split_is_fp32_accurate(dev, B, R, M, L, tr, monkeypatch):
+    """conv_bs (ADP_CONV_BS=1): the deep kernel-3 convs as six bf16 MFMA partial products of an exact three-way bf16
+    split.  The claim is fp32 accuracy, so the bound here is 2e-6 against an fp64 reference (the parity tolerance of
+    the path is 1e-3), next to the exact-f32 MFMA kernel on the same inputs; ragged tile, K split, full epilogue."""
+    monkeypatch.setenv("ADP_CONV_BS", "1")
+    x = rnd(B, R, L, seed=1)
+    w = rnd(R, M, 3, seed=2, scale=0.05) if tr else rnd(M, R, 3, seed=2, scale=0.05)
+    b, res, sc = rnd(M, seed=3), rnd(B, M, L, seed=4), rnd(B * M, seed=5)
+    xd_, wd_ = x.double(), w.double()
+    ref = F.conv_transpose1d(xd_, wd_, None, padding=1) if tr else F.conv1d(xd_, wd_, None, padding=1)
+    pre_ref = ref + b.double()[None, :, None]
+    ref = pre_ref * sc.double().view(B, M, 1) + res.double()
+    pre = torch.empty(B, M, L).to(dev)
+    args = (x.to(dev), w.to(dev), b.to(dev))
+    kw = dict(pad=1, transposed=tr, e_scale=sc.to(dev), res=res.to(dev))
+    out = ops.conv1d(*args, out_pre=pre, **kw)
+    e_bs = ((out.cpu().double() - ref).abs().max() / ref.abs().max()).item()
+    e_pre = ((pre.cpu().double() - pre_ref).abs().max() / pre_ref.abs().max()).item()
+    monkeypatch.setenv("ADP_CONV_BS", "0")
+    out32 = ops.conv1d(*args, **kw)
+    e_32 = ((out32.cpu().double() - ref).abs().max() / ref.abs().max()).item()
+    assert e_bs < 2e-6 and e_pre < 2e-6, (e_bs, e_pre, e_32)
+    assert e_bs < 4 * e_32 + 2e-7, (e_bs, e_32)
+
+
 def test_conv1d_big_tile(dev):
     # enough workgroups to select the 128x128 tile on the dispatcher
     B, R, M, L = 6, 32, 128, 1024 if dev.type == "cuda" else 1024
