@@ -195,21 +195,27 @@ def _time(fn, n, warmup=3):
 
 
 def _attn_summary(recs):
-    """Per attention kernel: launches, average time and TFLOP/s against the f32 MFMA peak."""
-    out = {}
-    for call, kern, meta, ms in recs:
+    """Attention kernels of one instrumented step: per kernel launches + average time; per C-ABI call (the backward
+    is four kernels: delta, key/value pass, its reduce, query pass) the TFLOP/s of its algorithmic flops against the
+    f32 MFMA peak."""
+    kern, calls = {}, {}
+    for call, k, meta, ms in recs:
         if not call.startswith("adp_attn"):
             continue
-        a = out.setdefault(kern.split("(")[0], {"launches": 0, "ms": 0.0, "flops": 0})
+        a = kern.setdefault(k.split("(")[0], {"launches": 0, "ms": 0.0})
         a["launches"] += 1
         a["ms"] += ms
-        a["flops"] += meta.get("flops", 0)
-    res = {}
-    for k, a in out.items():
-        tf = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["flops"] and a["ms"] > 0 else None
-        res[k] = {"launches": a["launches"], "avg_us": round(a["ms"] / a["launches"] * 1e3, 2),
-                  "tflops": None if tf is None else round(tf, 2),
-                  "frac_of_f32_mfma_peak": None if tf is None else round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+        c = calls.setdefault(call, {"calls": 0, "ms": 0.0, "flops": 0})
+        c["ms"] += ms
+        if meta.get("flops"):  # the tag rides on the first kernel of a call
+            c["calls"] += 1
+            c["flops"] += meta["flops"]
+    res = {k: {"launches": a["launches"], "avg_us": round(a["ms"] / a["launches"] * 1e3, 2)} for k, a in kern.items()}
+    for call, c in calls.items():
+        if c["calls"] and c["ms"] > 0:
+            tf = c["flops"] / (c["ms"] * 1e-3) / 1e12
+            res[call] = {"calls": c["calls"], "avg_us_per_call": round(c["ms"] / c["calls"] * 1e3, 2), "tflops": round(tf, 2),
+                         "frac_of_f32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
     return res
 
 
