@@ -17,8 +17,24 @@ from .unet import UNetV0Net
 
 XUNet = UNetV0Net
 
+
+def _out_of_scope(name: str, why: str):
+    """Reference exports outside the denoising hot path (SURVEY section 8 / DESIGN section 7): importable, but they
+    say what they are instead of failing with an ImportError at the call site."""
+    def ctor(*args, **kwargs):
+        raise NotImplementedError(f"{name} is not part of the MI355X-native hot path ({why}); see DESIGN.md section 7")
+    ctor.__name__ = ctor.__qualname__ = name
+    return ctor
+
+
+DiffusionVocoder = _out_of_scope("DiffusionVocoder", "needs torchaudio's STFT / mel filterbank")
+MelSpectrogram = _out_of_scope("MelSpectrogram", "needs torchaudio's STFT / mel filterbank")
+DiffusionAR = _out_of_scope("DiffusionAR", "autoregressive ARVDiffusion / ARVSampler use a different net signature")
+LTPlugin = _out_of_scope("LTPlugin", "learned-transform front end, not on the UNetV0 denoising path")
+
 __all__ = [
     "AppendChannelsPlugin", "UNetV0", "XUNet", "UNetV0Net", "Diffusion", "Distribution", "LinearSchedule", "Sampler",
     "Schedule", "UniformDistribution", "VDiffusion", "VInpainter", "VSampler", "DiffusionModel", "DiffusionUpsampler",
-    "DiffusionAE", "EncoderBase", "AdapterBase", "ClassifierFreeGuidanceNet",
+    "DiffusionAE", "EncoderBase", "AdapterBase", "ClassifierFreeGuidanceNet", "DiffusionVocoder", "MelSpectrogram",
+    "DiffusionAR", "LTPlugin",
 ]

@@ -248,3 +248,11 @@ def test_unshuffle_and_pool_sum(dev, f):
     sa, sb = ops.split_channels(cat, 3)
     assert torch.equal(sa.cpu(), a) and torch.equal(sb.cpu(), b)
     assert rel_err(ops.axpby(0.5, a.to(dev), -2.0, a.to(dev)), -1.5 * a) < 1e-6
+
+
+def test_out_of_scope_reference_exports_say_so():
+    """Reference exports outside the hot path import cleanly and raise NotImplementedError."""
+    import audio_diffusion_pytorch_amd as adp
+    for name in ("DiffusionVocoder", "MelSpectrogram", "DiffusionAR", "LTPlugin"):
+        with pytest.raises(NotImplementedError, match=name):
+            getattr(adp, name)(net_t=None)
