@@ -878,8 +878,11 @@ extern "C" int64_t adp_conv1d_gn_entries(const adp_conv_desc* dp) {
   if (d.B <= 0 || d.R <= 0 || d.M <= 0 || d.N <= 0 || d.Lin <= 0) return ADP_ERR_SHAPE;
   if (d.store != 0 || d.M % 4 != 0) return 0;
   if (adp_conv_stream_eligible(d)) return adp_conv_stream_gn_entries(d);
-  if (adp_conv_bs_enabled() && adp_conv_bs_eligible(d)) return 0;
-  if (adp_conv_mm_eligible(d)) return adp_conv_mm_ksplit(d) > 1 ? 0 : adp_cdiv(d.N, 64);  // one slice per 64-position tile
+  // (the K split only happens when the caller passed its scratch: set d.ws before asking)
+  if (adp_conv_bs_enabled() && adp_conv_bs_eligible(d))
+    return d.ws && adp_conv_bs_ksplit(d) > 1 ? adp_conv_splitk_gn_entries(d) : 0;
+  if (adp_conv_mm_eligible(d))  // one slice per 64-position tile, or the K-split reduce kernel's slices
+    return d.ws && adp_conv_mm_ksplit(d) > 1 ? adp_conv_splitk_gn_entries(d) : adp_cdiv(d.N, 64);
   return 0;
 }
 

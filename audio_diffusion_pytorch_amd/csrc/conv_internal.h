@@ -10,6 +10,7 @@ int64_t adp_conv_mm_tile(const adp_conv_desc& d);  // NKG * 1000000 + BM * 1000 
 int64_t adp_conv_mm_ksplit(const adp_conv_desc& d);  // cross-workgroup K split the dispatcher picks (1 = none)
 
 int adp_conv_splitk_reduce(const adp_conv_desc& d, int64_t ks, void* stream);  // sum of d.ws partial tiles + epilogue
+int64_t adp_conv_splitk_gn_entries(const adp_conv_desc& d);  // gn_part slices per row the reduce kernel writes
 
 // conv_bs.hip: the deep kernel-3 convs on the bf16 matrix cores at fp32 accuracy (three-way bf16 split, 6 products)
 bool adp_conv_bs_enabled();

@@ -69,7 +69,61 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(adp_conv_desc d
   }
 }
 
+// The same sum + epilogue for an output that feeds a GroupNorm: one workgroup per (batch element, 4-channel row quad,
+// slice of SPLITK_GN_SLICE positions) keeps its <= 16 values per thread in registers and writes the quad's
+// (mean, M2, count) entry of d.gn_part -- the layout the conv epilogues write, so adp_gn_finalize[_act] serves both
+// and the consumer's statistics pass over the tensor disappears (batch 1: one launch less per deep ConvBlock).
+constexpr int SPLITK_GN_SLICE = 1024;
+__global__ __launch_bounds__(256) void conv_splitk_reduce_gn_kernel(adp_conv_desc d, int KS, int E) {
+  __shared__ float sh[4];
+  const int64_t M = d.M, N = d.N;
+  int id = blockIdx.x;
+  const int e = id % E;
+  id /= E;
+  const int64_t q = id % (M / 4), b = id / (M / 4);
+  const int64_t n0 = (int64_t)e * SPLITK_GN_SLICE;
+  const int cnt = (int)((N - n0) < SPLITK_GN_SLICE ? (N - n0) : SPLITK_GN_SLICE);
+  const int64_t total = d.B * M * N;
+  const int64_t ebs = d.e_bstride ? d.e_bstride : M;
+  float v[16];
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int idx = (int)threadIdx.x + 256 * k;
+    v[k] = 0.0f;
+    if (idx < 4 * cnt) {
+      const int64_t m = 4 * q + idx / cnt, i = (b * M + m) * N + n0 + idx % cnt;
+      float a = d.ws[i];
+      for (int j = 1; j < KS; ++j) a += d.ws[j * total + i];
+      if (d.bias) a += d.bias[m];
+      if (d.out_pre) d.out_pre[i] = a;
+      if (d.e_scale) a *= d.e_scale[b * ebs + m];
+      if (d.res) a += d.res[i];
+      d.out[i] = a;
+      v[k] = a;
+      s += a;
+    }
+  }
+  const float fcnt = 4.0f * (float)cnt;
+  const float mean = adp_block_sum<4>(s, sh) / fcnt;
+  float m2 = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float dv = ((int)threadIdx.x + 256 * k < 4 * cnt) ? v[k] - mean : 0.0f;
+    m2 = fmaf(dv, dv, m2);
+  }
+  m2 = adp_block_sum<4>(m2, sh);
+  if (threadIdx.x == 0) {
+    float* o = d.gn_part + (((int64_t)b * (M / 4) + q) * E + e) * 3;
+    o[0] = mean;
+    o[1] = m2;
+    o[2] = fcnt;
+  }
+}
+
 }  // namespace
+
+int64_t adp_conv_splitk_gn_entries(const adp_conv_desc& d) { return adp_cdiv(d.N, SPLITK_GN_SLICE); }
 
 // Cross-workgroup K split: when the output tiles alone leave most of the 256 CUs idle (batch-1 deep layers: depth 8
 // has 64 tiles of 32 x 64) the reduction over input channels is cut into 2 / 4 / 8 slices run by separate
@@ -109,6 +163,11 @@ int64_t adp_conv_mm_tile(const adp_conv_desc& d) {
 }
 
 int adp_conv_splitk_reduce(const adp_conv_desc& d, int64_t ks, void* stream) {
+  if (d.gn_part != nullptr && d.M % 4 == 0) {
+    const int64_t E = adp_conv_splitk_gn_entries(d);
+    ADP_LAUNCH(conv_splitk_reduce_gn_kernel, dim3((unsigned)(d.B * (d.M / 4) * E)), dim3(256), stream, d, (int)ks, (int)E);
+    return ADP_LAUNCH_OK();
+  }
   const int64_t total = d.B * d.M * d.N;
   int64_t g = adp_cdiv(total, 1024);
   if (g > 2048) g = 2048;

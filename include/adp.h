@@ -91,7 +91,8 @@ typedef struct adp_conv_desc {
 
 /* Scratch the launch wants (0 for most shapes).  With ws == NULL the call still succeeds on the unsplit path. */
 int64_t adp_conv1d_ws_bytes(const adp_conv_desc* d);
-/* Slices per output row the epilogue would report statistics for (see gn_part); 0 = not available for this launch. */
+/* Slices per output row the epilogue would report statistics for (see gn_part); 0 = not available for this launch.
+   Depends on whether the launch will K-split: fill in d->ws (adp_conv1d_ws_bytes) BEFORE asking. */
 int64_t adp_conv1d_gn_entries(const adp_conv_desc* d);
 int adp_conv1d(const adp_conv_desc* d, void* stream);
 /* tile the dispatcher selects for this problem, BM*1000+BN (introspection for profiling / roofline reports) */

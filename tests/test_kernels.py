@@ -639,6 +639,8 @@ def test_attention_fwd_bwd(dev, B, H, D, n, m):
     (3, 32, 32, 1280, 3, 1, 1),    # conv_stream32, batch that does not divide the CU count
     (1, 32, 64, 256, 4, 4, 1),     # DownsampleItem (kernel = stride = 4)
     (1, 64, 32, 96, 3, 1, 2),      # UpsampleItem loader with the SkipModulate epilogue
+    (1, 512, 64, 64, 3, 1, 1),     # small grid: cross-workgroup K split, statistics from the reduce kernel
+    (2, 1024, 32, 60, 1, 1, 1),    # K split, kernel 1, ragged rows
 ])
 def test_groupnorm_statistics_from_conv_epilogue(dev, B, R, M, L, KT, stride, up):
     """adp_conv_desc.gn_part: the conv epilogue's per-row (mean, M2, count) slices + adp_gn_finalize reproduce
