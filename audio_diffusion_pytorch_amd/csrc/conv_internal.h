@@ -18,6 +18,13 @@ bool adp_conv_bs_eligible(const adp_conv_desc& d);
 int64_t adp_conv_bs_ksplit(const adp_conv_desc& d);
 int adp_conv_bs(const adp_conv_desc& d, void* stream);
 
+// conv_wino.hip: Winograd F(2,3) form of the wide kernel-3 convs (forward / data gradient, >= 256 channels, materialised
+// input) on the exact-f32 matrix cores: two thirds of the MFMA work of conv_mm
+bool adp_conv_wino_enabled();
+bool adp_conv_wino_eligible(const adp_conv_desc& d);
+int64_t adp_conv_wino_ksplit(const adp_conv_desc& d);
+int adp_conv_wino(const adp_conv_desc& d, void* stream);
+
 // wgrad_mm.hip: wave-specialised weight gradient of the same convolutions (channels % 32 == 0)
 bool adp_wgrad_mm_eligible(const adp_wgrad_desc& d);
 int64_t adp_wgrad_mm_ws_floats(const adp_wgrad_desc& d);

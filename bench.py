@@ -252,21 +252,25 @@ def extra_legs(model, x, dev):
                           "ms_per_step": round(dt / 50 * 1e3, 3), "ms_per_50_step_sample": round(dt * 1e3, 2)}
     except Exception as e:
         out["sampler"] = {"error": f"{type(e).__name__}: {e}"}
-    try:  # opt-in kernel family: the deep convs as six bf16 MFMA products of an exact 3-way split (conv_bs.hip)
-        os.environ["ADP_CONV_BS"] = "1"
+    # opt-in kernel families for the forward / data-gradient convs of the >= 256-channel layers (both off by default):
+    # conv_bs.hip = six bf16 MFMA products of an exact 3-way bf16 split (fp32 accuracy on the bf16 matrix cores),
+    # conv_wino.hip = Winograd F(2,3) on the exact-f32 matrix cores (two thirds of the MFMA work)
+    for key, env, what in (("bf16_split_convs", "ADP_CONV_BS", "on the bf16 matrix cores at fp32 accuracy (3-way bf16 split)"),
+                           ("winograd_convs", "ADP_CONV_WINO", "as Winograd F(2,3) on the f32 matrix cores")):
+        try:
+            os.environ[env] = "1"
 
-        def stepb():
-            zero(model)
-            model(x).backward()
-        dt = _time(_graphed(stepb, lambda: zero(model)), 20)
-        out["bf16_split_convs"] = {"workload": f"headline step ([{x.shape[0]},2,2**18] fwd+bwd) with ADP_CONV_BS=1: forward / "
-                                               "data-gradient convs of the >= 256-channel layers on the bf16 matrix "
-                                               "cores at fp32 accuracy (off by default)",
-                                   "steps_per_s": round(1.0 / dt, 2), "ms_per_step": round(dt * 1e3, 3)}
-    except Exception as e:
-        out["bf16_split_convs"] = {"error": f"{type(e).__name__}: {e}"}
-    finally:
-        os.environ["ADP_CONV_BS"] = "0"
+            def stepb():
+                zero(model)
+                model(x).backward()
+            dt = _time(_graphed(stepb, lambda: zero(model)), 20)
+            out[key] = {"workload": f"headline step ([{x.shape[0]},2,2**18] fwd+bwd) with {env}=1: forward / data-gradient "
+                                    f"convs of the >= 256-channel layers {what} (off by default)",
+                        "steps_per_s": round(1.0 / dt, 2), "ms_per_step": round(dt * 1e3, 3)}
+        except Exception as e:
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            os.environ[env] = "0"
     legs = {
         "readme_attention": (dict(attentions=[0, 0, 0, 0, 0, 1, 1, 1, 1], attention_heads=8, attention_features=64), False),
         "config4": (dict(cross_attentions=[0, 0, 0, 1, 1, 1, 1, 1, 1], embedding_features=768, attention_heads=8,

@@ -105,6 +105,45 @@ def test_conv1d_bf16_split_is_fp32_accurate(dev, B, R, M, L, tr, monkeypatch):
     assert e_bs < 4 * e_32 + 2e-7, (e_bs, e_32)
 
 
+@pytest.mark.parametrize("B,R,M,L,tr", [(2, 256, 64, 200, False), (1, 512, 64, 64, False), (2, 256, 96, 132, True),
+                                        (1, 1024, 32, 64, True), (3, 288, 32, 4, False), (1, 256, 32, 260, True)])
+def test_conv1d_winograd_family(dev, B, R, M, L, tr, monkeypatch):
+    """conv_wino: Winograd F(2,3) form of the wide kernel-3 convs (>= 256 input channels, materialised input) on the
+    exact-f32 matrix cores -- forward and transposed-weight view, ragged last tile, a length shorter than one tile,
+    the cross-workgroup K split, the full epilogue and the GroupNorm partial statistics.  fp32 throughout: the bound
+    against an fp64 reference is 1e-5, next to the direct-form kernel (ADP_CONV_WINO=0) on the same inputs."""
+    x = rnd(B, R, L, seed=1)
+    w = rnd(R, M, 3, seed=2, scale=0.05) if tr else rnd(M, R, 3, seed=2, scale=0.05)
+    b, res, sc = rnd(M, seed=3), rnd(B, M, L, seed=4), rnd(B * M, seed=5)
+    x64, w64 = x.double(), w.double()
+    ref = F.conv_transpose1d(x64, w64, None, padding=1) if tr else F.conv1d(x64, w64, None, padding=1)
+    pre_ref = ref + b.double()[None, :, None]
+    ref = pre_ref * sc.double().view(B, M, 1) + res.double()
+    args = (x.to(dev), w.to(dev), b.to(dev))
+    kw = dict(pad=1, transposed=tr, e_scale=sc.to(dev), res=res.to(dev))
+    err = lambda a, r: ((a.cpu().double() - r).abs().max() / r.abs().max()).item()  # noqa: E731
+    from ctypes import byref
+    from audio_diffusion_pytorch_amd import _C
+    d = _C.ConvDesc(_C.ptr(args[0]), None, _C.ptr(args[1]), None, None, None, None, None, None, _C.ptr(args[0]), None, B, R, R,
+                    L, M, L, 3, 1, 1, 1, 1, int(tr), 0, 1, 0, 1, 0)
+    monkeypatch.setenv("ADP_CONV_WINO", "1")
+    assert _C.query("adp_conv1d_tile", byref(d)) == 4032064, "this shape is meant to take the Winograd kernel"
+    pre = torch.empty(B, M, L).to(dev)
+    gn = ops.GnPart()
+    out = ops.conv1d(*args, out_pre=pre, gn=gn, **kw)
+    monkeypatch.setenv("ADP_CONV_WINO", "0")
+    out_direct = ops.conv1d(*args, **kw)
+    e_w, e_d = err(out, ref), err(out_direct, ref)
+    assert e_w < 1e-5 and err(pre, pre_ref) < 1e-5, (e_w, e_d)
+    assert e_w < 8 * e_d + 1e-6, (e_w, e_d)
+    if M % 32 == 0 and gn.part is not None:
+        st = ops.gn_finalize(gn.part, 8)
+        ref_st = ops.gn_stats(out, 8)
+        assert gn.part[..., 2].sum(dim=2).eq(4 * L).all()
+        assert rel_err(st[..., 1], ref_st[..., 1]) < 1e-5
+        assert (st[..., 0] - ref_st[..., 0]).abs().max() < 1e-5
+
+
 def test_conv1d_big_tile(dev):
     # enough workgroups to select the 128x128 tile on the dispatcher
     B, R, M, L = 6, 32, 128, 1024 if dev.type == "cuda" else 1024
