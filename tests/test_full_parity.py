@@ -218,3 +218,40 @@ def test_sampler_graph_cache_follows_kwargs(hip):
 def up_sample_input(up, low):
     from audio_diffusion_pytorch_amd.utils import upsample
     return upsample(low, factor=up.upsample_factor)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", ["ADP_CONV_WINO", "ADP_CONV_BS"])
+def test_opt_in_conv_families_inside_the_unet(hip, env, monkeypatch):
+    """The opt-in kernel families for the wide convs (Winograd F(2,3); three-way bf16 split) inside a whole U-Net step:
+    loss, prediction and every parameter gradient against the default kernels on the same weights and inputs.  Both
+    are fp32-accurate, so the bound is 1e-4 (ten times tighter than the path's parity tolerance)."""
+    cfg = dict(in_channels=2, channels=[8, 32, 256, 512], factors=[1, 4, 4, 2], items=[1, 1, 2, 2])
+    torch.manual_seed(0)
+    model = adp.DiffusionModel(net_t=adp.UNetV0, diffusion_sigma_distribution=FixedSigmas([0.3, 0.7]), **cfg).to(hip)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 2, 2 ** 13, generator=g).to(hip)
+    t = torch.tensor([0.3, 0.7], device=hip)
+
+    def run():
+        for p in model.parameters():
+            p.grad = None
+        torch.manual_seed(5)  # the same noise draw in VDiffusion
+        loss = model(x)
+        loss.backward()
+        with torch.no_grad():
+            v = model.net(x, t)
+        return loss.detach().clone(), v.clone(), {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    monkeypatch.setenv(env, "0")
+    loss0, v0, g0 = run()
+    monkeypatch.setenv(env, "1")
+    loss1, v1, g1 = run()
+    assert not torch.equal(v0, v1), "the opt-in family was meant to run (different rounding)"
+    assert abs(loss1.item() - loss0.item()) <= 1e-5 * abs(loss0.item())
+    assert rel_err(v1, v0) < 1e-4
+    # (a conv bias that feeds a GroupNorm has a true gradient of zero -- both runs hold cancellation noise there -- so the
+    # denominator is floored at 1e-3 x the largest gradient of the model, as in test_unet.compare_grads)
+    gmax = max(v.abs().max().item() for v in g0.values())
+    worst = max(((g1[n] - g0[n]).abs().max().item() / max(g0[n].abs().max().item(), 1e-3 * gmax), n) for n in g0)
+    assert worst[0] < 1e-4, worst
