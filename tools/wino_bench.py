@@ -63,6 +63,7 @@ def cold():
         nw = max(2, int(600e6 / (C * C * 12)))
         ws = [torch.randn(C, C, 3, device=dev) * 0.05 for _ in range(nw)]
         x = torch.randn(B, C, L, device=dev)
+        xs = [torch.randn(B, C, L, device=dev) for _ in range(nw)]  # cold activations too (fresh tensor per conv)
         row = f"C{C} L{L} ({nw} weight tensors):"
         for mode in ("0", "1"):
             os.environ["ADP_CONV_WINO"] = mode
@@ -75,10 +76,24 @@ def cold():
                 for w in ws:
                     ops.conv1d(x, w, None, pad=1, gn=ops.GnPart())
 
+            def fc():
+                for w, xc in zip(ws, xs):
+                    ops.conv1d(xc, w, None, pad=1)
+
+            def fw():  # written by the kernel right before, as in the model
+                for w, xc in zip(ws, xs):
+                    xc.mul_(1.0)
+                    ops.conv1d(xc, w, None, pad=1)
+
+            def fw0():
+                for xc in xs:
+                    xc.mul_(1.0)
+
             def t():
                 for w in ws:
                     ops.conv1d(x, w, None, pad=1, transposed=True)
-            row += f"  [wino {mode}] fwd {timeit(f, 2) / nw:6.1f} us  fwd+gn_part {timeit(fg, 2) / nw:6.1f} us  dgrad {timeit(t, 2) / nw:6.1f} us"
+            row += (f"  [wino {mode}] fwd {timeit(f, 2) / nw:6.1f} us  cold x {timeit(fc, 2) / nw:6.1f} us  x just written "
+                    f"{(timeit(fw, 2) - timeit(fw0, 2)) / nw:6.1f} us  dgrad {timeit(t, 2) / nw:6.1f} us")
         print(row, flush=True)
 
 
