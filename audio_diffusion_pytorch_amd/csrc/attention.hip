@@ -116,11 +116,14 @@ __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_c
 template <bool D64>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* q, const float* k, const float* v, int H, int D,
                                                        int n, int m, int64_t qbs, int64_t kvbs, float scale,
-                                                       float* o, float* lse) {
+                                                       float* o, float* lse, int nsplit, int tps, float* part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int64_t b = blockIdx.z, h = blockIdx.y;
-  const int i0 = blockIdx.x * 128 + wave * 32;
+  const int qblocks = (n + 127) / 128;
+  const int sp = blockIdx.x / qblocks;  // key split: this wave covers key tiles [sp * tps, (sp + 1) * tps)
+  const int i0 = (blockIdx.x - sp * qblocks) * 128 + wave * 32;
   if (i0 >= n) return;  // no workgroup-wide synchronisation anywhere below
+  const int j_lo = sp * tps * 32, j_hi = (j_lo + tps * 32 < m) ? j_lo + tps * 32 : m;
   const float* qh = q + b * qbs + h * (int64_t)D * n;
   const float* kh = k + b * kvbs + h * (int64_t)D * m;
   const float* vh = v + b * kvbs + h * (int64_t)D * m;
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* q, const flo
 #pragma unroll
     for (int t = 0; t < 2; ++t)
       if (D64 || 32 * t < D) ld_row16<D64>(vh, m, 32 * t + l31, D, j0, hi, full && vec, vr[t]);
-    if (j0 + 32 < m) load_kc(kn, j0 + 32);
+    if (j0 + 32 < j_hi) load_kc(kn, j0 + 32);
 #ifndef ADP_EMULATE
     __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the matrix work
 #endif
@@ -195,10 +198,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* q, const flo
     }
   };
   float ka[DMAX / 2], kb[DMAX / 2];
-  load_kc(ka, 0);
-  for (int j0 = 0; j0 < m; j0 += 64) {  // two tiles per trip: the register sets swap roles statically
+  load_kc(ka, j_lo);
+  for (int j0 = j_lo; j0 < j_hi; j0 += 64) {  // two tiles per trip: the register sets swap roles statically
     tile(ka, kb, j0);
-    if (j0 + 32 < m) tile(kb, ka, j0 + 32);
+    if (j0 + 32 < j_hi) tile(kb, ka, j0 + 32);
+  }
+  if (nsplit > 1) {
+    // partial result of this key range: un-normalised O^T, running maximum and sum; attn_fwd_combine_kernel merges the
+    // nsplit partials in split order.  part = [nsplit][B*H][D][n] | m [nsplit][B*H][n] | l [nsplit][B*H][n]
+    const int64_t BH = (int64_t)gridDim.z * H, bh = b * H + h;
+    float* po = part + ((int64_t)sp * BH + bh) * D * n;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dd = 32 * t + acc_row(r, hi);
+        if (dd < D && qok) po[(int64_t)dd * n + iq] = oacc[t][r];
+      }
+    if (hi == 0 && qok) {
+      float* pm = part + (int64_t)nsplit * BH * D * n + ((int64_t)sp * BH + bh) * n;
+      pm[iq] = mrun;
+      pm[(int64_t)nsplit * BH * n + iq] = lrun;
+    }
+    return;
   }
   const float inv = (lrun > 0.0f) ? 1.0f / lrun : 0.0f;
   float* oh = o + (b * H + h) * (int64_t)D * n;
@@ -210,6 +232,45 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* q, const flo
       if (dd < D && qok) oh[dd * n + iq] = oacc[t][r] * inv;
     }
   if (hi == 0 && qok) lse[(b * H + h) * (int64_t)n + iq] = mrun + logf(lrun);
+}
+
+// merge of the forward key split (fixed order): M = max_s m_s, w_s = exp(m_s - M), L = sum_s w_s l_s,
+// o[d][i] = sum_s w_s O_s[d][i] / L, lse = M + log L.  One workgroup = 64 queries x 4 channels (blockIdx.z picks the
+// channel quad): every thread owns one output element, so the launch is wide instead of long.
+__global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float* part, int nsplit, int D, int64_t n, int64_t BH,
+                                                               float* o, float* lse) {
+  const int ql = threadIdx.x & 63, d = blockIdx.z * 4 + (threadIdx.x >> 6);
+  const int64_t bh = blockIdx.y, i = (int64_t)blockIdx.x * 64 + ql;
+  if (i >= n || d >= D) return;
+  const float* pm = part + (int64_t)nsplit * BH * D * n + bh * n + i;
+  const int64_t sstride = BH * n;  // between splits of m / l
+  float mv[8], pv[8];
+  float M = -3.0e38f;
+  for (int s = 0; s < nsplit; ++s) {
+    mv[s] = pm[s * sstride];
+    pv[s] = part[(((int64_t)s * BH + bh) * D + d) * n + i];
+    M = fmaxf(M, mv[s]);
+  }
+  float L = 0.0f, a = 0.0f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float w = __expf(mv[s] - M);
+    L += w * pm[(int64_t)nsplit * sstride + s * sstride];
+    a += w * pv[s];
+  }
+  o[(bh * D + d) * n + i] = L > 0.0f ? a / L : 0.0f;
+  if (d == 0) lse[bh * n + i] = M + logf(L);
+}
+
+// out[b][e] = sum_{sp < nsplit} part[sp * pstride + b * bstride + e], e < cnt (fixed order); blockIdx.y = b
+__global__ __launch_bounds__(256) void attn_sum_splits_kernel(const float* part, int nsplit, int64_t pstride, int64_t bstride,
+                                                              int64_t cnt, float* out) {
+  const float* p = part + blockIdx.y * bstride;
+  float* o = out + blockIdx.y * bstride;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < cnt; e += (int64_t)gridDim.x * 256) {
+    float a = 0.0f;
+    for (int sp = 0; sp < nsplit; ++sp) a += p[sp * pstride + e];
+    o[e] = a;
+  }
 }
 
 // delta[b,h,i] = sum_d dO[d,i] * O[d,i].  One workgroup = 64 queries x 4 channel groups (lanes along the queries:
@@ -377,11 +438,14 @@ template <bool D64>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* q, const float* k, const float* v,
                                                          const float* dout, const float* lse, const float* delta,
                                                          int H, int D, int n, int m, int64_t qbs, int64_t kvbs,
-                                                         float scale, float* dq) {
+                                                         float scale, float* dq, int tps, int64_t pstride) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int64_t b = blockIdx.z, h = blockIdx.y;
-  const int i0 = blockIdx.x * 128 + wave * 32;
+  const int qblocks = (n + 127) / 128;
+  const int sp = blockIdx.x / qblocks;  // key split (partial dq tiles go to dq + sp * pstride, summed afterwards)
+  const int i0 = (blockIdx.x - sp * qblocks) * 128 + wave * 32;
   if (i0 >= n) return;
+  const int j_lo = sp * tps * 32, j_hi = (j_lo + tps * 32 < m) ? j_lo + tps * 32 : m;
   const float* qh = q + b * qbs + h * (int64_t)D * n;
   const float* kh = k + b * kvbs + h * (int64_t)D * m;
   const float* vh = v + b * kvbs + h * (int64_t)D * m;
@@ -418,7 +482,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* q, const f
 #pragma unroll
     for (int t = 0; t < 2; ++t)
       if (D64 || 32 * t < D) ld_row16<D64>(kh, m, 32 * t + l31, D, j0, hi, full && vec, kr[t]);
-    if (j0 + 32 < m) load_c(kn, vn, j0 + 32);
+    if (j0 + 32 < j_hi) load_c(kn, vn, j0 + 32);
 #ifndef ADP_EMULATE
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -446,12 +510,12 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* q, const f
     }
   };
   float ka[DMAX / 2], va[DMAX / 2], kb[DMAX / 2], vb[DMAX / 2];
-  load_c(ka, va, 0);
-  for (int j0 = 0; j0 < m; j0 += 64) {
+  load_c(ka, va, j_lo);
+  for (int j0 = j_lo; j0 < j_hi; j0 += 64) {
     tile(ka, va, kb, vb, j0);
-    if (j0 + 32 < m) tile(kb, vb, ka, va, j0 + 32);
+    if (j0 + 32 < j_hi) tile(kb, vb, ka, va, j0 + 32);
   }
-  float* dqh = dq + b * qbs + h * (int64_t)D * n;
+  float* dqh = dq + sp * pstride + b * qbs + h * (int64_t)D * n;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -471,6 +535,19 @@ int64_t kv_nsplit(int64_t B, int64_t H, int64_t n, int64_t m) {
   return ns;
 }
 
+// key split of the query-major passes (forward, dq): when B * H * query tiles leaves most SIMDs idle (batch 1: 256 waves
+// at n = 1024, 32 at n = 128) the key range is cut into up to 8 slices run by separate waves
+int64_t q_nsplit(int64_t B, int64_t H, int64_t n, int64_t m, int64_t* tps_out) {
+  const int64_t ktiles = (m + 31) / 32, qtiles = (n + 31) / 32;
+  int64_t ns = 1024 / (B * H * qtiles);
+  if (ns > 8) ns = 8;
+  if (ns > ktiles / 2) ns = ktiles / 2;  // at least two key tiles per slice (cross attention over 64 keys: no split)
+  if (ns < 1) ns = 1;
+  const int64_t tps = (ktiles + ns - 1) / ns;
+  *tps_out = tps;
+  return (ktiles + tps - 1) / tps;  // every slice non-empty
+}
+
 bool attn_shape_ok(int64_t B, int64_t H, int64_t D, int64_t n, int64_t m) {
   return B > 0 && H > 0 && D >= 2 && D <= DMAX && (D % 2 == 0) && n > 0 && m > 0 && B <= 65535 && H <= 65535 &&
          D * n < ((int64_t)1 << 31) && D * m < ((int64_t)1 << 31);  // 32-bit element offsets inside one head's slab
@@ -478,28 +555,44 @@ bool attn_shape_ok(int64_t B, int64_t H, int64_t D, int64_t n, int64_t m) {
 
 }  // namespace
 
+extern "C" int64_t adp_attn_fwd_ws_bytes(int64_t B, int64_t H, int64_t D, int64_t n, int64_t m) {
+  if (!attn_shape_ok(B, H, D, n, m)) return ADP_ERR_SHAPE;
+  int64_t tps;
+  const int64_t ns = q_nsplit(B, H, n, m, &tps);
+  return ns > 1 ? ns * B * H * (D * n + 2 * n) * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int adp_attn_fwd(const float* q, const float* k, const float* v, int64_t B, int64_t H, int64_t D,
                             int64_t n, int64_t m, int64_t q_bstride, int64_t kv_bstride, float* o, float* lse,
-                            void* stream) {
+                            float* ws, void* stream) {
   if (!q || !k || !v || !o || !lse) return ADP_ERR_NULL;
   if (!attn_shape_ok(B, H, D, n, m)) return ADP_ERR_SHAPE;
   const float scale = 1.0f / sqrtf((float)D);
-  const dim3 grid((unsigned)adp_cdiv(n, 128), (unsigned)H, (unsigned)B);
+  int64_t tps = adp_cdiv(m, 32);
+  const int64_t ns = ws ? q_nsplit(B, H, n, m, &tps) : 1;
+  if (ns == 1) tps = adp_cdiv(m, 32);
+  const dim3 grid((unsigned)(adp_cdiv(n, 128) * ns), (unsigned)H, (unsigned)B);
   if (D == 64)
     ADP_LAUNCH(attn_fwd_kernel<true>, grid, dim3(256), stream, q, k, v, (int)H, (int)D, (int)n, (int)m, q_bstride,
-               kv_bstride, scale, o, lse);
+               kv_bstride, scale, o, lse, (int)ns, (int)tps, ws);
   else
     ADP_LAUNCH(attn_fwd_kernel<false>, grid, dim3(256), stream, q, k, v, (int)H, (int)D, (int)n, (int)m, q_bstride,
-               kv_bstride, scale, o, lse);
+               kv_bstride, scale, o, lse, (int)ns, (int)tps, ws);
+  if (ns > 1)
+    ADP_LAUNCH(attn_fwd_combine_kernel, dim3((unsigned)adp_cdiv(n, 64), (unsigned)(B * H), (unsigned)adp_cdiv(D, 4)), dim3(256), stream,
+               (const float*)ws, (int)ns, (int)D, n, B * H, o, lse);
   return ADP_LAUNCH_OK();
 }
 
 extern "C" int64_t adp_attn_bwd_ws_bytes(int64_t B, int64_t H, int64_t D, int64_t n, int64_t m) {
   if (!attn_shape_ok(B, H, D, n, m)) return ADP_ERR_SHAPE;
   const int64_t ns = kv_nsplit(B, H, n, m);
+  int64_t tps;
+  const int64_t nq = q_nsplit(B, H, n, m, &tps);
   // delta [B, H, n] + (query-split dk/dv pass) nsplit partial copies of dk and of dv, each B * kv_bstride floats at
-  // most 2*H*D*m per batch element (k and v are the two halves of one projection output)
-  return (B * H * n + (ns > 1 ? 2 * ns * B * 2 * H * D * m : 0)) * (int64_t)sizeof(float);
+  // most 2*H*D*m per batch element (k and v are the two halves of one projection output) + (key-split dq pass) nq
+  // partial copies of dq (packed q: q_bstride = H*D*n)
+  return (B * H * n + (ns > 1 ? 2 * ns * B * 2 * H * D * m : 0) + (nq > 1 ? nq * B * H * D * n : 0)) * (int64_t)sizeof(float);
 }
 
 extern "C" int adp_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
@@ -523,7 +616,6 @@ extern "C" int adp_attn_bwd(const float* q, const float* k, const float* v, cons
     pv = pk + ns * pstride;
   }
   const dim3 gkv((unsigned)adp_cdiv(ktiles * ns, 4), (unsigned)H, (unsigned)B);
-  const dim3 gq((unsigned)adp_cdiv(n, 128), (unsigned)H, (unsigned)B);
   if (D == 64)
     ADP_LAUNCH(attn_bwd_kv_kernel<true>, gkv, dim3(256), stream, q, k, v, dout, lse, (const float*)ws, (int)H, (int)D,
                (int)n, (int)m, q_bstride, kv_bstride, scale, (int)ns, (int)tps, pstride, pk, pv);
@@ -533,11 +625,26 @@ extern "C" int adp_attn_bwd(const float* q, const float* k, const float* v, cons
   if (ns > 1)  // dk and dv are [H*D, m] slabs inside each batch stride
     ADP_LAUNCH(attn_kv_reduce_kernel, dim3((unsigned)adp_cdiv(H * D * m, 1024), (unsigned)(2 * B)), dim3(256), stream,
                (const float*)pk, (const float*)pv, (int)ns, pstride, kv_bstride, H * D * m, dk, dv);
+  // query-major pass, key-split when the query tiles alone do not fill the chip (needs packed q: one partial copy is
+  // addressed exactly like dq)
+  int64_t qtps = ktiles;
+  int64_t nq = (q_bstride == H * D * n) ? q_nsplit(B, H, n, m, &qtps) : 1;
+  if (nq == 1) qtps = ktiles;
+  float* pq = dq;
+  int64_t qstride = 0;
+  if (nq > 1) {
+    pq = ws + B * H * n + (ns > 1 ? 2 * ns * pstride : 0);
+    qstride = B * q_bstride;
+  }
+  const dim3 gq2((unsigned)(adp_cdiv(n, 128) * nq), (unsigned)H, (unsigned)B);
   if (D == 64)
-    ADP_LAUNCH(attn_bwd_q_kernel<true>, gq, dim3(256), stream, q, k, v, dout, lse, (const float*)ws, (int)H, (int)D,
-               (int)n, (int)m, q_bstride, kv_bstride, scale, dq);
+    ADP_LAUNCH(attn_bwd_q_kernel<true>, gq2, dim3(256), stream, q, k, v, dout, lse, (const float*)ws, (int)H, (int)D,
+               (int)n, (int)m, q_bstride, kv_bstride, scale, pq, (int)qtps, qstride);
   else
-    ADP_LAUNCH(attn_bwd_q_kernel<false>, gq, dim3(256), stream, q, k, v, dout, lse, (const float*)ws, (int)H, (int)D,
-               (int)n, (int)m, q_bstride, kv_bstride, scale, dq);
+    ADP_LAUNCH(attn_bwd_q_kernel<false>, gq2, dim3(256), stream, q, k, v, dout, lse, (const float*)ws, (int)H, (int)D,
+               (int)n, (int)m, q_bstride, kv_bstride, scale, pq, (int)qtps, qstride);
+  if (nq > 1)
+    ADP_LAUNCH(attn_sum_splits_kernel, dim3((unsigned)adp_cdiv(H * D * n, 1024), (unsigned)B), dim3(256), stream,
+               (const float*)pq, (int)nq, qstride, q_bstride, H * D * n, dq);
   return ADP_LAUNCH_OK();
 }

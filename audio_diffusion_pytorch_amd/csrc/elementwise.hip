@@ -202,7 +202,7 @@ unsigned stream_grid(int64_t n) {
 
 }  // namespace
 
-extern "C" int adp_version(void) { return 200; }
+extern "C" int adp_version(void) { return 201; }
 
 // ---- launch trace (profiling introspection; off by default, host-side only, per thread)
 namespace {

@@ -471,9 +471,11 @@ def attn_fwd(q: Tensor, kv: Tensor, heads: int, head_features: int):
     o = torch.empty_like(q)
     lse = torch.empty((B, H, n), dtype=torch.float32, device=q.device)
     kvf = kv.view(-1)
+    need = _C.query("adp_attn_fwd_ws_bytes", B, H, D, n, m)
+    ws = _ws(need, q) if need > 0 else None  # key-split partials (small grids)
     _C.tag(flops=4 * B * H * n * m * D, bytes=4 * (2 * q.numel() + kv.numel()), shape=f"B{B} H{H} D{D} n{n} m{m}")
     _C.call("adp_attn_fwd", ptr(q), ptr(kvf), ptr(kvf[mid * m:]), B, H, D, n, m, mid * n, 2 * mid * m, ptr(o),
-            ptr(lse), _C.stream())
+            ptr(lse), ptr(ws), _C.stream())
     return o, lse
 
 

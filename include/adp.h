@@ -250,8 +250,11 @@ int adp_v_step(const float* x, const float* v, const float* ab4, int64_t n, floa
  *   q [B, H*D, n], k,v [B, H*D, m]  ->  o [B, H*D, n] = softmax(q^T k * D^-0.5) v   per head
  * lse [B, H, n] (log-sum-exp) is written for the backward pass.
  * ------------------------------------------------------------------------------------------ */
+/* ws: scratch of adp_attn_fwd_ws_bytes() bytes or NULL.  With it, small grids (batch 1) split the key range over
+ * several waves per query tile and merge the partial softmax results in a second launch (fixed order). */
 int adp_attn_fwd(const float* q, const float* k, const float* v, int64_t B, int64_t H, int64_t D, int64_t n,
-                 int64_t m, int64_t q_bstride, int64_t kv_bstride, float* o, float* lse, void* stream);
+                 int64_t m, int64_t q_bstride, int64_t kv_bstride, float* o, float* lse, float* ws, void* stream);
+int64_t adp_attn_fwd_ws_bytes(int64_t B, int64_t H, int64_t D, int64_t n, int64_t m);
 int adp_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
                  const float* lse, int64_t B, int64_t H, int64_t D, int64_t n, int64_t m, int64_t q_bstride,
                  int64_t kv_bstride, float* dq, float* dk, float* dv, float* ws, void* stream);
