@@ -86,7 +86,7 @@ def profiled_step(model, step):
 
 
 def roofline_leg(model, x, top: int = 14):
-    """One instrumented eager step: while recording is on, libadp_hip.so brackets EVERY kernel launch with a pair of
+    """Three instrumented eager steps (after two warm ones), averaged per step: while recording is on, libadp_hip.so brackets EVERY kernel launch with a pair of
     HIP events recorded on the stream the kernel is launched on (`adp_launch_trace` / `adp_launch_times`) and names
     the kernel instantiation (the spelling rocprofv3 prints); the host layer attaches the ALGORITHMIC flops / bytes of
     the call.  Reports
@@ -96,14 +96,21 @@ def roofline_leg(model, x, top: int = 14):
       kernels                  the `top` kernels by total time.
     `traffic` (HBM bytes per launch from the rocprofv3 PMC passes) is looked up in profiles/pmc_traffic.json, which
     tools/pmc_summary.py writes from the FETCH_SIZE / WRITE_SIZE passes of this same command."""
-    recs = profiled_step(model, lambda: model(x).backward())
+    NREP = 3  # instrumented steps (after two warm ones: the clocks settle); everything below is per step
+    for _ in range(2):
+        profiled_step(model, lambda: model(x).backward())
+    recs = []
+    for _ in range(NREP):
+        recs += profiled_step(model, lambda: model(x).backward())
     agg = {}
     for call, kern, meta, ms in recs:
         a = agg.setdefault(kern, {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0})
         a["launches"] += 1
-        a["ms"] += ms
-        a["flops"] += meta.get("flops", 0)
-        a["bytes"] += meta.get("bytes", 0)
+        a["ms"] += ms / NREP
+        a["flops"] += meta.get("flops", 0) / NREP
+        a["bytes"] += meta.get("bytes", 0) / NREP
+    for a in agg.values():
+        a["launches"] = max(1, round(a["launches"] / NREP))
     pmc = {}
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -123,7 +130,7 @@ def roofline_leg(model, x, top: int = 14):
         e["frac"] = round(e["achieved"] / e["peak"], 4)
         t = pmc.get(name.split(" | ")[0])
         e["traffic"] = t.get("hbm_bytes_per_launch") if t else None
-        e["algorithmic_bytes_per_launch"] = a["bytes"] // a["launches"]
+        e["algorithmic_bytes_per_launch"] = int(a["bytes"] // a["launches"])
         return e
 
     detail_path = os.environ.get("ADP_BENCH_DETAIL")
@@ -137,6 +144,7 @@ def roofline_leg(model, x, top: int = 14):
             a[3] += meta.get("bytes", 0)
         with open(detail_path, "w") as f:
             for k, (n, ms, fl, by) in sorted(det.items(), key=lambda kv: -kv[1][1]):
+                n, ms, fl, by = max(1, n // NREP), ms / NREP, fl / NREP, by / NREP  # per step
                 f.write(f"{ms:8.3f} ms  n={n:3d}  avg {ms / n * 1e3:7.1f} us  {fl / ms / 1e9:6.1f} TF  {by / ms / 1e6:7.1f} GB/s  {k}\n")
     total_ms = sum(a["ms"] for a in agg.values())
     order = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
@@ -156,6 +164,7 @@ def roofline_leg(model, x, top: int = 14):
                 names.append(kern)
     hbm = None
     if hb["launches"]:
+        hb = {"launches": max(1, hb["launches"] // NREP), "ms": hb["ms"] / NREP, "flops": 0, "bytes": hb["bytes"] / NREP}
         hbm = entry(" | ".join(sorted(names)), hb)
         hbm["traffic"] = None
         hbm["what"] = "forward ConvBlock convs (GroupNorm+SiLU prologue, k=3) of depths 0-1: A_in + A_out (+A_res) bytes"
