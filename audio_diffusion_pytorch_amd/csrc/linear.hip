@@ -11,6 +11,10 @@ namespace {
 
 constexpr int LIN_BMAX = 16;
 constexpr int LIN_KC = 1024;  // K chunk held in LDS: 16 rows x 1024 x 4 B = 64 KiB max
+// output rows per wave: the activation rows are staged (and their SiLU evaluated) once per workgroup, so a workgroup
+// should stream more than four weight rows behind them -- 8 per wave = 128 KiB of weights per 16 KiB staged
+constexpr int LIN_RPW = 8;
+static inline int64_t lin_rpw(int64_t N) { return N >= 4096 ? LIN_RPW : 1; }
 
 __device__ __forceinline__ float lin_act(float x, int act) {
   return act == 1 ? adp_silu(x) : (act == 2 ? adp_gelu(x) : x);
@@ -29,20 +33,22 @@ __device__ __forceinline__ void lin_stage(const float* x, int64_t B, int64_t K, 
 template <int BT>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* x, const float* w, const float* bias,
                                                          int64_t B, int64_t K, int64_t N, int act, int post,
-                                                         int64_t ybstride, float* y) {
+                                                         int64_t ybstride, float* y, int rpw) {
   __shared__ float xs[BT * LIN_KC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t n = (int64_t)blockIdx.x * 4 + wave;
-  float acc[BT];
-#pragma unroll
-  for (int b = 0; b < BT; ++b) acc[b] = 0.0f;
+  const int64_t nbase = ((int64_t)blockIdx.x * 4 + wave) * rpw;
   const bool vec = (K % 4 == 0);
   for (int64_t k0 = 0; k0 < K; k0 += LIN_KC) {
     const int kc = (int)((K - k0) < LIN_KC ? (K - k0) : LIN_KC);
     __syncthreads();
     lin_stage(x, B, K, k0, kc, act, xs);
     __syncthreads();
-    if (n < N) {
+    for (int r = 0; r < rpw; ++r) {
+      const int64_t n = nbase + r;
+      if (n >= N) break;
+      float acc[BT];
+#pragma unroll
+      for (int b = 0; b < BT; ++b) acc[b] = 0.0f;
       const float* wr = w + n * K + k0;
 #pragma unroll 4
       for (int k = lane * 4; k < kc; k += 256) {  // a 1024-wide row is four independent 16-byte loads per lane
@@ -64,15 +70,17 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* x, const f
           }
         }
       }
-    }
-  }
+      // (K <= LIN_KC for every layer with rpw > 1; longer rows accumulate through y)
 #pragma unroll
-  for (int b = 0; b < BT; ++b) {
-    const float s = adp_wave_sum(acc[b]);
-    if (lane == 0 && n < N && b < B) {
-      float v = s + (bias ? bias[n] : 0.0f);
-      if (post == 2) v = adp_gelu(v);
-      y[b * ybstride + n] = v;
+      for (int b = 0; b < BT; ++b) {
+        const float sres = adp_wave_sum(acc[b]);
+        if (lane == 0 && b < B) {
+          float v = sres + ((k0 == 0 && bias) ? bias[n] : 0.0f);
+          if (k0 > 0) v += y[b * ybstride + n];
+          if (post == 2 && k0 + LIN_KC >= K) v = adp_gelu(v);
+          y[b * ybstride + n] = v;
+        }
+      }
     }
   }
 }
@@ -156,32 +164,54 @@ __global__ __launch_bounds__(256) void linear_bwd_data_kernel(const float* dy, i
 template <int BT>
 __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float* dy, int64_t dybstride, const float* x,
                                                                 int64_t B, int64_t K, int64_t N, int act,
-                                                                int accumulate, float* dw, float* dbias) {
-  __shared__ float xs[BT * LIN_KC];
+                                                                int accumulate, float* dw, float* dbias, int rpw) {
+  __shared__ __attribute__((aligned(16))) float xs[BT * LIN_KC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t n = (int64_t)blockIdx.x * 4 + wave;
-  float d[BT];
-#pragma unroll
-  for (int b = 0; b < BT; ++b) d[b] = (b < B && n < N) ? dy[b * dybstride + n] : 0.0f;
-  if (dbias && lane == 0 && n < N) {
-    float s = 0.0f;
-#pragma unroll
-    for (int b = 0; b < BT; ++b) s += d[b];
-    dbias[n] = accumulate ? dbias[n] + s : s;
-  }
+  const int64_t nbase = ((int64_t)blockIdx.x * 4 + wave) * rpw;
+  const bool vec = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(dw) & 15) == 0);
   for (int64_t k0 = 0; k0 < K; k0 += LIN_KC) {
     const int kc = (int)((K - k0) < LIN_KC ? (K - k0) : LIN_KC);
     __syncthreads();
     lin_stage(x, B, K, k0, kc, act, xs);
     __syncthreads();
-    if (n < N) {
-      for (int k = lane; k < kc; k += 64) {
+    for (int r = 0; r < rpw; ++r) {
+      const int64_t n = nbase + r;
+      if (n >= N) break;
+      float d[BT];
+#pragma unroll
+      for (int b = 0; b < BT; ++b) d[b] = (b < B) ? dy[b * dybstride + n] : 0.0f;
+      if (k0 == 0 && dbias && lane == 0) {
         float s = 0.0f;
 #pragma unroll
-        for (int b = 0; b < BT; ++b)
-          if (b < B) s = fmaf(d[b], xs[b * LIN_KC + k], s);
-        float* o = dw + n * K + k0 + k;
-        *o = accumulate ? *o + s : s;
+        for (int b = 0; b < BT; ++b) s += d[b];
+        dbias[n] = accumulate ? dbias[n] + s : s;
+      }
+      float* orow = dw + n * K + k0;
+      if (vec) {
+        for (int k = lane * 4; k < kc; k += 256) {  // 16-byte stores: the gradient rows are what bounds this kernel
+          f32x4 sv = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int b = 0; b < BT; ++b)
+            if (b < B) {
+              const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + b * LIN_KC + k);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) sv[j] = fmaf(d[b], xv[j], sv[j]);
+            }
+          if (accumulate) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(orow + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sv[j] += o[j];
+          }
+          *reinterpret_cast<f32x4*>(orow + k) = sv;
+        }
+      } else {
+        for (int k = lane; k < kc; k += 64) {
+          float s = 0.0f;
+#pragma unroll
+          for (int b = 0; b < BT; ++b)
+            if (b < B) s = fmaf(d[b], xs[b * LIN_KC + k], s);
+          orow[k] = accumulate ? orow[k] + s : s;
+        }
       }
     }
   }
@@ -202,9 +232,10 @@ extern "C" int adp_linear_fwd(const float* x, const float* w, const float* bias,
   if (B <= 0 || B > LIN_BMAX || K <= 0 || N <= 0) return ADP_ERR_SHAPE;
   if (act < 0 || act > 2 || (post != 0 && post != 2)) return ADP_ERR_UNSUPPORTED;
   if (y_bstride == 0) y_bstride = N;
-  dim3 grid((unsigned)adp_cdiv(N, 4));
+  const int64_t rpw = lin_rpw(N);
+  dim3 grid((unsigned)adp_cdiv(N, 4 * rpw));
   LIN_DISPATCH(B, ADP_LAUNCH((linear_fwd_kernel<BT>), grid, dim3(256), stream, x, w, bias, B, K, N, (int)act,
-                             (int)post, y_bstride, y));
+                             (int)post, y_bstride, y, (int)rpw));
   return ADP_LAUNCH_OK();
 }
 
@@ -233,8 +264,9 @@ extern "C" int adp_linear_bwd_weight(const float* dy, int64_t dy_bstride, const 
   if (B <= 0 || B > LIN_BMAX || K <= 0 || N <= 0) return ADP_ERR_SHAPE;
   if (act < 0 || act > 2) return ADP_ERR_UNSUPPORTED;
   if (dy_bstride == 0) dy_bstride = N;
-  dim3 grid((unsigned)adp_cdiv(N, 4));
+  const int64_t rpw = lin_rpw(N);
+  dim3 grid((unsigned)adp_cdiv(N, 4 * rpw));
   LIN_DISPATCH(B, ADP_LAUNCH((linear_bwd_weight_kernel<BT>), grid, dim3(256), stream, dy, dy_bstride, x, B, K, N,
-                             (int)act, (int)accumulate, dw, dbias));
+                             (int)act, (int)accumulate, dw, dbias, (int)rpw));
   return ADP_LAUNCH_OK();
 }

@@ -623,10 +623,31 @@ __global__ __launch_bounds__(256) void skipmod_bwd_kernel(const float* g, const 
   const float sc = scale[b * sbstride + c];
   const int64_t lo = split * CL, hi = (lo + CL < L) ? lo + CL : L;
   float dot = 0.0f;
-  for (int64_t l = lo + threadIdx.x; l < hi; l += 256) {
-    const float gv = g[row * L + l];
-    dot = fmaf(gv, x[row * L + l], dot);
-    dx[row * L + l] = sc * gv;
+  const float* gr = g + row * L;
+  const float* xr = x + row * L;
+  float* dr = dx + row * L;
+  // 16-byte accesses when the slice is tileable by 4 and the rows are aligned (the 4-byte loop ran the depth-0 merge,
+  // 8 rows of 262144, at 0.27 TB/s)
+  const bool vec = ((L | CL) & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+  if (vec) {
+    for (int64_t l = lo + 4 * (int64_t)threadIdx.x; l < hi; l += 1024) {
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(gr + l);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + l);
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        dot = fmaf(gv[k], xv[k], dot);
+        o[k] = sc * gv[k];
+      }
+      *reinterpret_cast<f32x4*>(dr + l) = o;
+    }
+  } else {
+    for (int64_t l = lo + threadIdx.x; l < hi; l += 256) {
+      const float gv = gr[l];
+      dot = fmaf(gv, xr[l], dot);
+      dr[l] = sc * gv;
+    }
   }
   dot = adp_block_sum<4>(dot, sh);
   if (threadIdx.x == 0) ws[row * NS + split] = dot;
