@@ -177,7 +177,8 @@ WdPlan wd_plan(const adp_wgrad_desc& d) {
   return p;
 }
 
-constexpr int WD_LDS_SMALL = 5120, WD_LDS_BIG = 16384;  // floats: 20 KiB / 64 KiB
+constexpr int WD_LDS_SMALL = 5120, WD_LDS_BIG = 16640;  // floats: 20 KiB / 65 KiB (the 8 -> 32 channel kernel-4 stride-4
+                                                         // DownsampleItem needs 16544: two workgroups per CU either way)
 
 template <int KT, int S, int UP>
 int launch_wd(const adp_wgrad_desc& d, void* stream) {
