@@ -251,13 +251,16 @@ __global__ __launch_bounds__((WN_NMMA + WN_NLD) * 64, 4) void conv_wino_kernel(a
 
 }  // namespace
 
-// Opt-in (read per call): ADP_CONV_WINO=1 routes the eligible convs here instead of conv_mm.  Isolated launches are
-// 8-15 % faster than conv_mm on the batch-4 shapes, inside the U-Net step the gain shrinks to 0.8 % (and batch 1 loses
-// 1 %): the loaders' transform arithmetic and LDS traffic share the SIMDs with the f32 MFMAs.
-bool adp_conv_wino_enabled() {
+// ADP_CONV_WINO (read per call): unset = on for grids of >= 400 tiles (the batch >= 4 shapes of the wide layers: +0.8 %
+// on the step, interleaved A/B on three boxes), "1" = on for every eligible conv, "0" = off.  Small grids (batch 1:
+// K-split launches of 8-16 chunks) lose 1 % and stay on conv_mm.  Isolated launches are 8-15 % faster than conv_mm;
+// inside the step most of that is lost because the loaders' transform arithmetic and LDS traffic share the SIMDs with
+// the f32 MFMAs.
+int adp_conv_wino_mode() {
   const char* e = getenv("ADP_CONV_WINO");
-  return e != nullptr && e[0] == '1';
+  return e == nullptr ? 2 : (e[0] == '1' ? 1 : 0);
 }
+bool adp_conv_wino_enabled() { return adp_conv_wino_mode() != 0; }
 
 bool adp_conv_wino_eligible(const adp_conv_desc& d) {
   if (d.KT != 3 || d.stride != 1 || d.up != 1 || d.dil != 1 || d.pad != 1 || d.prologue != 0 || d.store != 0) return false;
@@ -267,6 +270,7 @@ bool adp_conv_wino_eligible(const adp_conv_desc& d) {
        reinterpret_cast<uintptr_t>(d.res) | reinterpret_cast<uintptr_t>(d.out_pre) | reinterpret_cast<uintptr_t>(d.ws)) & 15)
     return false;
   if (d.B * d.R * d.Lin >= (int64_t)1 << 31 || d.M * d.R * 3 >= (int64_t)1 << 31) return false;
+  if (adp_conv_wino_mode() == 2 && (d.M / WN_BM) * adp_cdiv(d.N, WN_BN) * d.B < 400) return false;  // default: big grids
   return true;
 }
 

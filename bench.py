@@ -261,25 +261,31 @@ def extra_legs(model, x, dev):
                           "ms_per_step": round(dt / 50 * 1e3, 3), "ms_per_50_step_sample": round(dt * 1e3, 2)}
     except Exception as e:
         out["sampler"] = {"error": f"{type(e).__name__}: {e}"}
-    # opt-in kernel families for the forward / data-gradient convs of the >= 256-channel layers (both off by default):
-    # conv_bs.hip = six bf16 MFMA products of an exact 3-way bf16 split (fp32 accuracy on the bf16 matrix cores),
-    # conv_wino.hip = Winograd F(2,3) on the exact-f32 matrix cores (two thirds of the MFMA work)
-    for key, env, what in (("bf16_split_convs", "ADP_CONV_BS", "on the bf16 matrix cores at fp32 accuracy (3-way bf16 split)"),
-                           ("winograd_convs", "ADP_CONV_WINO", "as Winograd F(2,3) on the f32 matrix cores")):
+    # kernel-family A/B on the headline step (forward / data-gradient convs of the >= 256-channel layers):
+    #   default             conv_wino.hip (Winograd F(2,3) on the exact-f32 matrix cores, two thirds of the MFMA work) for
+    #                       grids of >= 400 tiles, conv_mm.hip otherwise
+    #   direct_form_convs   ADP_CONV_WINO=0: conv_mm.hip everywhere (the round-1 / early round-2 default)
+    #   bf16_split_convs    ADP_CONV_BS=1: conv_bs.hip, six bf16 MFMA products of an exact 3-way bf16 split (opt-in)
+    for key, env, val, what in (("direct_form_convs", "ADP_CONV_WINO", "0", "in the direct form on the f32 matrix cores (conv_mm only)"),
+                                ("bf16_split_convs", "ADP_CONV_BS", "1", "on the bf16 matrix cores at fp32 accuracy (3-way bf16 split; opt-in)")):
+        prev = os.environ.get(env)
         try:
-            os.environ[env] = "1"
+            os.environ[env] = val
 
             def stepb():
                 zero(model)
                 model(x).backward()
             dt = _time(_graphed(stepb, lambda: zero(model)), 20)
-            out[key] = {"workload": f"headline step ([{x.shape[0]},2,2**18] fwd+bwd) with {env}=1: forward / data-gradient "
-                                    f"convs of the >= 256-channel layers {what} (off by default)",
+            out[key] = {"workload": f"headline step ([{x.shape[0]},2,2**18] fwd+bwd) with {env}={val}: forward / data-gradient "
+                                    f"convs of the >= 256-channel layers {what}",
                         "steps_per_s": round(1.0 / dt, 2), "ms_per_step": round(dt * 1e3, 3)}
         except Exception as e:
             out[key] = {"error": f"{type(e).__name__}: {e}"}
         finally:
-            os.environ[env] = "0"
+            if prev is None:
+                os.environ.pop(env, None)
+            else:
+                os.environ[env] = prev
     legs = {
         "readme_attention": (dict(attentions=[0, 0, 0, 0, 0, 1, 1, 1, 1], attention_heads=8, attention_features=64), False),
         "config4": (dict(cross_attentions=[0, 0, 0, 1, 1, 1, 1, 1, 1], embedding_features=768, attention_heads=8,
