@@ -223,7 +223,8 @@ def up_sample_input(up, low):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", ["ADP_CONV_WINO", "ADP_CONV_BS"])
 def test_opt_in_conv_families_inside_the_unet(hip, env, monkeypatch):
-    """The opt-in kernel families for the wide convs (Winograd F(2,3); three-way bf16 split) inside a whole U-Net step:
+    """The alternative kernel families for the wide convs (Winograd F(2,3): default on big grids, forced on here for a
+    small one; three-way bf16 split: opt-in) inside a whole U-Net step:
     loss, prediction and every parameter gradient against the default kernels on the same weights and inputs.  Both
     are fp32-accurate, so the bound is 1e-4 (ten times tighter than the path's parity tolerance)."""
     cfg = dict(in_channels=2, channels=[8, 32, 256, 512], factors=[1, 4, 4, 2], items=[1, 1, 2, 2])
@@ -247,7 +248,7 @@ def test_opt_in_conv_families_inside_the_unet(hip, env, monkeypatch):
     loss0, v0, g0 = run()
     monkeypatch.setenv(env, "1")
     loss1, v1, g1 = run()
-    assert not torch.equal(v0, v1), "the opt-in family was meant to run (different rounding)"
+    assert not torch.equal(v0, v1), "the other family was meant to run (different rounding)"
     assert abs(loss1.item() - loss0.item()) <= 1e-5 * abs(loss0.item())
     assert rel_err(v1, v0) < 1e-4
     # (a conv bias that feeds a GroupNorm has a true gradient of zero -- both runs hold cancellation noise there -- so the
