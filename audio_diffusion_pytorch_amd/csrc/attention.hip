@@ -542,8 +542,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* q, const f
 // query split of the key-major pass: enough waves to cover the chip when there are few key tiles
 int64_t kv_nsplit(int64_t B, int64_t H, int64_t n, int64_t m) {
   const int64_t ktiles = (m + 31) / 32, qtiles = (n + 31) / 32;
-  int64_t ns = 1024 / (B * H * ktiles);          // target ~1024 waves (4 per CU) ...
-  if (ns > qtiles / 4) ns = qtiles / 4;          // ... of at least four query tiles each,
+  int64_t ns = 1024 / (B * H * ktiles);          // target ~1024 waves (4 per CU),
+  if (ns > qtiles) ns = qtiles;                  // down to one query tile per wave (a wave is serial: 8 us per tile; the
+                                                 // old floor of four tiles left n = 256 cross attention on 32 waves)
   if (ns > 32) ns = 32;                          // and a bounded number of partial copies to sum
   if (ns < 1) ns = 1;
   return ns;
