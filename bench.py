@@ -106,11 +106,14 @@ def roofline_leg(model, x, top: int = 14):
     for call, kern, meta, ms in recs:
         a = agg.setdefault(kern, {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0})
         a["launches"] += 1
-        a["ms"] += ms / NREP
-        a["flops"] += meta.get("flops", 0) / NREP
-        a["bytes"] += meta.get("bytes", 0) / NREP
-    for a in agg.values():
+        a["ms"] += ms
+        a["flops"] += meta.get("flops", 0)
+        a["bytes"] += meta.get("bytes", 0)
+    for a in agg.values():  # per step (integer work counts stay integers)
         a["launches"] = max(1, round(a["launches"] / NREP))
+        a["ms"] /= NREP
+        a["flops"] //= NREP
+        a["bytes"] //= NREP
     pmc = {}
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -164,7 +167,7 @@ def roofline_leg(model, x, top: int = 14):
                 names.append(kern)
     hbm = None
     if hb["launches"]:
-        hb = {"launches": max(1, hb["launches"] // NREP), "ms": hb["ms"] / NREP, "flops": 0, "bytes": hb["bytes"] / NREP}
+        hb = {"launches": max(1, hb["launches"] // NREP), "ms": hb["ms"] / NREP, "flops": 0, "bytes": hb["bytes"] // NREP}
         hbm = entry(" | ".join(sorted(names)), hb)
         hbm["traffic"] = None
         hbm["what"] = "forward ConvBlock convs (GroupNorm+SiLU prologue, k=3) of depths 0-1: A_in + A_out (+A_res) bytes"
