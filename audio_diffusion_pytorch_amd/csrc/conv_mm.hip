@@ -139,6 +139,29 @@ int64_t adp_conv_mm_ksplit(const adp_conv_desc& d) {
   return ks;
 }
 
+// Winograd F(2,3) variant of conv_mm (WN, conv_mm_impl.h): kernel-3 'same' convs whose K loop is long enough to be
+// matrix bound.  ADP_CONV_WINO (read per call): unset / "1" / "R" = this variant for every eligible conv with at least
+// ADP_WINO_MIN_R (default 256) input channels; "0" = direct form everywhere; "L" = the first-generation kernel that
+// transforms in the loader waves (conv_wino.hip, kept for A/B).
+int adp_conv_wino_env() {
+  const char* e = getenv("ADP_CONV_WINO");
+  if (e == nullptr || e[0] == '1' || e[0] == 'R') return 'R';
+  return e[0] == 'L' ? 'L' : '0';
+}
+
+bool adp_conv_mm_winograd(const adp_conv_desc& d) {
+  if (adp_conv_wino_env() != 'R') return false;
+  if (d.KT != 3 || d.stride != 1 || d.up != 1 || d.dil != 1 || d.pad != 1 || d.store != 0 || d.R1 != d.R) return false;
+  if (d.N != d.Lin || d.Lin % 4 != 0) return false;
+  const char* mr = getenv("ADP_WINO_MIN_R");
+  const int64_t min_r = mr ? atoll(mr) : 256;
+  if (d.R < min_r) return false;
+  if ((reinterpret_cast<uintptr_t>(d.out) | reinterpret_cast<uintptr_t>(d.res) | reinterpret_cast<uintptr_t>(d.out_pre) |
+       reinterpret_cast<uintptr_t>(d.ws)) & 7)
+    return false;  // 8-byte accesses to the output pair
+  return true;
+}
+
 bool adp_conv_mm_eligible(const adp_conv_desc& d) {
   if (d.R1 != d.R) return false;
   const bool plain = d.stride == 1 && (d.KT == 1 || d.KT == 3) && d.up == 1;                    // ConvBlock family
@@ -159,7 +182,7 @@ bool adp_conv_mm_eligible(const adp_conv_desc& d) {
 // NKG * 1e6 + BM * 1e3 + BN of the tile the dispatcher picks
 int64_t adp_conv_mm_tile(const adp_conv_desc& d) {
   const int64_t nkg = d.stride == 4 ? 2 : 4;
-  return nkg * 1000000 + (mm_use64(d) ? 64064 : 32064);
+  return (adp_conv_mm_winograd(d) ? 40000000 : 0) + nkg * 1000000 + (mm_use64(d) ? 64064 : 32064);
 }
 
 int adp_conv_splitk_reduce(const adp_conv_desc& d, int64_t ks, void* stream) {

@@ -81,9 +81,22 @@ struct cmax {
 // BM: output channels per block (32 / 64); S: conv stride (1, or kernel = stride = 2 / 4 for DownsampleItem);
 // UP: nearest-upsample factor folded into the X loader (UpsampleItem: the [B, C, L*UP] intermediate is never
 // materialised); BKT: channels per staged chunk; PD: loader prefetch distance in chunks (register stages).
-template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD>
+//
+// WN = true (kernel 3, stride 1, pad 1, dil 1, store 0 only): the same block, loaders and LDS tiles, but the MMA waves
+// multiply in the Winograd F(2,3) domain.  Column l31 of a wave's tile is an output PAIR (positions n0 + 2*l31, +1);
+// per input channel the lane reads the three taps g and the four inputs d = x[2j-1 .. 2j+2] around its pair, forms
+//     U = (g0, g0+g1+g2, g0-g1+g2, g2)        V = (d0-d2, d1+d2, d2-d1, d1-d3)
+// in registers (7 VALU adds, issued in the shadow of the 64-cycle MFMAs) and issues FOUR MFMAs -- one per Winograd
+// plane, four accumulator tiles -- where the direct form issues six.  After the K loop
+//     y0 = P0 + (P1 + P2) / 2      y1 = (P1 - P2) / 2 - P3
+// turns the planes into the two output tiles (the halves of G are applied here, once, instead of per weight).
+// Two thirds of the matrix work of the direct form in plain fp32 arithmetic; the loaders stay pure copies, so the
+// overlap of staging and MFMAs that conv_mm measures is kept (the first Winograd kernel of this repository
+// transformed in the loader waves and lost its MFMA saving to exactly that: DESIGN.md section 4).
+template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD, bool WN = false>
 __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 64) void conv_mm_kernel(adp_conv_desc d,
                                                                                                     int KS) {
+  static_assert(!WN || (KT == 3 && S == 1 && UP == 1), "Winograd F(2,3): kernel 3, stride 1");
   constexpr int MM_NLD = mm_nld(PRO, BM, PD);
   constexpr int BN = MM_BN, NKG = mm_nkg(BKT), NQM = BM / 32;
   constexpr int CPK = BKT / NKG;                    // channels of a chunk one K group multiplies (8 or 16)
@@ -217,14 +230,16 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
   // =========================== MMA waves ===========================
   const int mq = wave % NQM, kg = wave / NQM;
   const int wm0 = mq * 32;
-  f32x16 acc[2];
+  constexpr int NACC = WN ? 4 : 2;
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
+  for (int ni = 0; ni < NACC; ++ni)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ni][r] = 0.0f;
 
   // lane-constant fragment offsets
-  const int xfrag = 4 * hi * XSP + l31 * S + 4 - pad;                 // + ni*32*S + (ci + c) * XSP + t * dil
+  const int xfrag = WN ? 4 * hi * XSP + 2 * l31 + 2                   // 8-byte pieces at +0, +2, +4: x[2j-2 .. 2j+3]
+                       : 4 * hi * XSP + l31 * S + 4 - pad;            // + ni*32*S + (ci + c) * XSP + t * dil
   const int afrag = TR ? 4 * hi * AS + (wm0 + l31) * KT                // + (ci + c) * AS + (KT - 1 - t)
                        : (wm0 + l31) * AS + 4 * hi * KT;               // + ci * KT + (c * KT + t)
   if (PRO == 1) __syncthreads();
@@ -236,7 +251,37 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
 #pragma unroll
       for (int sub = 0; sub < CPK / 8; ++sub) {
         const int ci = kg * CPK + sub * 8;
-        if (!TR) {
+        if constexpr (WN) {
+          float av[4 * KT];  // av[cc * 3 + t] = tap t of channel ci + cc + 4 * hi for this lane's output row
+          if (!TR) {
+            const float* ap = Ab + afrag + ci * KT;
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+              const f32x4 q = *reinterpret_cast<const f32x4*>(ap + 4 * j);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) av[4 * j + k] = q[k];
+            }
+          } else {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+              for (int t = 0; t < KT; ++t) av[cc * KT + t] = Ab[afrag + (ci + cc) * AS + (KT - 1 - t)];
+          }
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const float* xp = Xb + xfrag + (ci + cc) * XSP;
+            const f32x2 p0 = *reinterpret_cast<const f32x2*>(xp);
+            const f32x2 p1 = *reinterpret_cast<const f32x2*>(xp + 2);
+            const f32x2 p2 = *reinterpret_cast<const f32x2*>(xp + 4);
+            const float d0 = p0[1], d1 = p1[0], d2 = p1[1], d3 = p2[0];
+            const float g0 = av[cc * KT], g1 = av[cc * KT + 1], g2 = av[cc * KT + 2];
+            const float gs = g0 + g2;
+            acc[0] = adp_mfma32(g0, d0 - d2, acc[0]);
+            acc[1] = adp_mfma32(gs + g1, d1 + d2, acc[1]);
+            acc[2] = adp_mfma32(gs - g1, d2 - d1, acc[2]);
+            acc[3] = adp_mfma32(g2, d1 - d3, acc[3]);
+          }
+        } else if (!TR) {
           float av[4 * KT];
           const float* ap = Ab + afrag + ci * KT;
 #pragma unroll
@@ -270,6 +315,14 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
     }
   }
   __syncthreads();  // the staging buffers are free
+  if constexpr (WN) {  // output transform A^T (linear: applied to this K group's partial planes before the exchange)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p0 = acc[0][r], p1 = acc[1][r], p2 = acc[2][r], p3 = acc[3][r];
+      acc[0][r] = fmaf(0.5f, p1 + p2, p0);
+      acc[1][r] = fmaf(0.5f, p1 - p2, -p3);
+    }
+  }
 
   // ---- K-group exchange through LDS: every MMA wave parks both tiles, then sums + stores accumulator rows
   // [16/NKG * kg, 16/NKG * (kg+1)) of its (mq) tile over the NKG groups in the fixed order 0..NKG-1.
@@ -288,6 +341,56 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
   const int sp = (int)d.sp;
   const int64_t ebs = d.e_bstride ? d.e_bstride : M;
   float vfin[2][RPW];  // final output values of this lane (GroupNorm partial statistics below)
+  if constexpr (WN) {
+    // tiles 0 / 1 hold the even / odd position of the lane's output pair: 8-byte accesses, 256 contiguous bytes per
+    // output row and half-wave
+    const int n = n0 + 2 * l31;
+    const bool nok = n < N;  // N is even: a pair is inside or outside
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int r = kg * RPW + rr;
+      float v0, v1;
+      if (NKG > 1) {
+        v0 = v1 = 0.0f;
+#pragma unroll
+        for (int g = 0; g < NKG; ++g) {
+          v0 += smem[((g * NQM + mq) * 2 + 0) * 1024 + r * 64 + lane];
+          v1 += smem[((g * NQM + mq) * 2 + 1) * 1024 + r * 64 + lane];
+        }
+      } else {
+        v0 = acc[0][rr];
+        v1 = acc[1][rr];
+      }
+      const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const bool ok = (m < M) && nok;
+      vfin[0][rr] = vfin[1][rr] = 0.0f;
+      if (!ok) continue;
+      if (KS > 1) {  // raw partial tile; the epilogue runs in the reduce kernel
+        *reinterpret_cast<f32x2*>(d.ws + (((int64_t)ks * d.B + b) * M + m) * N + n) = f32x2{v0, v1};
+        continue;
+      }
+      const int64_t o = ((int64_t)b * M + m) * N + n;
+      if (d.bias) {
+        const float bv = d.bias[m];
+        v0 += bv;
+        v1 += bv;
+      }
+      if (d.out_pre) *reinterpret_cast<f32x2*>(d.out_pre + o) = f32x2{v0, v1};
+      if (d.e_scale) {
+        const float sc = d.e_scale[b * ebs + m];
+        v0 *= sc;
+        v1 *= sc;
+      }
+      if (d.res) {
+        const f32x2 rv = *reinterpret_cast<const f32x2*>(d.res + o);
+        v0 += rv[0];
+        v1 += rv[1];
+      }
+      *reinterpret_cast<f32x2*>(d.out + o) = f32x2{v0, v1};
+      vfin[0][rr] = v0;
+      vfin[1][rr] = v1;
+    }
+  } else {
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int n = n0 + ni * 32 + l31;
@@ -339,12 +442,13 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
       }
     }
   }
+  }
   // ---- GroupNorm partial statistics of the tile just stored (store 0, no K split): one (mean, M2, count) entry per
   // ROW QUAD (the 4 consecutive output channels a lane holds in accumulator registers 4q .. 4q+3) over the tile's
   // <= 64 positions: 8 values per lane, then the 32 lanes of the half-wave; two passes in registers.
   if (d.gn_part != nullptr && KS == 1 && d.store == 0) {
     const int cntv = (N - n0) < BN ? (N - n0) : BN;
-    const bool ok0 = n0 + l31 < N, ok1 = n0 + 32 + l31 < N;
+    const bool ok0 = WN ? (n0 + 2 * l31 < N) : (n0 + l31 < N), ok1 = WN ? ok0 : (n0 + 32 + l31 < N);
     const float fcnt = 4.0f * (float)cntv;
 #pragma unroll
     for (int q = 0; q < RPW / 4; ++q) {
@@ -374,22 +478,22 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
   }
 }
 
-template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD>
+template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD, bool WN = false>
 int launch_mm(const adp_conv_desc& d, void* stream) {
   const int64_t blocks = (d.M / BM) * adp_cdiv(d.N, MM_BN) * d.B;
   const int KS = d.ws ? (int)adp_conv_mm_ksplit(d) : 1;
-  ADP_LAUNCH((conv_mm_kernel<BM, KT, S, UP, TR, PRO, BKT, PD>), dim3((unsigned)blocks, (unsigned)KS),
+  ADP_LAUNCH((conv_mm_kernel<BM, KT, S, UP, TR, PRO, BKT, PD, WN>), dim3((unsigned)blocks, (unsigned)KS),
              dim3(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 64), stream, d, KS);
   return ADP_LAUNCH_OK();
 }
 
 // short K (one or two chunks: the HBM-bound shallow layers) runs without ghost iterations
-template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT>
+template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, bool WN = false>
 int launch_pd(const adp_conv_desc& d, void* stream) {
   const int64_t KS = d.ws ? adp_conv_mm_ksplit(d) : 1;
   // (a 64-channel chunk already is two 32-channel register stages; a second one does not fit the register file)
-  if (BKT < 64 && d.R / BKT / KS >= 4) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 2>(d, stream);
-  return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1>(d, stream);
+  if (BKT < 64 && d.R / BKT / KS >= 4) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 2, WN>(d, stream);
+  return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1, WN>(d, stream);
 }
 
 // every (kernel, stride, upsample, direction, prologue) variant of one block tile
@@ -401,6 +505,13 @@ int run_tile(const adp_conv_desc& d, void* stream) {
   if (d.up == 2) return launch_pd<BM, 3, 1, 2, false, 0, 32>(d, stream);
   if (d.up == 4) return launch_pd<BM, 3, 1, 4, false, 0, 32>(d, stream);
   if (d.KT == 3) {
+    if (adp_conv_mm_winograd(d)) {  // Winograd F(2,3) in the MMA waves' registers (two thirds of the MFMAs)
+      if (d.prologue == 1)
+        return tr ? launch_pd<BM, 3, 1, 1, true, 1, 32, true>(d, stream)
+                  : launch_pd<BM, 3, 1, 1, false, 1, 32, true>(d, stream);
+      return tr ? launch_pd<BM, 3, 1, 1, true, 0, 32, true>(d, stream)
+                : launch_pd<BM, 3, 1, 1, false, 0, 32, true>(d, stream);
+    }
     if (d.prologue == 1)
       return tr ? launch_pd<BM, 3, 1, 1, true, 1, 32>(d, stream) : launch_pd<BM, 3, 1, 1, false, 1, 32>(d, stream);
     return tr ? launch_pd<BM, 3, 1, 1, true, 0, 32>(d, stream) : launch_pd<BM, 3, 1, 1, false, 0, 32>(d, stream);

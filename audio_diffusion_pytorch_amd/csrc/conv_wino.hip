@@ -251,16 +251,10 @@ __global__ __launch_bounds__((WN_NMMA + WN_NLD) * 64, 4) void conv_wino_kernel(a
 
 }  // namespace
 
-// ADP_CONV_WINO (read per call): unset = on for grids of >= 400 tiles (the batch >= 4 shapes of the wide layers: +0.8 %
-// on the step, interleaved A/B on three boxes), "1" = on for every eligible conv, "0" = off.  Small grids (batch 1:
-// K-split launches of 8-16 chunks) lose 1 % and stay on conv_mm.  Isolated launches are 8-15 % faster than conv_mm;
-// inside the step most of that is lost because the loaders' transform arithmetic and LDS traffic share the SIMDs with
-// the f32 MFMAs.
-int adp_conv_wino_mode() {
-  const char* e = getenv("ADP_CONV_WINO");
-  return e == nullptr ? 2 : (e[0] == '1' ? 1 : 0);
-}
-bool adp_conv_wino_enabled() { return adp_conv_wino_mode() != 0; }
+// First-generation Winograd kernel (transforms in the loader waves): only on request, ADP_CONV_WINO=L, for A/B against
+// conv_mm's WN variant, which replaced it (conv_mm.hip: adp_conv_wino_env).
+int adp_conv_wino_env();
+bool adp_conv_wino_enabled() { return adp_conv_wino_env() == 'L'; }
 
 bool adp_conv_wino_eligible(const adp_conv_desc& d) {
   if (d.KT != 3 || d.stride != 1 || d.up != 1 || d.dil != 1 || d.pad != 1 || d.prologue != 0 || d.store != 0) return false;
@@ -270,7 +264,6 @@ bool adp_conv_wino_eligible(const adp_conv_desc& d) {
        reinterpret_cast<uintptr_t>(d.res) | reinterpret_cast<uintptr_t>(d.out_pre) | reinterpret_cast<uintptr_t>(d.ws)) & 15)
     return false;
   if (d.B * d.R * d.Lin >= (int64_t)1 << 31 || d.M * d.R * 3 >= (int64_t)1 << 31) return false;
-  if (adp_conv_wino_mode() == 2 && (d.M / WN_BM) * adp_cdiv(d.N, WN_BN) * d.B < 400) return false;  // default: big grids
   return true;
 }
 

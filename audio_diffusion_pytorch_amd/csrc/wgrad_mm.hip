@@ -16,9 +16,12 @@
 //   The GroupNorm+SiLU of the conv input is recomputed on the way into LDS (per-slot gamma/beta in registers,
 //   the (mean, rstd) pair of the chunk's batch element fetched with the prefetch).
 //   dbias is summed by the dy loader threads on the VALU (each staging slot owns one row), not on the MFMA.
+#include <stdlib.h>
 #include "adp_rt.h"
 #include "adp.h"
 #include "conv_internal.h"
+
+int adp_conv_wino_env();  // conv_mm.hip
 
 namespace {
 
@@ -54,9 +57,18 @@ constexpr int WG_NLD = 4;  // loader waves per block
 // GroupNorm+SiLU -> LDS) one chunk ahead of the MMA waves, which only read fragments and issue MFMAs; one
 // workgroup barrier per chunk hands the double-buffered LDS tiles over.  MMA wave = one 32x32 (m, r) quad x KT taps
 // (KT accumulator tiles sharing the dy fragment); NKG wave groups split every chunk's 64 positions.
-template <int BM, int KT, int S, int UP, int PRO, int PD>
+//
+// WN = true (kernel 3, stride 1, pad 1): the same tiles and loaders, the contraction in the Winograd F(2,3) domain --
+// the weight gradient of F(2,3) is, per output PAIR n = (p, p+1) with e = dy[p .. p+1] and d = x[p-1 .. p+2],
+//     dw[0..2] += G^T [ (A e) * (B^T d) ]      A e = (e0, e0+e1, e0-e1, -e1)      B^T d = (d0-d2, d1+d2, d2-d1, d1-d3)
+// i.e. FOUR rank-1 updates (one per Winograd plane: four accumulator tiles) where the direct form spends six.  Both
+// transforms are a handful of VALU adds on the fragments the lane has read anyway, issued in the shadow of the
+// 64-cycle MFMAs; G^T (with its halves) is applied once to the accumulators at the end:
+//     dw0 = P0 + (P1+P2)/2     dw1 = (P1-P2)/2     dw2 = (P1+P2)/2 + P3      (P3 is accumulated with +e1, so: - P3)
+template <int BM, int KT, int S, int UP, int PRO, int PD, bool WN = false>
 __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NLD) * 64) void wgrad_mm_kernel(
     adp_wgrad_desc d, int CPB, int CPS, int nsplit) {
+  static_assert(!WN || (KT == 3 && S == 1 && UP == 1), "Winograd F(2,3): kernel 3, stride 1");
   constexpr int BR = BM, BKN = WG_BKN, NKG = (BM == 64 ? 2 : 4), PPW = BKN / NKG;
   constexpr int NQR = BR / 32, NQ = (BM / 32) * NQR, NMMA = NQ * NKG, NLT = WG_NLD * 64;
   constexpr int PAD = (KT - 1) / 2;
@@ -216,9 +228,10 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
   // =========================== MMA waves ===========================
   const int quad = wave % NQ, kg = wave / NQ;
   const int wm0 = (quad / NQR) * 32, wr0 = (quad % NQR) * 32;
-  f32x16 acc[KT];
+  constexpr int NACC = WN ? 4 : KT;
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int t = 0; t < KT; ++t)
+  for (int t = 0; t < NACC; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
@@ -246,10 +259,24 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
 #pragma unroll
             for (int j = 0; j < 4; ++j) xq[4 + j] = v[j];
           }
+          if constexpr (WN) {
+            // xq[i] = x[base - 4 + i]: pair 0 = positions (base, base+1) with d = xq[3..6], pair 1 = (base+2, base+3)
+            // with d = xq[5..8]; the MFMA K pair is (this half-wave's pair, the other half-wave's pair)
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+              const float e0 = dq[2 * pp], e1 = dq[2 * pp + 1];
+              const float d0 = xq[3 + 2 * pp], d1 = xq[4 + 2 * pp], d2 = xq[5 + 2 * pp], d3 = xq[6 + 2 * pp];
+              acc[0] = adp_mfma32(e0, d0 - d2, acc[0]);
+              acc[1] = adp_mfma32(e0 + e1, d1 + d2, acc[1]);
+              acc[2] = adp_mfma32(e0 - e1, d2 - d1, acc[2]);
+              acc[3] = adp_mfma32(e1, d1 - d3, acc[3]);
+            }
+          } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int t = 0; t < KT; ++t) acc[t] = adp_mfma32(dq[j], xq[j + 4 - PAD + t], acc[t]);
+          }
         } else {
           const float* xp = Xb + (wr0 + l31) * XS + base * S;
 #pragma unroll
@@ -267,6 +294,16 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
     }
   }
   __syncthreads();
+  if constexpr (WN) {  // G^T: planes -> taps (linear, so applied to this K group's partial sums)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p0 = acc[0][r], p1 = acc[1][r], p2 = acc[2][r], p3 = acc[3][r];
+      const float h = 0.5f * (p1 + p2);
+      acc[0][r] = p0 + h;
+      acc[1][r] = 0.5f * (p1 - p2);
+      acc[2][r] = h - p3;
+    }
+  }
 
   // ---- fixed-order sum of the K groups through LDS, one group per round
 #pragma unroll
@@ -415,11 +452,11 @@ int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, fl
 namespace {
 
 // PD: a 64x64 chunk is 2.6 us of MFMAs (one register stage), a 32x32 chunk 0.64 us (two)
-template <int BM, int KT, int S, int UP, int PRO, int PD = (BM == 64 ? 1 : 2)>
+template <int BM, int KT, int S, int UP, int PRO, bool WN = false, int PD = (BM == 64 ? 1 : 2)>
 int launch_wg(const adp_wgrad_desc& d, const WgPlan& p, void* stream) {
   dim3 grid((unsigned)p.nsplit, (unsigned)(d.M / BM), (unsigned)(d.R / BM));
   constexpr int NTH = ((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NLD) * 64;
-  ADP_LAUNCH((wgrad_mm_kernel<BM, KT, S, UP, PRO, PD>), grid, dim3(NTH), stream, d, (int)p.cpb, (int)p.cps,
+  ADP_LAUNCH((wgrad_mm_kernel<BM, KT, S, UP, PRO, PD, WN>), grid, dim3(NTH), stream, d, (int)p.cpb, (int)p.cps,
              (int)p.nsplit);
   if (p.nsplit > 1) {
     return adp_wgrad_reduce(d.ws, p.nsplit, d.M * d.R * KT, d.M, d.dw, d.dbias, (int)d.accumulate, stream);
@@ -427,13 +464,22 @@ int launch_wg(const adp_wgrad_desc& d, const WgPlan& p, void* stream) {
   return ADP_LAUNCH_OK();
 }
 
-template <int KT, int S, int UP, int PRO>
+template <int KT, int S, int UP, int PRO, bool WN = false>
 int pick_wg(const adp_wgrad_desc& d, void* stream) {
   const WgPlan p = wg_plan(d);
   if constexpr (S != 4) {
-    if (p.bm == 64) return launch_wg<64, KT, S, UP, PRO>(d, p, stream);
+    if (p.bm == 64) return launch_wg<64, KT, S, UP, PRO, WN>(d, p, stream);
   }
-  return launch_wg<32, KT, S, UP, PRO>(d, p, stream);
+  return launch_wg<32, KT, S, UP, PRO, WN>(d, p, stream);
+}
+
+// Winograd F(2,3) form of the kernel-3 weight gradients (WN): same switch as the forward / data-gradient convs
+// (ADP_CONV_WINO, conv_mm.hip), for layers with at least ADP_WINO_WGRAD_MIN_R (default 128) channels
+bool wg_winograd(const adp_wgrad_desc& d) {
+  if (adp_conv_wino_env() != 'R') return false;
+  const char* mr = getenv("ADP_WINO_WGRAD_MIN_R");
+  const int64_t min_r = mr ? atoll(mr) : 128;
+  return d.KT == 3 && d.stride == 1 && d.up == 1 && d.pad == 1 && d.R >= min_r;
 }
 
 }  // namespace
@@ -464,6 +510,8 @@ int adp_wgrad_mm(const adp_wgrad_desc& d, void* stream) {
   if (d.stride == 4) return pick_wg<4, 4, 1, 0>(d, stream);
   if (d.up == 2) return pick_wg<3, 1, 2, 0>(d, stream);
   if (d.up == 4) return pick_wg<3, 1, 4, 0>(d, stream);
+  if (d.KT == 3 && wg_winograd(d))
+    return d.prologue == 1 ? pick_wg<3, 1, 1, 1, true>(d, stream) : pick_wg<3, 1, 1, 0, true>(d, stream);
   if (d.KT == 3) return d.prologue == 1 ? pick_wg<3, 1, 1, 1>(d, stream) : pick_wg<3, 1, 1, 0>(d, stream);
   return d.prologue == 1 ? pick_wg<1, 1, 1, 1>(d, stream) : pick_wg<1, 1, 1, 0>(d, stream);
 }

@@ -376,6 +376,14 @@ class _Run:
         return self.ss_all.view(-1)[off:], (self.dss_all.view(-1)[off:] if self.need_grad else None)
 
     # -- GroupNorm statistics: from the producer's epilogue partials when the producing kernel wrote them --------
+    def gn_part_for(self, C: int) -> Optional[ops.GnPart]:
+        """A GnPart for the kernel about to produce a C-channel tensor that a GroupNorm reads next -- or None when the
+        statistics have to come from a pass over the tensor: the producers write one partial per 4-channel row quad,
+        which only nests into the groups when a group holds a multiple of 4 channels."""
+        if GN_EPILOGUE and (C // self.net.groups) % 4 == 0:
+            return ops.GnPart()
+        return None
+
     def gn_stats_of(self, x: Tensor) -> Tensor:
         """stats [B, G, 2] of x: one tiny launch over the partials its producer left (conv / Modulation epilogue),
         else the two-launch statistics pass over the tensor."""
@@ -398,10 +406,10 @@ class _Run:
     # -- items ----------------------------------------------------------------------------
     def resnet(self, p, x: Tensor) -> Tensor:
         G = self.net.groups
-        if x.shape[1] >= ACT_MATERIALIZE_MIN_C:
+        if x.shape[1] >= ACT_MATERIALIZE_MIN_C and x.shape[0] * x.shape[1] <= 65535:  # (grid limit of gn_apply)
             return self.resnet_wide(p, x)
         st1 = self.gn_stats_of(x)
-        self.gn = ops.GnPart() if GN_EPILOGUE else None
+        self.gn = self.gn_part_for(x.shape[1])
         h1 = ops.conv1d(x, p.conv1.weight, p.conv1.bias, pad=1, prologue=1, pro_stats=st1, pro_gamma=p.gn1.weight,
                         pro_beta=p.gn1.bias, groups=G, gn=self.gn)
         st2 = self.gn_stats_of(h1)
@@ -430,7 +438,7 @@ class _Run:
         workgroups that stage a tile of it (the tensors are 2-8 MB here; see gn_apply_kernel in csrc/norm.hip)."""
         G = self.net.groups
         st1, a1 = self.gn_stats_act_of(x, p.gn1)
-        self.gn = ops.GnPart() if GN_EPILOGUE else None
+        self.gn = self.gn_part_for(x.shape[1])
         h1 = ops.conv1d(a1, p.conv1.weight, p.conv1.bias, pad=1, gn=self.gn)
         st2, a2 = self.gn_stats_act_of(h1, p.gn2)
         self.gn = None
@@ -515,7 +523,7 @@ class _Run:
             assert x2 is None
             skip = x
         wd = blk.down.weight
-        self.gn = ops.GnPart() if GN_EPILOGUE else None  # the first item of every depth is a ResnetItem (GroupNorm of h0)
+        self.gn = self.gn_part_for(n.channels[d])  # the first item of every depth is a ResnetItem (GroupNorm of h0)
         if native:
             xs = x2s = None
             h0 = ops.conv1d(x, wd, blk.down.bias, stride=f, x2=x2, gn=self.gn)
@@ -533,7 +541,7 @@ class _Run:
             sc, dsc = self.ss((d, "skip"))
             u = torch.empty((x.shape[0], blk.out_ch, h.shape[2] * f), dtype=torch.float32, device=x.device) \
                 if self.need_grad else None
-            self.gn = ops.GnPart() if (d > 0 and GN_EPILOGUE) else None  # the outer depth's first up ResnetItem reads y
+            self.gn = self.gn_part_for(blk.out_ch) if d > 0 else None  # the outer depth's first up ResnetItem reads y
             y = ops.conv1d(h, blk.up.weight, blk.up.bias, pad=1, up=f, e_scale=sc, e_bstride=NT, res=skip, out_pre=u,
                            gn=self.gn)
         else:

@@ -105,13 +105,18 @@ def test_conv1d_bf16_split_is_fp32_accurate(dev, B, R, M, L, tr, monkeypatch):
     assert e_bs < 4 * e_32 + 2e-7, (e_bs, e_32)
 
 
+@pytest.mark.parametrize("mode", ["R", "L"])
 @pytest.mark.parametrize("B,R,M,L,tr", [(2, 256, 64, 200, False), (1, 512, 64, 64, False), (2, 256, 96, 132, True),
-                                        (1, 1024, 32, 64, True), (3, 288, 32, 4, False), (1, 256, 32, 260, True)])
-def test_conv1d_winograd_family(dev, B, R, M, L, tr, monkeypatch):
-    """conv_wino: Winograd F(2,3) form of the wide kernel-3 convs (>= 256 input channels, materialised input) on the
-    exact-f32 matrix cores -- forward and transposed-weight view, ragged last tile, a length shorter than one tile,
-    the cross-workgroup K split, the full epilogue and the GroupNorm partial statistics.  fp32 throughout: the bound
-    against an fp64 reference is 1e-5, next to the direct-form kernel (ADP_CONV_WINO=0) on the same inputs."""
+                                        (1, 1024, 32, 64, True), (3, 288, 32, 4, False), (1, 256, 32, 260, True),
+                                        (4, 256, 128, 512, False)])
+def test_conv1d_winograd_family(dev, B, R, M, L, tr, mode, monkeypatch):
+    """Winograd F(2,3) form of the wide kernel-3 convs on the exact-f32 matrix cores -- mode R: conv_mm's WN variant
+    (transforms in the MMA waves' registers, the default), mode L: the first-generation conv_wino kernel (transforms in
+    the loader waves, kept for A/B).  Forward and transposed-weight view, ragged last tile, a length shorter than one
+    tile, the cross-workgroup K split, 32- and 64-row blocks, the full epilogue and the GroupNorm partial statistics.
+    fp32 throughout: the bound against an fp64 reference is 1e-5, next to the direct form (ADP_CONV_WINO=0)."""
+    if dev.type != "cuda" and B * M * L > 100000 and mode == "L":
+        pytest.skip("big emulated case: covered for the default variant")
     x = rnd(B, R, L, seed=1)
     w = rnd(R, M, 3, seed=2, scale=0.05) if tr else rnd(M, R, 3, seed=2, scale=0.05)
     b, res, sc = rnd(M, seed=3), rnd(B, M, L, seed=4), rnd(B * M, seed=5)
@@ -126,8 +131,9 @@ def test_conv1d_winograd_family(dev, B, R, M, L, tr, monkeypatch):
     from audio_diffusion_pytorch_amd import _C
     d = _C.ConvDesc(_C.ptr(args[0]), None, _C.ptr(args[1]), None, None, None, None, None, None, _C.ptr(args[0]), None, B, R, R,
                     L, M, L, 3, 1, 1, 1, 1, int(tr), 0, 1, 0, 1, 0)
-    monkeypatch.setenv("ADP_CONV_WINO", "1")
-    assert _C.query("adp_conv1d_tile", byref(d)) == 4032064, "this shape is meant to take the Winograd kernel"
+    monkeypatch.setenv("ADP_CONV_WINO", mode)
+    tile = _C.query("adp_conv1d_tile", byref(d))
+    assert (tile // 10000000 == 4) if mode == "R" else (tile == 4032064), "this shape is meant to take the Winograd kernel"
     pre = torch.empty(B, M, L).to(dev)
     gn = ops.GnPart()
     out = ops.conv1d(*args, out_pre=pre, gn=gn, **kw)
@@ -142,6 +148,25 @@ def test_conv1d_winograd_family(dev, B, R, M, L, tr, monkeypatch):
         assert gn.part[..., 2].sum(dim=2).eq(4 * L).all()
         assert rel_err(st[..., 1], ref_st[..., 1]) < 1e-5
         assert (st[..., 0] - ref_st[..., 0]).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("C,L,tr", [(64, 200, False), (96, 132, True), (128, 64, False)])
+def test_conv1d_winograd_with_groupnorm_prologue(dev, C, L, tr, monkeypatch):
+    """The Winograd variant under the GroupNorm+SiLU loader prologue (the mid-depth ConvBlocks), channel counts below
+    the default threshold switched in with ADP_WINO_MIN_R."""
+    monkeypatch.setenv("ADP_CONV_WINO", "R")
+    monkeypatch.setenv("ADP_WINO_MIN_R", "32")
+    B, G = 2, 8
+    x = rnd(B, C, L, seed=1) * 1.7 + 0.3
+    w = rnd(C, C, 3, seed=2, scale=0.2)
+    b, gamma, beta, res = rnd(C, seed=3), rnd(C, seed=4) * 0.5 + 1, rnd(C, seed=5) * 0.1, rnd(B, C, L, seed=6)
+    a = ref_gn_silu(x, G, gamma, beta)
+    ref = (F.conv_transpose1d(a, w, None, padding=1) + b[None, :, None] if tr else F.conv1d(a, w, b, padding=1)) + res
+    xd = x.to(dev)
+    stats = ops.gn_stats(xd, G)
+    out = ops.conv1d(xd, w.to(dev), b.to(dev), pad=1, transposed=tr, prologue=1, pro_stats=stats,
+                     pro_gamma=gamma.to(dev), pro_beta=beta.to(dev), groups=G, res=res.to(dev))
+    assert rel_err(out, ref) < TOL
 
 
 def test_conv1d_big_tile(dev):
@@ -445,10 +470,17 @@ WGMM_CASES = [
 ]
 
 
+@pytest.mark.parametrize("wino", ["0", "R"])
 @pytest.mark.parametrize("B,R,M,L,KT", WGMM_CASES)
-def test_wgrad_mm_family(dev, B, R, M, L, KT):
+def test_wgrad_mm_family(dev, B, R, M, L, KT, wino, monkeypatch):
+    """wino = R: the kernel-3 cases on the Winograd F(2,3) weight-gradient variant (WN; four rank-1 updates per
+    output pair instead of six), switched in for every channel count."""
     if dev.type != "cuda" and R * M > 65536:
         pytest.skip("emulating 256 16-wave workgroups takes minutes; covered on the GPU")
+    if wino == "R" and KT != 3:
+        pytest.skip("Winograd F(2,3) is the kernel-3 form")
+    monkeypatch.setenv("ADP_CONV_WINO", wino)
+    monkeypatch.setenv("ADP_WINO_WGRAD_MIN_R", "32")
     G = 8
     pad = (KT - 1) // 2
     x = rnd(B, R, L, seed=1) * 1.3 + 0.2

@@ -46,6 +46,27 @@ def test_unet_any_integer_factor(dev, factors, L):
     assert rel_err(xd.grad, x.grad) < TOL
 
 
+@pytest.mark.parametrize("groups", [16, 32, 4])
+def test_unet_resnet_groups_other_than_8(dev, groups):
+    """resnet_groups (components.py:46, :104) only has to divide the channel counts.  With 32- and 64-channel layers
+    on the MFMA / streaming conv kernels, 16 and 32 groups give 2 / 1 / 4 channels per group: the producers' GroupNorm
+    partial statistics (one entry per 4-channel row quad) do not nest into such groups and the statistics must come
+    from the pass over the tensor instead (round-2 regression: adp_gn_finalize returned ADP_ERR_SHAPE)."""
+    cfg = dict(in_channels=2, channels=[32, 64], factors=[1, 2], items=[1, 1], modulation_features=32,
+               resnet_groups=groups)
+    oracle, net = build_pair(cfg, dev)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 2, 256, generator=g)
+    t = torch.tensor([0.3, 0.8])
+    y_ref = oracle(x, t)
+    y = net(x.to(dev), t.to(dev))
+    assert rel_err(y, y_ref) < TOL
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    y.backward(gy.to(dev))
+    compare_grads(net, oracle)
+
+
 def test_unet_skipcat_without_modulation(dev):
     """UNetV0(use_modulation=False, use_time_conditioning=False): no ModulationItems, SkipCat merges
     (Conv1x1(cat[skip * 2^-1/2, x])), forward takes x only."""
