@@ -118,12 +118,28 @@ class TextConditioningNet(nn.Module):
         self.net = net
         self.embedder = embedder if exists(embedder) else T5Embedder()
 
-    def forward(self, x: Tensor, *args, text=None, embedding: Optional[Tensor] = None, **kwargs) -> Tensor:
+    def _embed(self, x: Tensor, text, embedding: Optional[Tensor]) -> Tensor:
         assert exists(text), "TextConditioningPlugin requires `text` in forward"
         text_embedding = self.embedder(text).to(device=x.device, dtype=torch.float32)
         if exists(embedding):
             text_embedding = torch.cat([text_embedding, embedding], dim=1)  # token axis; memory movement only
-        return self.net(x, *args, embedding=text_embedding, **kwargs)
+        return text_embedding
+
+    def forward(self, x: Tensor, *args, text=None, embedding: Optional[Tensor] = None,
+                resolved_text_embedding: Optional[Tensor] = None, **kwargs) -> Tensor:
+        if resolved_text_embedding is not None:  # a sampling loop embedded the text once (prepare_sampling_kwargs)
+            return self.net(x, *args, embedding=resolved_text_embedding, **kwargs)
+        return self.net(x, *args, embedding=self._embed(x, text, embedding), **kwargs)
+
+    def prepare_sampling_kwargs(self, x: Tensor, kwargs: dict) -> dict:
+        """Called once by VSampler / VInpainter before their step loop: the text is embedded ONCE per sampling run
+        (the reference's plugin re-encodes it on each of the N steps) and reaches the steps as a plain device tensor,
+        so the step has no host-side tokenizer / H2D copy in it and can be captured in a hipGraph."""
+        if not exists(kwargs.get("text")):
+            return kwargs
+        rest = {k: v for k, v in kwargs.items() if k not in ("text", "embedding")}
+        rest["resolved_text_embedding"] = self._embed(x, kwargs["text"], kwargs.get("embedding")).contiguous()
+        return rest
 
 
 def UNetV0(
@@ -209,6 +225,10 @@ class _AppendChannelsNet(nn.Module):
         super().__init__()
         self.net = net
         self.two_pointer = _accepts_x_append(net)
+
+    def prepare_sampling_kwargs(self, x: Tensor, kwargs: dict) -> dict:
+        inner = getattr(self.net, "prepare_sampling_kwargs", None)
+        return inner(x, kwargs) if inner is not None else kwargs
 
     def forward(self, x: Tensor, *args, append_channels: Tensor, **kwargs) -> Tensor:
         if self.two_pointer:

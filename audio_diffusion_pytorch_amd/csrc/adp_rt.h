@@ -27,13 +27,6 @@ __device__ __forceinline__ f32x4 adp_mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// bf16 matrix core op with fp32 accumulation (v_mfma_f32_32x32x16_bf16): lane l holds A[row = l & 31][k = 8 * (l >> 5)
-// + j] and B[k = 8 * (l >> 5) + j][col = l & 31], j = 0..7; C/D layout as adp_mfma32.  Used by conv_bs.hip.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x16 adp_mfma32_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
 // compiler scheduling fence: nothing moves across (keeps prefetch loads ahead of the matrix work that hides them)
 __device__ __forceinline__ void adp_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 

@@ -9,22 +9,10 @@ int adp_conv_mm(const adp_conv_desc& d, void* stream);
 int64_t adp_conv_mm_tile(const adp_conv_desc& d);  // NKG * 1000000 + BM * 1000 + BN
 int64_t adp_conv_mm_ksplit(const adp_conv_desc& d);  // cross-workgroup K split the dispatcher picks (1 = none)
 bool adp_conv_mm_winograd(const adp_conv_desc& d);   // this conv runs conv_mm's Winograd F(2,3) variant (WN)
+bool adp_winograd_enabled();                         // ADP_CONV_WINO switch (shared with the weight gradients)
 
 int adp_conv_splitk_reduce(const adp_conv_desc& d, int64_t ks, void* stream);  // sum of d.ws partial tiles + epilogue
 int64_t adp_conv_splitk_gn_entries(const adp_conv_desc& d);  // gn_part slices per row the reduce kernel writes
-
-// conv_bs.hip: the deep kernel-3 convs on the bf16 matrix cores at fp32 accuracy (three-way bf16 split, 6 products)
-bool adp_conv_bs_enabled();
-bool adp_conv_bs_eligible(const adp_conv_desc& d);
-int64_t adp_conv_bs_ksplit(const adp_conv_desc& d);
-int adp_conv_bs(const adp_conv_desc& d, void* stream);
-
-// conv_wino.hip: Winograd F(2,3) form of the wide kernel-3 convs (forward / data gradient, >= 256 channels, materialised
-// input) on the exact-f32 matrix cores: two thirds of the MFMA work of conv_mm
-bool adp_conv_wino_enabled();
-bool adp_conv_wino_eligible(const adp_conv_desc& d);
-int64_t adp_conv_wino_ksplit(const adp_conv_desc& d);
-int adp_conv_wino(const adp_conv_desc& d, void* stream);
 
 // wgrad_mm.hip: wave-specialised weight gradient of the same convolutions (channels % 32 == 0)
 bool adp_wgrad_mm_eligible(const adp_wgrad_desc& d);

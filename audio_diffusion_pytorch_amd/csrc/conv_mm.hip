@@ -136,25 +136,29 @@ int64_t adp_conv_mm_ksplit(const adp_conv_desc& d) {
   const int64_t nchunks = d.R / (d.stride == 4 ? 16 : MM_BKT);
   int64_t ks = 1;
   while (ks < 8 && blocks * ks < 200 && nchunks / (ks * 2) >= 4) ks *= 2;
+  // the kernel gives slice i the chunks [i * ceil(n / ks), ...): every slice must own at least one (n = 33, ks = 8 would
+  // leave the last two slices empty -- they would launch, restage a ghost chunk and park an all-zero partial tile)
+  while (ks > 1 && (ks - 1) * adp_cdiv(nchunks, ks) >= nchunks) ks /= 2;
   return ks;
 }
 
 // Winograd F(2,3) variant of conv_mm (WN, conv_mm_impl.h): kernel-3 'same' convs whose K loop is long enough to be
-// matrix bound.  ADP_CONV_WINO (read per call): unset / "1" / "R" = this variant for every eligible conv with at least
-// ADP_WINO_MIN_R (default 256) input channels; "0" = direct form everywhere; "L" = the first-generation kernel that
-// transforms in the loader waves (conv_wino.hip, kept for A/B).
-int adp_conv_wino_env() {
+// matrix bound (also the UpsampleItem convs -- the LDS tile holds virtual upsampled positions -- and the pooled-store
+// data gradients of those).  ADP_CONV_WINO (read per call): unset / "1" = this variant for every eligible conv with at
+// least ADP_WINO_MIN_R (default 64) input channels; "0" = direct form everywhere (A/B and the parity tests).
+bool adp_winograd_enabled() {
   const char* e = getenv("ADP_CONV_WINO");
-  if (e == nullptr || e[0] == '1' || e[0] == 'R') return 'R';
-  return e[0] == 'L' ? 'L' : '0';
+  return e == nullptr || e[0] != '0';
 }
 
 bool adp_conv_mm_winograd(const adp_conv_desc& d) {
-  if (adp_conv_wino_env() != 'R') return false;
-  if (d.KT != 3 || d.stride != 1 || d.up != 1 || d.dil != 1 || d.pad != 1 || d.store != 0 || d.R1 != d.R) return false;
-  if (d.N != d.Lin || d.Lin % 4 != 0) return false;
+  if (!adp_winograd_enabled()) return false;
+  if (d.KT != 3 || d.stride != 1 || d.dil != 1 || d.pad != 1 || d.R1 != d.R) return false;
+  if (d.up != 1 && d.up != 2 && d.up != 4) return false;
+  if (d.store != 0 && !(d.store == 2 && (d.sp == 2 || d.sp == 4))) return false;  // plain or pooled store
+  if (d.N != d.Lin * d.up || d.N % 4 != 0) return false;
   const char* mr = getenv("ADP_WINO_MIN_R");
-  const int64_t min_r = mr ? atoll(mr) : 256;
+  const int64_t min_r = mr ? atoll(mr) : 64;
   if (d.R < min_r) return false;
   if ((reinterpret_cast<uintptr_t>(d.out) | reinterpret_cast<uintptr_t>(d.res) | reinterpret_cast<uintptr_t>(d.out_pre) |
        reinterpret_cast<uintptr_t>(d.ws)) & 7)

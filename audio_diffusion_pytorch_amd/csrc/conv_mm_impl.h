@@ -82,7 +82,7 @@ struct cmax {
 // UP: nearest-upsample factor folded into the X loader (UpsampleItem: the [B, C, L*UP] intermediate is never
 // materialised); BKT: channels per staged chunk; PD: loader prefetch distance in chunks (register stages).
 //
-// WN = true (kernel 3, stride 1, pad 1, dil 1, store 0 only): the same block, loaders and LDS tiles, but the MMA waves
+// WN = true (kernel 3, stride 1, pad 1, dil 1; store modes 0 and 2): the same block, loaders and LDS tiles, but the MMA waves
 // multiply in the Winograd F(2,3) domain.  Column l31 of a wave's tile is an output PAIR (positions n0 + 2*l31, +1);
 // per input channel the lane reads the three taps g and the four inputs d = x[2j-1 .. 2j+2] around its pair, forms
 //     U = (g0, g0+g1+g2, g0-g1+g2, g2)        V = (d0-d2, d1+d2, d2-d1, d1-d3)
@@ -96,7 +96,8 @@ struct cmax {
 template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD, bool WN = false>
 __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 64) void conv_mm_kernel(adp_conv_desc d,
                                                                                                     int KS) {
-  static_assert(!WN || (KT == 3 && S == 1 && UP == 1), "Winograd F(2,3): kernel 3, stride 1");
+  static_assert(!WN || (KT == 3 && S == 1), "Winograd F(2,3): kernel 3, stride 1 (any upsample factor: the LDS tile "
+                                            "holds virtual positions)");
   constexpr int MM_NLD = mm_nld(PRO, BM, PD);
   constexpr int BN = MM_BN, NKG = mm_nkg(BKT), NQM = BM / 32;
   constexpr int CPK = BKT / NKG;                    // channels of a chunk one K group multiplies (8 or 16)
@@ -364,6 +365,16 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
       const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       const bool ok = (m < M) && nok;
       vfin[0][rr] = vfin[1][rr] = 0.0f;
+      if (d.store == 2) {  // pooled store (gradient of the nearest upsample): sum of sp adjacent positions, no bias
+        float v = ok ? v0 + v1 : 0.0f;
+        if (sp == 4) v += __shfl_xor(v, 1, 64);
+        if (ok && (sp == 2 || (l31 & 1) == 0)) {
+          const int64_t o = ((int64_t)b * M + m) * (N / sp) + n / sp;
+          if (d.res) v += d.res[o];
+          d.out[o] = v;
+        }
+        continue;
+      }
       if (!ok) continue;
       if (KS > 1) {  // raw partial tile; the epilogue runs in the reduce kernel
         *reinterpret_cast<f32x2*>(d.ws + (((int64_t)ks * d.B + b) * M + m) * N + n) = f32x2{v0, v1};
@@ -502,8 +513,12 @@ int run_tile(const adp_conv_desc& d, void* stream) {
   const bool tr = d.transposed != 0;
   if (d.stride == 2) return launch_pd<BM, 2, 2, 1, false, 0, 32>(d, stream);
   if (d.stride == 4) return launch_pd<BM, 4, 4, 1, false, 0, 16>(d, stream);
-  if (d.up == 2) return launch_pd<BM, 3, 1, 2, false, 0, 32>(d, stream);
-  if (d.up == 4) return launch_pd<BM, 3, 1, 4, false, 0, 32>(d, stream);
+  if (d.up == 2)
+    return adp_conv_mm_winograd(d) ? launch_pd<BM, 3, 1, 2, false, 0, 32, true>(d, stream)
+                                   : launch_pd<BM, 3, 1, 2, false, 0, 32>(d, stream);
+  if (d.up == 4)
+    return adp_conv_mm_winograd(d) ? launch_pd<BM, 3, 1, 4, false, 0, 32, true>(d, stream)
+                                   : launch_pd<BM, 3, 1, 4, false, 0, 32>(d, stream);
   if (d.KT == 3) {
     if (adp_conv_mm_winograd(d)) {  // Winograd F(2,3) in the MMA waves' registers (two thirds of the MFMAs)
       if (d.prologue == 1)

@@ -21,8 +21,6 @@
 #include "adp.h"
 #include "conv_internal.h"
 
-int adp_conv_wino_env();  // conv_mm.hip
-
 namespace {
 
 constexpr int WG_BKN = 64;  // positions per staged chunk
@@ -68,7 +66,7 @@ constexpr int WG_NLD = 4;  // loader waves per block
 template <int BM, int KT, int S, int UP, int PRO, int PD, bool WN = false>
 __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NLD) * 64) void wgrad_mm_kernel(
     adp_wgrad_desc d, int CPB, int CPS, int nsplit) {
-  static_assert(!WN || (KT == 3 && S == 1 && UP == 1), "Winograd F(2,3): kernel 3, stride 1");
+  static_assert(!WN || (KT == 3 && S == 1), "Winograd F(2,3): kernel 3, stride 1 (any upsample factor)");
   constexpr int BR = BM, BKN = WG_BKN, NKG = (BM == 64 ? 2 : 4), PPW = BKN / NKG;
   constexpr int NQR = BR / 32, NQ = (BM / 32) * NQR, NMMA = NQ * NKG, NLT = WG_NLD * 64;
   constexpr int PAD = (KT - 1) / 2;
@@ -474,12 +472,12 @@ int pick_wg(const adp_wgrad_desc& d, void* stream) {
 }
 
 // Winograd F(2,3) form of the kernel-3 weight gradients (WN): same switch as the forward / data-gradient convs
-// (ADP_CONV_WINO, conv_mm.hip), for layers with at least ADP_WINO_WGRAD_MIN_R (default 128) channels
+// (ADP_CONV_WINO, conv_mm.hip), for layers with at least ADP_WINO_WGRAD_MIN_R (default 64) channels
 bool wg_winograd(const adp_wgrad_desc& d) {
-  if (adp_conv_wino_env() != 'R') return false;
+  if (!adp_winograd_enabled()) return false;
   const char* mr = getenv("ADP_WINO_WGRAD_MIN_R");
-  const int64_t min_r = mr ? atoll(mr) : 128;
-  return d.KT == 3 && d.stride == 1 && d.up == 1 && d.pad == 1 && d.R >= min_r;
+  const int64_t min_r = mr ? atoll(mr) : 64;
+  return d.KT == 3 && d.stride == 1 && d.pad == 1 && d.R >= min_r;
 }
 
 }  // namespace
@@ -508,8 +506,8 @@ int64_t adp_wgrad_mm_ws_floats(const adp_wgrad_desc& d) {
 int adp_wgrad_mm(const adp_wgrad_desc& d, void* stream) {
   if (d.stride == 2) return pick_wg<2, 2, 1, 0>(d, stream);
   if (d.stride == 4) return pick_wg<4, 4, 1, 0>(d, stream);
-  if (d.up == 2) return pick_wg<3, 1, 2, 0>(d, stream);
-  if (d.up == 4) return pick_wg<3, 1, 4, 0>(d, stream);
+  if (d.up == 2) return wg_winograd(d) ? pick_wg<3, 1, 2, 0, true>(d, stream) : pick_wg<3, 1, 2, 0>(d, stream);
+  if (d.up == 4) return wg_winograd(d) ? pick_wg<3, 1, 4, 0, true>(d, stream) : pick_wg<3, 1, 4, 0>(d, stream);
   if (d.KT == 3 && wg_winograd(d))
     return d.prologue == 1 ? pick_wg<3, 1, 1, 1, true>(d, stream) : pick_wg<3, 1, 1, 0, true>(d, stream);
   if (d.KT == 3) return d.prologue == 1 ? pick_wg<3, 1, 1, 1>(d, stream) : pick_wg<3, 1, 1, 0>(d, stream);

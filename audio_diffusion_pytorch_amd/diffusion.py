@@ -150,8 +150,10 @@ def _kw_spec(value, tensors: List[Tensor]):
     if isinstance(value, Tensor):
         tensors.append(value)
         return ("T", tuple(value.shape), value.dtype, value.device)
-    if value is None or isinstance(value, (bool, int, float, str)):
+    if value is None or isinstance(value, (bool, int, float)):
         return ("S", type(value).__name__, value)
+    # (strings are NOT static: a net that takes text runs a host-side tokenizer + H2D copy per call, which is illegal
+    # inside stream capture; our own TextConditioningNet resolves text to a tensor before the loop instead)
     if isinstance(value, (list, tuple)):
         items = tuple(_kw_spec(v, tensors) for v in value)
         return None if any(i is None for i in items) else ("L", type(value).__name__, items)
@@ -197,6 +199,9 @@ class VSampler(Sampler):
             b = x_noisy.shape[0]
             sig, ab = self._tables(num_steps, b, x_noisy.device)
             x = x_noisy.contiguous().clone()
+            prepare = getattr(self.net, "prepare_sampling_kwargs", None)
+            if prepare is not None:  # e.g. text -> embedding tensor, once per sampling run
+                kwargs = prepare(x, kwargs)
             if self.use_graph and x.is_cuda and not show_progress:
                 out = self._forward_graph(x, sig, ab, num_steps, kwargs)
                 if out is not None:
@@ -294,6 +299,9 @@ class VInpainter(Inpainter):
 
     def _run(self, source, mask, num_steps, num_resamples, show_progress, x_noisy, kwargs) -> Tensor:
         x = (x_noisy if x_noisy is not None else torch.randn_like(source)).contiguous()
+        prepare = getattr(self.net, "prepare_sampling_kwargs", None)
+        if prepare is not None:
+            kwargs = prepare(x, kwargs)
         b = x.shape[0]
         sigmas = self.schedule(num_steps + 1, device=x.device).to(torch.float32)
         alphas, betas = self.get_alpha_beta(sigmas)

@@ -6,8 +6,8 @@ encoder / adapter interfaces) and :134-165 (DiffusionUpsampler): same constructo
 the sampler, everything else to `net_t`, ONE net shared by both.
 
 What is organised around the gfx950 kernels rather than around torch ops:
-  * the starting noise of `sample` / `decode` is drawn where it is consumed (on the HIP device) unless the caller
-    hands over a CPU generator, in which case the reference's host draw is reproduced bit for bit;
+  * the starting noise of `sample` / `decode` is drawn on the host like the reference's (utils.py:123-125), so seeded
+    scripts reproduce its samples; one 8 MB copy per sampling run;
   * `reupsample` is two launches of the polyphase resampler (adp_resample) on the caller's tensor -- the kernel
     never writes its input, so no defensive clone;
   * the appended / injected conditioning tensors are consumed through a second input pointer of the depth-0 /
@@ -41,11 +41,13 @@ def _split_prefixed(kwargs: Dict[str, Any], *prefixes: str):
 
 
 def _start_noise(shape: Sequence[int], like: Tensor, generator: Optional[Generator]) -> Tensor:
-    """N(0, 1) starting point of a sampling run, produced on `like`'s device.  A CPU generator keeps the reference's
-    behaviour (utils.py:123-125: host draw, then one H2D copy) so seeded runs reproduce across backends."""
-    if generator is not None and generator.device.type == "cpu" and like.device.type != "cpu":
-        return torch.randn(tuple(shape), generator=generator, dtype=like.dtype).to(like.device)
-    return torch.randn(tuple(shape), generator=generator, dtype=like.dtype, device=like.device)
+    """N(0, 1) starting point of a sampling run.  Drawn exactly where the reference draws it (utils.py:123-125,
+    models.py:127-129, :164): on the HOST -- from `generator`, or from torch's global CPU generator when none is given
+    -- then moved to `like`'s device in one copy, so that `torch.manual_seed(s); model.sample(...)` scripts produce the
+    reference's starting noise on any backend.  (A generator that lives on the device is honoured in place.)"""
+    if generator is not None and generator.device.type != "cpu":
+        return torch.randn(tuple(shape), generator=generator, dtype=like.dtype, device=generator.device).to(like.device)
+    return torch.randn(tuple(shape), generator=generator, dtype=like.dtype).to(like.device)
 
 
 class DiffusionModel(nn.Module):

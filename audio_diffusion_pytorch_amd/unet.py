@@ -40,6 +40,26 @@ TIME_EMBED_DIM = 256
 TIME_NUM_LAYERS = 2
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 
+# The recalled a_unet semantics this file and the kernels HARD-WIRE (a_unet itself is not available offline: SURVEY.md
+# section 8c, Appendix A).  oracle/a_unet_restatement.py carries the same choices as named [switch] constants;
+# tests/test_oracle.py::test_product_semantics_match_oracle_switches asserts the two tables agree, so flipping a switch
+# in the oracle (e.g. once tools/pin_a_unet.py can compare it with a real a_unet) fails loudly and names the product
+# site that has to change with it.
+A_UNET_SEMANTICS = {
+    "DOWNSAMPLE_WIDTH": 1,                 # _Run.block: Conv1d(kernel = stride = factor), blk.down
+    "UPSAMPLE_KERNEL_SIZE": 3,             # _Run.block: nearest upsample (conv loader, up=f) + Conv1d(k=3, pad=1), blk.up
+    "RESNET_KERNEL_SIZE": 3,               # _Run.resnet: conv1 / conv2
+    "MODULATION_ONE_PLUS_SCALE": True,     # csrc/norm.hip chan_ln_fwd_kernel (modulation mode): xn * (1 + scale) + shift
+    "TIME_EMBED_DIM": TIME_EMBED_DIM,      # UNetV0Net.__init__: NumberEmbedder(dim=256)
+    "TIME_NUM_LAYERS": TIME_NUM_LAYERS,    # UNetV0Net.__init__: time_mlp
+    "TIME_GELU_AFTER_EMBEDDER": True,      # _Run.conditioning: act_fwd(GELU) on time_linear's output before the MLP
+    "ATTN_SEPARATE_CONTEXT_NORM": True,    # attention.attention_item: norm for q, norm_context for k / v (also self-attn)
+    "SKIP_SCALES_BRANCH": True,            # _Run.block: y = skip + scale * (up conv), conv epilogue e_scale / res
+    "SKIP_CAT_SCALE": 2 ** -0.5,           # _Run.block (use_modulation=False): cat[skip * 2^-1/2, x]
+    "GN_EPS": ops.GN_EPS,
+    "LN_EPS": ops.LN_EPS,
+}
+
 
 def item_list(items: int, use_modulation: bool, ctx_channels: int, att: int, cross: int) -> List[str]:
     """Item types of one depth, composed exactly as components.py:88-95 does."""
@@ -87,8 +107,13 @@ class UNetV0Net(nn.Module):
                  items: Sequence[int], attentions: Sequence[int], cross_attentions: Sequence[int],
                  context_channels: Sequence[int], attention_features: Optional[int], attention_heads: Optional[int],
                  embedding_features: Optional[int], resnet_groups: int, modulation_features: int,
-                 out_channels: Optional[int], use_modulation: bool = True, use_time_conditioning: bool = True):
+                 out_channels: Optional[int], use_modulation: bool = True, use_time_conditioning: bool = True,
+                 blocks=None):
         super().__init__()
+        if blocks is not None:  # the package also exports this class under a_unet's name XUNet (__init__.py:1 there)
+            raise NotImplementedError("a_unet's XUNet(in_channels, blocks=[XBlock(...), ...]) block-list constructor is "
+                                      "not rebuilt here (a_unet API, outside the hot-path scope); build the net through "
+                                      "UNetV0(...), which composes the same blocks (components.py:79-105)")
         assert dim == 1, "audio U-Net is 1-D"
         assert use_modulation or not use_time_conditioning, "use_time_conditioning requires use_modulation=True"
         n = len(channels)

@@ -66,9 +66,21 @@ def cpu_baseline(batch: int, threads: int = 16, budget_s: float = 25.0):
         if time.perf_counter() - t0 > 4 * budget_s:
             break
     dt = (time.perf_counter() - t0) / n
-    return {"value": round(1.0 / (dt * batch), 4), "unit": "denoising steps/s", "cores": cores, "kind": "port",
+    return {"value": round(1.0 / (dt * batch), 4), "unit": "denoising steps/s", "cores": cores,
+            "host_cores": os.cpu_count(), "host_cpu": _cpu_model(), "kind": "port",
             "sample": f"{n} fwd+bwd steps of the same UNetV0 on ONE sample [1,2,2**18] ({dt:.2f} s each, fp32, torch "
                       f"CPU, {cores} threads, after 1 warm-up step), scaled to the bench step of {batch} samples"}
+
+
+def _cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def profiled_step(model, step):
@@ -133,6 +145,10 @@ def roofline_leg(model, x, top: int = 14):
         e["frac"] = round(e["achieved"] / e["peak"], 4)
         t = pmc.get(name.split(" | ")[0])
         e["traffic"] = t.get("hbm_bytes_per_launch") if t else None
+        e["traffic_source"] = ("stored rocprofv3 PMC pass of this command (profiles/pmc_traffic.json: separate FETCH_SIZE / "
+                               "WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction)") if t else None
+        if t and "mfma_busy" in t:  # SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES-derived, same stored pass family
+            e["mfma_busy"] = t["mfma_busy"]
         e["algorithmic_bytes_per_launch"] = int(a["bytes"] // a["launches"])
         return e
 
@@ -264,13 +280,10 @@ def extra_legs(model, x, dev):
                           "ms_per_step": round(dt / 50 * 1e3, 3), "ms_per_50_step_sample": round(dt * 1e3, 2)}
     except Exception as e:
         out["sampler"] = {"error": f"{type(e).__name__}: {e}"}
-    # kernel-family A/B on the headline step (forward / data-gradient convs of the >= 256-channel layers):
-    #   default             conv_wino.hip (Winograd F(2,3) on the exact-f32 matrix cores, two thirds of the MFMA work) for
-    #                       grids of >= 400 tiles, conv_mm.hip otherwise
-    #   direct_form_convs   ADP_CONV_WINO=0: conv_mm.hip everywhere (the round-1 / early round-2 default)
-    #   bf16_split_convs    ADP_CONV_BS=1: conv_bs.hip, six bf16 MFMA products of an exact 3-way bf16 split (opt-in)
-    for key, env, val, what in (("direct_form_convs", "ADP_CONV_WINO", "0", "in the direct form on the f32 matrix cores (conv_mm only)"),
-                                ("bf16_split_convs", "ADP_CONV_BS", "1", "on the bf16 matrix cores at fp32 accuracy (3-way bf16 split; opt-in)")):
+    # kernel-family A/B on the headline step: the kernel-3 convs and weight gradients run in the Winograd F(2,3) domain
+    # on the exact-f32 matrix cores by default (conv_mm / wgrad_mm WN variants: two thirds of the MFMAs, plain fp32);
+    #   direct_form_convs   ADP_CONV_WINO=0: the same kernels in the direct form (the round-1 / round-2 arithmetic)
+    for key, env, val, what in (("direct_form_convs", "ADP_CONV_WINO", "0", "in the direct form on the f32 matrix cores"),):
         prev = os.environ.get(env)
         try:
             os.environ[env] = val
@@ -279,8 +292,8 @@ def extra_legs(model, x, dev):
                 zero(model)
                 model(x).backward()
             dt = _time(_graphed(stepb, lambda: zero(model)), 20)
-            out[key] = {"workload": f"headline step ([{x.shape[0]},2,2**18] fwd+bwd) with {env}={val}: forward / data-gradient "
-                                    f"convs of the >= 256-channel layers {what}",
+            out[key] = {"workload": f"headline step ([{x.shape[0]},2,2**18] fwd+bwd) with {env}={val}: kernel-3 convs and "
+                                    f"weight gradients {what}",
                         "steps_per_s": round(1.0 / dt, 2), "ms_per_step": round(dt * 1e3, 3)}
         except Exception as e:
             out[key] = {"error": f"{type(e).__name__}: {e}"}
@@ -323,6 +336,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE configs[1]: 4)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling: total batch split over the ranks (BASELINE configs 4/5: 8 over 8 GPUs); "
+                         "0 = weak scaling with --batch per GPU (the default the driver runs)")
     ap.add_argument("--graph", type=int, default=-1, help="1: replay the step from a hipGraph, 0: eager; "
                                                           "default: graph on 1 GPU, eager with RCCL")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -340,6 +356,11 @@ def main():
     dev = torch.device("cuda", local)
     import torch.distributed as dist
 
+    scaling = "weak"
+    if args.global_batch:
+        assert args.global_batch % world == 0, "--global-batch must be divisible by the number of GPUs"
+        args.batch = args.global_batch // world
+        scaling = "strong"
     model = build_model(dev)
     if world > 1:
         model = parallel.DataParallel(model)
@@ -403,7 +424,7 @@ def main():
     line = {
         "metric": "denoising steps/s (UNetV0 fwd+bwd) at [B,2,2**18]", "value": round(value, 3),
         "unit": "denoising steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: unconditional DiffusionModel(UNetV0 channels="
                                "[8,32,64,128,256,512,512,1024,1024], factors=[1,4,4,4,2,2,2,2,2], "
@@ -411,8 +432,22 @@ def main():
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "length": LENGTH,
                    "samples_per_s": round(value * args.batch, 2), "launch": "hipGraph replay" if graph else "eager",
                    "parallelism": f"dp{world}" if world > 1 else "single",
+                   "collective_backend": (dist.get_backend() if world > 1 else None),
+                   "collective_world_size": (dist.get_world_size() if world > 1 else 1),
                    "optimizer": "none (the metric is fwd+bwd; gradients for all 176M parameters are produced)"},
     }
+    if world > 1 and not args.no_extras:
+        # outside the timed region, every rank in lockstep: how much of the gradient all-reduce hides under backward
+        try:
+            def dp_step():
+                zero()
+                model(x).backward()
+            ov = model.measure_overlap(dp_step, lambda fn, n: _time(fn, n, warmup=1), reps=5)
+            if rank == 0:
+                line["dp_overlap"] = ov
+        except Exception as e:
+            if rank == 0:
+                line["dp_overlap"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_roofline:
         try:
             rf, hbm, extra, eager_ms = roofline_leg(model.module if world > 1 else model, x)

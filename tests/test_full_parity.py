@@ -62,6 +62,49 @@ def test_config3_sampler_full(hip, pair):
         assert torch.equal(out, out2)
 
 
+@pytest.mark.gpu
+def test_config3_sampler_50_steps(hip, pair):
+    """BASELINE config 3 as stated: VSampler.sample with num_steps=50 on noise [1, 2, 2**18] (hipGraph-captured step
+    replayed 50 times) against the CPU oracle's 50 steps (diffusion.py:183-188), 1e-3 rel on the final sample."""
+    oracle = pair
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    noise = torch.randn(1, 2, 2 ** 18, generator=torch.Generator().manual_seed(0))
+    ref = ovd.v_sample(oracle, noise, 50)
+    model = adp.DiffusionModel(net_t=adp.UNetV0, **FULL)
+    model.net.load_oracle_state_dict(oracle.state_dict())
+    model = model.to(hip)
+    out = model.sample(noise.to(hip), num_steps=50)
+    assert out.shape == ref.shape and rel_err(out, ref) < 1e-3
+
+
+@pytest.mark.gpu
+def test_config5_upsampler_sample_at_batch_8(hip):
+    """BASELINE config 5's sampling half as stated: `DiffusionUpsampler.sample(randn(8, 2, 2**14), num_steps=50)` ->
+    [8, 2, 2**18] (models.py:160-165: polyphase upsample x16, host-drawn starting noise, 50 VSampler steps with the
+    conditioning appended).  Seeded like a user script (torch.manual_seed): the product must draw the reference's
+    starting noise.  The whole batch runs on the GPU; two of the eight samples are followed through the CPU oracle
+    (samples are independent: no batch-coupled op exists on the path)."""
+    from oracle.a_unet_restatement import AppendChannelsOracle
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    torch.manual_seed(0)
+    cfg = dict(FULL)
+    cfg.pop("in_channels")
+    up = adp.DiffusionUpsampler(net_t=adp.UNetV0, in_channels=2, upsample_factor=16, **cfg)
+    oracle = AppendChannelsOracle(lambda **kw: UNetV0Oracle(**kw), channels=2)(in_channels=2, **cfg)
+    up.net.net.load_oracle_state_dict(oracle.net.state_dict())
+    up = up.to(hip)
+    low = torch.randn(8, 2, 2 ** 14, generator=torch.Generator().manual_seed(7))
+    torch.manual_seed(123)
+    out = up.sample(low.to(hip), num_steps=50)
+    assert out.shape == (8, 2, 2 ** 18)
+    torch.manual_seed(123)
+    start = torch.randn(8, 2, 2 ** 18)  # the reference's draw: utils.randn_like on the host (utils.py:123-125)
+    cond = ovd.upsample(low, 16)
+    for i in (0, 5):
+        ref = ovd.v_sample(oracle, start[i:i + 1], 50, append_channels=cond[i:i + 1])
+        assert rel_err(out[i:i + 1], ref) < 1e-3, i
+
+
 ATTN_README = dict(attentions=[0, 0, 0, 0, 0, 1, 1, 1, 1], attention_heads=8, attention_features=64)
 CROSS_CFG4 = dict(cross_attentions=[0, 0, 0, 1, 1, 1, 1, 1, 1], embedding_features=768, attention_heads=8,
                   attention_features=64)
@@ -221,12 +264,11 @@ def up_sample_input(up, low):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["ADP_CONV_WINO", "ADP_CONV_BS"])
-def test_opt_in_conv_families_inside_the_unet(hip, env, monkeypatch):
-    """The alternative kernel families for the wide convs (Winograd F(2,3): default on big grids, forced on here for a
-    small one; three-way bf16 split: opt-in) inside a whole U-Net step:
-    loss, prediction and every parameter gradient against the default kernels on the same weights and inputs.  Both
-    are fp32-accurate, so the bound is 1e-4 (ten times tighter than the path's parity tolerance)."""
+def test_winograd_and_direct_form_agree_inside_the_unet(hip, monkeypatch):
+    """The Winograd F(2,3) variants of the kernel-3 convs and weight gradients (the default) against the direct form
+    (ADP_CONV_WINO=0) inside a whole U-Net step: loss, prediction and every parameter gradient on the same weights and
+    inputs.  Both are plain fp32 arithmetic, so the bound is 1e-4 (ten times tighter than the path's parity tolerance)."""
+    env = "ADP_CONV_WINO"
     cfg = dict(in_channels=2, channels=[8, 32, 256, 512], factors=[1, 4, 4, 2], items=[1, 1, 2, 2])
     torch.manual_seed(0)
     model = adp.DiffusionModel(net_t=adp.UNetV0, diffusion_sigma_distribution=FixedSigmas([0.3, 0.7]), **cfg).to(hip)

@@ -78,45 +78,14 @@ def test_conv1d_cross_workgroup_split_k(dev, B, R, M, L, KT, tr):
     assert rel_err(out, ref) < TOL and rel_err(pre, pre_ref) < TOL
 
 
-@pytest.mark.parametrize("B,R,M,L,tr", [(2, 256, 128, 200, False), (1, 512, 256, 128, False), (2, 256, 128, 130, True),
-                                        (1, 1024, 128, 64, True)])
-def test_conv1d_bf16_split_is_fp32_accurate(dev, B, R, M, L, tr, monkeypatch):
-    """conv_bs (ADP_CONV_BS=1): the deep kernel-3 convs as six bf16 MFMA partial products of an exact three-way bf16
-    split.  The claim is fp32 accuracy, so the bound here is 2e-6 against an fp64 reference (the parity tolerance of
-    the path is 1e-3), next to the exact-f32 MFMA kernel on the same inputs; ragged tile, K split, full epilogue."""
-    monkeypatch.setenv("ADP_CONV_BS", "1")
-    x = rnd(B, R, L, seed=1)
-    w = rnd(R, M, 3, seed=2, scale=0.05) if tr else rnd(M, R, 3, seed=2, scale=0.05)
-    b, res, sc = rnd(M, seed=3), rnd(B, M, L, seed=4), rnd(B * M, seed=5)
-    xd_, wd_ = x.double(), w.double()
-    ref = F.conv_transpose1d(xd_, wd_, None, padding=1) if tr else F.conv1d(xd_, wd_, None, padding=1)
-    pre_ref = ref + b.double()[None, :, None]
-    ref = pre_ref * sc.double().view(B, M, 1) + res.double()
-    pre = torch.empty(B, M, L).to(dev)
-    args = (x.to(dev), w.to(dev), b.to(dev))
-    kw = dict(pad=1, transposed=tr, e_scale=sc.to(dev), res=res.to(dev))
-    out = ops.conv1d(*args, out_pre=pre, **kw)
-    e_bs = ((out.cpu().double() - ref).abs().max() / ref.abs().max()).item()
-    e_pre = ((pre.cpu().double() - pre_ref).abs().max() / pre_ref.abs().max()).item()
-    monkeypatch.setenv("ADP_CONV_BS", "0")
-    out32 = ops.conv1d(*args, **kw)
-    e_32 = ((out32.cpu().double() - ref).abs().max() / ref.abs().max()).item()
-    assert e_bs < 2e-6 and e_pre < 2e-6, (e_bs, e_pre, e_32)
-    assert e_bs < 4 * e_32 + 2e-7, (e_bs, e_32)
-
-
-@pytest.mark.parametrize("mode", ["R", "L"])
 @pytest.mark.parametrize("B,R,M,L,tr", [(2, 256, 64, 200, False), (1, 512, 64, 64, False), (2, 256, 96, 132, True),
                                         (1, 1024, 32, 64, True), (3, 288, 32, 4, False), (1, 256, 32, 260, True),
                                         (4, 256, 128, 512, False)])
-def test_conv1d_winograd_family(dev, B, R, M, L, tr, mode, monkeypatch):
-    """Winograd F(2,3) form of the wide kernel-3 convs on the exact-f32 matrix cores -- mode R: conv_mm's WN variant
-    (transforms in the MMA waves' registers, the default), mode L: the first-generation conv_wino kernel (transforms in
-    the loader waves, kept for A/B).  Forward and transposed-weight view, ragged last tile, a length shorter than one
+def test_conv1d_winograd_family(dev, B, R, M, L, tr, monkeypatch):
+    """Winograd F(2,3) form of the wide kernel-3 convs on the exact-f32 matrix cores (conv_mm's WN variant: transforms
+    in the MMA waves' registers).  Forward and transposed-weight view, ragged last tile, a length shorter than one
     tile, the cross-workgroup K split, 32- and 64-row blocks, the full epilogue and the GroupNorm partial statistics.
     fp32 throughout: the bound against an fp64 reference is 1e-5, next to the direct form (ADP_CONV_WINO=0)."""
-    if dev.type != "cuda" and B * M * L > 100000 and mode == "L":
-        pytest.skip("big emulated case: covered for the default variant")
     x = rnd(B, R, L, seed=1)
     w = rnd(R, M, 3, seed=2, scale=0.05) if tr else rnd(M, R, 3, seed=2, scale=0.05)
     b, res, sc = rnd(M, seed=3), rnd(B, M, L, seed=4), rnd(B * M, seed=5)
@@ -131,9 +100,8 @@ def test_conv1d_winograd_family(dev, B, R, M, L, tr, mode, monkeypatch):
     from audio_diffusion_pytorch_amd import _C
     d = _C.ConvDesc(_C.ptr(args[0]), None, _C.ptr(args[1]), None, None, None, None, None, None, _C.ptr(args[0]), None, B, R, R,
                     L, M, L, 3, 1, 1, 1, 1, int(tr), 0, 1, 0, 1, 0)
-    monkeypatch.setenv("ADP_CONV_WINO", mode)
-    tile = _C.query("adp_conv1d_tile", byref(d))
-    assert (tile // 10000000 == 4) if mode == "R" else (tile == 4032064), "this shape is meant to take the Winograd kernel"
+    monkeypatch.setenv("ADP_CONV_WINO", "1")
+    assert _C.query("adp_conv1d_tile", byref(d)) // 10000000 == 4, "this shape is meant to take the Winograd variant"
     pre = torch.empty(B, M, L).to(dev)
     gn = ops.GnPart()
     out = ops.conv1d(*args, out_pre=pre, gn=gn, **kw)
@@ -154,7 +122,7 @@ def test_conv1d_winograd_family(dev, B, R, M, L, tr, mode, monkeypatch):
 def test_conv1d_winograd_with_groupnorm_prologue(dev, C, L, tr, monkeypatch):
     """The Winograd variant under the GroupNorm+SiLU loader prologue (the mid-depth ConvBlocks), channel counts below
     the default threshold switched in with ADP_WINO_MIN_R."""
-    monkeypatch.setenv("ADP_CONV_WINO", "R")
+    monkeypatch.setenv("ADP_CONV_WINO", "1")
     monkeypatch.setenv("ADP_WINO_MIN_R", "32")
     B, G = 2, 8
     x = rnd(B, C, L, seed=1) * 1.7 + 0.3
@@ -328,16 +296,22 @@ MM_RESAMPLE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("wino", ["0", "1"])
 @pytest.mark.parametrize("B,R,M,L,KT,stride,pad,up", MM_RESAMPLE_CASES)
-def test_conv_mm_resample(dev, B, R, M, L, KT, stride, pad, up):
+def test_conv_mm_resample(dev, B, R, M, L, KT, stride, pad, up, wino, monkeypatch):
     from audio_diffusion_pytorch_amd import _C
+    if wino == "1" and KT != 3:
+        pytest.skip("Winograd F(2,3) is the kernel-3 form")
+    monkeypatch.setenv("ADP_CONV_WINO", wino)
+    monkeypatch.setenv("ADP_WINO_MIN_R", "32")
     x, w, b = rnd(B, R, L, seed=1), rnd(M, R, KT, seed=2, scale=0.2), rnd(M, seed=3)
     xr = F.interpolate(x, scale_factor=up, mode="nearest") if up > 1 else x
     ref = F.conv1d(xr, w, b, stride=stride, padding=pad)
     xd, wd = x.to(dev), w.to(dev)
     d = _C.ConvDesc(_C.ptr(xd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(xd), None, B, R, R, L, M,
                     ref.shape[-1], KT, stride, 1, pad, up, 0, 0, 1, 0, 1, 0)
-    assert _C.query("adp_conv1d_tile", d) >= 1000000, "case must dispatch to the conv_mm family"
+    tile = _C.query("adp_conv1d_tile", d)
+    assert tile >= 1000000 and (tile >= 40000000) == (wino == "1"), "case must dispatch to the conv_mm family"
     # with the SkipModulate epilogue of the up path: out = skip + scale[b, m] * (conv + bias), pre-merge value kept
     skip, scale = rnd(*ref.shape, seed=5), rnd(B, M, seed=6)
     pre = torch.empty(ref.shape, device=dev)
@@ -345,6 +319,73 @@ def test_conv_mm_resample(dev, B, R, M, L, KT, stride, pad, up):
                      res=skip.to(dev), out_pre=pre)
     assert rel_err(pre, ref) < TOL
     assert rel_err(out, skip + scale[:, :, None] * ref) < TOL
+
+
+@pytest.mark.parametrize("wino", ["0", "1"])
+@pytest.mark.parametrize("B,Rf,Mf,L,up", [(2, 64, 96, 72, 2), (1, 32, 64, 40, 4), (2, 64, 32, 64, 4)])
+def test_conv_mm_upsample_dgrad_pooled_store(dev, B, Rf, Mf, L, up, wino, monkeypatch):
+    """Data gradient of UpsampleItem (nearest x up, then k3 conv) on conv_mm: the transposed-weight conv over dy with
+    the pooled store (sum of the `up` replicas of each source position) + the residual epilogue, direct and Winograd."""
+    monkeypatch.setenv("ADP_CONV_WINO", wino)
+    monkeypatch.setenv("ADP_WINO_MIN_R", "32")
+    x = rnd(B, Rf, L, seed=1).requires_grad_()
+    w = rnd(Mf, Rf, 3, seed=2, scale=0.2)
+    y = F.conv1d(F.interpolate(x, scale_factor=up, mode="nearest"), w, None, padding=1)
+    dy, res = rnd(*y.shape, seed=9), rnd(B, Rf, L, seed=10)
+    (dx_ref,) = torch.autograd.grad(y, x, dy)
+    dx = ops.conv1d(dy.to(dev), w.to(dev), None, pad=1, transposed=True, store=2, sp=up, res=res.to(dev))
+    assert rel_err(dx, dx_ref + res) < TOL
+
+
+# ------------------------------------------------------------------ integer index math: bit-exact (north_star)
+@pytest.mark.parametrize("wino", ["0", "1"])
+@pytest.mark.parametrize("B,C,L,up", [(2, 32, 96, 2), (1, 64, 40, 4), (2, 8, 50, 4), (1, 2, 64, 2), (1, 32, 30, 3)])
+def test_nearest_upsample_gather_is_bit_exact(dev, B, C, L, up, wino, monkeypatch):
+    """UpsampleItem = nearest upsample (source index floor(dst / f)) then a k3 conv, with the gather folded into the conv
+    loaders.  With a one-hot centre tap the conv is the identity, so the output must EQUAL the nearest-upsampled input
+    -- integer-valued inputs keep every evaluation order (direct, Winograd F(2,3)) exact, so torch.equal tests the index
+    math alone, on every kernel family that serves the shape (MFMA, direct VALU, generic)."""
+    monkeypatch.setenv("ADP_CONV_WINO", wino)
+    monkeypatch.setenv("ADP_WINO_MIN_R", "32")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-64, 64, (B, C, L), generator=g).float()
+    w = torch.zeros(C, C, 3)
+    w[torch.arange(C), torch.arange(C), 1] = 1.0
+    out = ops.conv1d(x.to(dev), w.to(dev), None, pad=1, up=up)
+    ref = x.repeat_interleave(up, dim=2)  # dst l reads source l // up
+    assert torch.equal(out.cpu(), ref)
+    # shifted taps: output l = upsampled[l - 1] / upsampled[l + 1] with the zero padding at the ends
+    for tap, sh in ((0, 1), (2, -1)):
+        w = torch.zeros(C, C, 3)
+        w[torch.arange(C), torch.arange(C), tap] = 1.0
+        out = ops.conv1d(x.to(dev), w.to(dev), None, pad=1, up=up).cpu()
+        exp = torch.zeros_like(ref)
+        if sh == 1:
+            exp[..., 1:] = ref[..., :-1]
+        else:
+            exp[..., :-1] = ref[..., 1:]
+        assert torch.equal(out, exp), tap
+
+
+@pytest.mark.parametrize("B,R,f,L", [(2, 32, 2, 128), (1, 32, 4, 256), (2, 8, 4, 64), (1, 2, 4, 1024), (1, 16, 2, 36),
+                                     (2, 4, 3, 30)])
+def test_strided_window_is_bit_exact(dev, B, R, f, L):
+    """DownsampleItem = Conv1d(kernel = stride = f): output l reads the window x[l*f .. l*f + f - 1].  One-hot weights
+    that route input (r, k) to output channel r*f + k turn the conv into the space-to-depth permutation, which must be
+    reproduced exactly (torch.equal) by every strided kernel variant and by adp_unshuffle's path for f = 3."""
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, R, L, generator=g)
+    M = R * f
+    w = torch.zeros(M, R, f)
+    for r in range(R):
+        for k in range(f):
+            w[r * f + k, r, k] = 1.0
+    ref = x.view(B, R, L // f, f).permute(0, 1, 3, 2).reshape(B, M, L // f)
+    if f in (2, 4):
+        out = ops.conv1d(x.to(dev), w.to(dev), None, stride=f)
+    else:
+        out = ops.conv1d(ops.unshuffle(x.to(dev), f), w.view(M, R * f, 1).to(dev), None)
+    assert torch.equal(out.cpu(), ref)
 
 
 DIRECT_CASES = [
@@ -470,14 +511,14 @@ WGMM_CASES = [
 ]
 
 
-@pytest.mark.parametrize("wino", ["0", "R"])
+@pytest.mark.parametrize("wino", ["0", "1"])
 @pytest.mark.parametrize("B,R,M,L,KT", WGMM_CASES)
 def test_wgrad_mm_family(dev, B, R, M, L, KT, wino, monkeypatch):
-    """wino = R: the kernel-3 cases on the Winograd F(2,3) weight-gradient variant (WN; four rank-1 updates per
+    """wino = 1: the kernel-3 cases on the Winograd F(2,3) weight-gradient variant (WN; four rank-1 updates per
     output pair instead of six), switched in for every channel count."""
     if dev.type != "cuda" and R * M > 65536:
         pytest.skip("emulating 256 16-wave workgroups takes minutes; covered on the GPU")
-    if wino == "R" and KT != 3:
+    if wino == "1" and KT != 3:
         pytest.skip("Winograd F(2,3) is the kernel-3 form")
     monkeypatch.setenv("ADP_CONV_WINO", wino)
     monkeypatch.setenv("ADP_WINO_WGRAD_MIN_R", "32")
@@ -507,10 +548,15 @@ def test_wgrad_mm_family(dev, B, R, M, L, KT, wino, monkeypatch):
     assert rel_err(db, db_ref + db0) < TOL
 
 
+@pytest.mark.parametrize("wino", ["0", "1"])
 @pytest.mark.parametrize("B,R,M,L,KT,stride,pad,up", MM_RESAMPLE_CASES + [(2, 64, 64, 128, 2, 2, 0, 1),
                                                                          (2, 64, 128, 20, 3, 1, 1, 4)])
-def test_wgrad_mm_resample(dev, B, R, M, L, KT, stride, pad, up):
+def test_wgrad_mm_resample(dev, B, R, M, L, KT, stride, pad, up, wino, monkeypatch):
     """Weight gradients of DownsampleItem (kernel = stride) and UpsampleItem (nearest + k3) on wgrad_mm."""
+    if wino == "1" and KT != 3:
+        pytest.skip("Winograd F(2,3) is the kernel-3 form")
+    monkeypatch.setenv("ADP_CONV_WINO", wino)
+    monkeypatch.setenv("ADP_WINO_WGRAD_MIN_R", "32")
     x = rnd(B, R, L, seed=1)
     w = rnd(M, R, KT, seed=2, scale=0.2).requires_grad_()
     b = rnd(M, seed=3).requires_grad_()

@@ -159,6 +159,21 @@ def test_restatement_structure():
         adp.UNetV0(dim=1, in_channels=2, channels=[8, 16], factors=[1], items=[1, 1])
 
 
+def test_product_semantics_match_oracle_switches():
+    """The product hard-wires the recalled a_unet semantics in kernels and host code (unet.A_UNET_SEMANTICS says where);
+    the oracle names the same choices as [switch] constants.  The two tables must agree: a switch flipped in the oracle
+    (e.g. after tools/pin_a_unet.py compared it with a real a_unet) cannot silently diverge from the kernels."""
+    import oracle.a_unet_restatement as rs
+    from audio_diffusion_pytorch_amd.unet import A_UNET_SEMANTICS
+    switches = {k: getattr(rs, k) for k in A_UNET_SEMANTICS}
+    assert switches == A_UNET_SEMANTICS
+    # every [switch] of the oracle's header block is covered by the product table
+    src = open(rs.__file__).read()
+    block = src[src.index("# [switch] constants"):src.index("ITEM_RESNET")]
+    import re
+    assert set(re.findall(r"^([A-Z][A-Z0-9_]+)\s*=", block, flags=re.M)) == set(A_UNET_SEMANTICS)
+
+
 def test_c_abi_exports_every_declared_symbol():
     """include/adp.h <-> the built libraries: every declared function is exported (no compute calls)."""
     import ctypes

@@ -153,6 +153,30 @@ def test_upsampler_append_channels(dev):
     compare_grads(up.net.net, oracle_wrap.net)
 
 
+def test_upsampler_sample_draws_the_references_noise(dev):
+    """`DiffusionUpsampler.sample(low)` in a seeded script: the reference draws the starting noise on the HOST from the
+    global generator (utils.randn_like, utils.py:123-125; models.py:164).  The product does the same, so
+    torch.manual_seed(s) reproduces the reference's sample on any backend; an explicit CPU generator likewise."""
+    from oracle.a_unet_restatement import AppendChannelsOracle
+    torch.manual_seed(0)
+    cfg = dict(TINY)
+    cfg.pop("in_channels")
+    up = adp.DiffusionUpsampler(net_t=adp.UNetV0, in_channels=2, upsample_factor=4, **cfg)
+    oracle = AppendChannelsOracle(lambda **kw: UNetV0Oracle(**kw), channels=2)(in_channels=2, **cfg)
+    up.net.net.load_oracle_state_dict(oracle.net.state_dict())
+    up = up.to(dev)
+    low = torch.randn(2, 2, 64, generator=torch.Generator().manual_seed(9))
+    cond = ovd.upsample(low, 4)
+    torch.manual_seed(77)
+    out = up.sample(low.to(dev), num_steps=3)
+    torch.manual_seed(77)
+    ref = ovd.v_sample(oracle, torch.randn(cond.shape), 3, append_channels=cond)
+    assert rel_err(out, ref) < TOL
+    out_g = up.sample(low.to(dev), generator=torch.Generator().manual_seed(5), num_steps=3)
+    ref_g = ovd.v_sample(oracle, torch.randn(cond.shape, generator=torch.Generator().manual_seed(5)), 3, append_channels=cond)
+    assert rel_err(out_g, ref_g) < TOL
+
+
 ATTN = dict(in_channels=2, channels=[8, 16, 32], factors=[1, 2, 2], items=[1, 1, 2], modulation_features=32,
             attentions=[0, 1, 1], cross_attentions=[0, 0, 1], attention_heads=2, attention_features=8,
             embedding_features=12)

@@ -151,6 +151,40 @@ def test_text_conditioning_with_supplied_embedder(dev):
         adp.UNetV0(dim=1, use_text_conditioning=True, **cfg)
 
 
+def test_sampling_with_text_embeds_once_and_replays_a_graph(dev):
+    """`model.sample(noise, text=[...])` on a use_text_conditioning net: the sampler resolves the text to an embedding
+    tensor ONCE before its loop (TextConditioningNet.prepare_sampling_kwargs) instead of running the host-side
+    embedder on every step, so the captured step holds no tokenizer / H2D copy and the default use_graph=True path
+    replays a hipGraph on the GPU (round-2 advisor finding: the embedder used to be captured).  Same samples as the
+    oracle driven with the pre-computed embedding."""
+    cfg = dict(in_channels=2, channels=[8, 16], factors=[2, 2], items=[1, 1], modulation_features=32,
+               cross_attentions=[0, 1], attention_heads=2, attention_features=8, embedding_features=12)
+    from oracle import vdiffusion as ovd
+    torch.manual_seed(0)
+    oracle = UNetV0Oracle(**cfg)
+    emb = _ToyTextEmbedder(12)
+    calls = []
+    emb.register_forward_hook(lambda m, a, o: calls.append(1))
+    model = adp.DiffusionModel(net_t=adp.UNetV0, use_text_conditioning=True, text_embedder=emb, **cfg)
+    model.net.net.load_oracle_state_dict(oracle.state_dict())
+    model = model.to(dev)
+    g = torch.Generator().manual_seed(15)
+    noise, extra = torch.randn(2, 2, 64, generator=g), torch.randn(2, 2, 12, generator=g)
+    texts = ["abc", "xyz"]
+    e_ref = torch.cat([emb(texts).cpu(), extra], dim=1)
+    calls.clear()
+    ref = ovd.v_sample(oracle, noise, 4, embedding=e_ref)
+    for _ in range(2):  # second run: cached graph on the GPU
+        out = model.sample(noise.to(dev), num_steps=4, text=texts, embedding=extra.to(dev))
+        assert rel_err(out, ref) < TOL
+    assert len(calls) == 2, "one embedder call per sampling run"
+    if dev.type == "cuda":
+        assert len(model.sampler._graph_cache) == 1, "the step was captured and replayed"
+    # strings that reach a step un-resolved are never treated as static graph inputs
+    from audio_diffusion_pytorch_amd.diffusion import _kw_spec
+    assert _kw_spec("abc", []) is None and _kw_spec(["a", "b"], []) is None
+
+
 def test_append_channels_around_any_net(dev):
     """AppendChannelsPlugin(net_t) with a net_t that is not UNetV0: the plugin concatenates with adp_copy2d and the
     wrapped net sees [B, C + channels, L] (components.py:174-176); gradients flow to both inputs."""
@@ -277,3 +311,14 @@ def test_out_of_scope_reference_exports_say_so():
     for name in ("DiffusionVocoder", "MelSpectrogram", "DiffusionAR", "LTPlugin"):
         with pytest.raises(NotImplementedError, match=name):
             getattr(adp, name)(net_t=None)
+    for name in ("DiffusionVocoder", "MelSpectrogram", "DiffusionAR"):  # classes in the reference: stay classes
+        assert isinstance(getattr(adp, name), type)
+
+        class Sub(getattr(adp, name)):  # subclassing / issubclass keep working
+            pass
+        assert issubclass(Sub, getattr(adp, name))
+    # XUNet is exported under a_unet's name; its block-list constructor is a_unet API and says so
+    with pytest.raises(NotImplementedError, match="XUNet"):
+        adp.XUNet(dim=1, in_channels=2, channels=[8], factors=[1], items=[1], attentions=[0], cross_attentions=[0],
+                  context_channels=[0], attention_features=None, attention_heads=None, embedding_features=None,
+                  resnet_groups=8, modulation_features=32, out_channels=None, blocks=[object()])

@@ -1,8 +1,8 @@
 """A/B of the conv families behind adp_conv1d / adp_conv1d_wgrad on the GPU box (kernel work, not part of the product):
 
   python tools/conv_family_ab.py micro [batch]   isolated launches of the wide ResnetItem shapes, forward / data gradient /
-                                                 weight gradient, per ADP_CONV_WINO mode (0 = direct form, L = loader-side
-                                                 Winograd of round 2, R = Winograd in the MMA waves' registers)
+                                                 weight gradient, per ADP_CONV_WINO mode (0 = direct form, 1 = Winograd F(2,3)
+                                                 in the MMA waves' registers)
   python tools/conv_family_ab.py step [rounds]   the headline training step replayed from a hipGraph under a list of
                                                  environment settings, interleaved
 """
@@ -54,9 +54,7 @@ def micro():
         res = torch.randn(B, C, L, device=dev)
         fl = 2 * B * C * C * 3 * L
         ref = torch.nn.functional.conv1d(x.double(), w.double(), bias.double(), padding=1) + res.double()
-        for mode in ("0", "L", "R"):
-            if mode == "L" and C < 256:
-                continue
+        for mode in ("0", "1"):
             setenv({"ADP_CONV_WINO": mode, "ADP_WINO_MIN_R": "64", "ADP_WINO_WGRAD_MIN_R": "64"})
             out = ops.conv1d(x, w, bias, pad=1, res=res)
             err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
@@ -75,13 +73,12 @@ def step():
     dev = torch.device("cuda:0")
     settings = [
         ("direct", {"ADP_CONV_WINO": "0"}),
-        ("wino-L", {"ADP_CONV_WINO": "L"}),
-        ("wino-R", {}),
-        ("wino-R conv only", {"ADP_WINO_WGRAD_MIN_R": "100000"}),
-        ("wino-R wgrad only", {"ADP_WINO_MIN_R": "100000"}),
-        ("wino-R all>=64", {"ADP_WINO_MIN_R": "64", "ADP_WINO_WGRAD_MIN_R": "64"}),
-        ("wino-R all>=128", {"ADP_WINO_MIN_R": "128", "ADP_WINO_WGRAD_MIN_R": "128"}),
-        ("wino-R wgrad>=256", {"ADP_WINO_WGRAD_MIN_R": "256"}),
+        ("wino", {}),
+        ("wino conv only", {"ADP_WINO_WGRAD_MIN_R": "100000"}),
+        ("wino wgrad only", {"ADP_WINO_MIN_R": "100000"}),
+        ("wino all>=32", {"ADP_WINO_MIN_R": "32", "ADP_WINO_WGRAD_MIN_R": "32"}),
+        ("wino all>=128", {"ADP_WINO_MIN_R": "128", "ADP_WINO_WGRAD_MIN_R": "128"}),
+        ("wino all>=256", {"ADP_WINO_MIN_R": "256", "ADP_WINO_WGRAD_MIN_R": "256"}),
     ]
     extra = os.environ.get("AB_SETTINGS")
     if extra:  # name=K:V,K:V;name2=...
