@@ -209,6 +209,90 @@ __global__ __launch_bounds__(256) void gn_act_kernel(const float* x, const float
   }
 }
 
+// ---- the three materialising kernels above, slab form (L % 4 == 0) -------------------------------------------------------
+// A group's Cg rows are one contiguous run of Cg * L floats, so a workgroup takes 256 * NV float4 of that run -- whatever
+// the row length -- instead of one (mostly idle) workgroup per 1024-element piece of a row: the deep layers' rows are
+// 128-256 floats long, where the row form ran 4096 workgroups with a quarter of their threads busy, each re-deriving the
+// group's statistics (10.9 us for a 4 MB tensor).  SRC: 0 = finished statistics, 1 = the producer's (mean, M2, count)
+// partials (gn_finalize_act), 2 = gn_partial_kernel's chunk partials (gn_stats_act).
+template <int SRC, int NV>
+__global__ __launch_bounds__(256) void gn_act_slab_kernel(const float* x, const float* src, const float* gamma,
+                                                          const float* beta, int64_t C, int64_t L, int64_t G, int64_t E,
+                                                          float eps, float* stats, float* a) {
+  __shared__ float st[2];
+  const int64_t bg = blockIdx.y, b = bg / G, g = bg % G, Cg = C / G, NG = Cg * L;
+  if (SRC == 0) {
+    if (threadIdx.x == 0) {
+      st[0] = src[bg * 2];
+      st[1] = src[bg * 2 + 1];
+    }
+  } else if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    float mean, rstd;
+    if (SRC == 1) {
+      const int64_t Qg = Cg / 4;
+      gn_combine_wave(src + ((b * (C / 4) + g * Qg) * E) * 3, Qg * E, lane, eps, mean, rstd);
+    } else {  // Chan's combination of gn_partial_kernel's chunks, in gn_final_kernel's order of operations
+      float s = 0.0f;
+      for (int64_t k = lane; k < E; k += 64) {
+        const int64_t n = (NG - k * GN_CHUNK) < GN_CHUNK ? (NG - k * GN_CHUNK) : GN_CHUNK;
+        s += src[(bg * E + k) * 2] * (float)n;
+      }
+      mean = adp_wave_sum(s) / (float)NG;
+      float q = 0.0f;
+      for (int64_t k = lane; k < E; k += 64) {
+        const int64_t n = (NG - k * GN_CHUNK) < GN_CHUNK ? (NG - k * GN_CHUNK) : GN_CHUNK;
+        const float dm = src[(bg * E + k) * 2] - mean;
+        q += src[(bg * E + k) * 2 + 1] + (float)n * dm * dm;
+      }
+      q = adp_wave_sum(q);
+      rstd = 1.0f / sqrtf(q / (float)NG + eps);
+    }
+    if (lane == 0) {
+      st[0] = mean;
+      st[1] = rstd;
+      if (blockIdx.x == 0) {
+        stats[bg * 2] = mean;
+        stats[bg * 2 + 1] = rstd;
+      }
+    }
+  }
+  __syncthreads();
+  const float mean = st[0], rstd = st[1];
+  const float* xs = x + bg * NG;
+  float* as = a + bg * NG;
+  f32x4 v[NV];
+  int64_t e[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    e[j] = (((int64_t)blockIdx.x * NV + j) * 256 + threadIdx.x) * 4;
+    if (e[j] < NG) v[j] = *reinterpret_cast<const f32x4*>(xs + e[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    if (e[j] >= NG) continue;
+    const int64_t c = g * Cg + e[j] / L;  // L % 4 == 0: a quad never straddles two rows
+    const float pa = gamma[c] * rstd, pb = beta[c] - mean * pa;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[j][k] = adp_silu_fast(fmaf(v[j][k], pa, pb));
+    *reinterpret_cast<f32x4*>(as + e[j]) = v[j];
+  }
+}
+
+template <int SRC>
+static int launch_gn_act_slab(const float* x, const float* src, const float* gamma, const float* beta, int64_t B,
+                              int64_t C, int64_t L, int64_t G, int64_t E, float eps, float* stats, float* a, void* stream) {
+  const int64_t NG = (C / G) * L;
+  // 4096 elements per workgroup unless that leaves the chip short of workgroups (the 2-4 MB tensors of the deep layers)
+  if (B * G * adp_cdiv(NG, 4096) >= 1024)
+    ADP_LAUNCH((gn_act_slab_kernel<SRC, 4>), dim3((unsigned)adp_cdiv(NG, 4096), (unsigned)(B * G)), dim3(256), stream, x,
+               src, gamma, beta, C, L, G, E, eps, stats, a);
+  else
+    ADP_LAUNCH((gn_act_slab_kernel<SRC, 1>), dim3((unsigned)adp_cdiv(NG, 1024), (unsigned)(B * G)), dim3(256), stream, x,
+               src, gamma, beta, C, L, G, E, eps, stats, a);
+  return ADP_LAUNCH_OK();
+}
+
 // ---- backward of y = SiLU(GN(x)) ------------------------------------------------------------------------
 // ab[b, c, split, {A,B}] : A = sum ds*xhat, B = sum ds over the split's slice of L, ds = dact * silu'(h)
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* x, const float* dact, const float* stats,
@@ -284,6 +368,132 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* x, const
     if (dres) v += dres[row * L + l];
     dx[row * L + l] = v;
   }
+}
+
+// The same two stages with 16-byte accesses and TPR threads per (row, split) segment (L % 4 == 0, segment length
+// CL % 4 == 0): a segment of the deep layers is 128-256 floats, one float4 per lane of ONE wave (TPR = 32 / 64: no LDS,
+// no workgroup barrier, four segments per workgroup) where the row form spent a 256-thread workgroup with two
+// barrier-synchronised block sums on it; long segments take the whole workgroup (TPR = 256) as before.
+__device__ __forceinline__ float adp_dsilu_fast(float h) {
+  const float sg = adp_rcp(1.0f + __expf(-h));
+  return sg * fmaf(h, 1.0f - sg, 1.0f);
+}
+template <int TPR>
+__device__ __forceinline__ float gn_seg_sum(float v, float* sh) {
+  if (TPR == 256) return adp_block_sum<4>(v, sh);
+#pragma unroll
+  for (int o = 1; o < TPR; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int TPR>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_vec_kernel(const float* x, const float* dact, const float* stats,
+                                                                const float* gamma, const float* beta, int64_t C,
+                                                                int64_t L, int64_t G, int64_t NS, int64_t CL,
+                                                                int64_t nseg, float* ab) {
+  __shared__ float sh[4];
+  const int sl = threadIdx.x / TPR, li = threadIdx.x % TPR;
+  const int64_t seg = (int64_t)blockIdx.x * (256 / TPR) + sl;
+  const bool live = seg < nseg;
+  const int64_t sg = live ? seg : nseg - 1;  // idle tail segments shadow the last one (uniform control flow)
+  const int64_t row = sg / NS, split = sg % NS;
+  const int64_t b = row / C, c = row % C, g = c / (C / G);
+  const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+  const float ga = gamma[c] * rstd, be = beta[c] - mean * ga;  // h = x * ga + be
+  const int64_t lo = split * CL, hi = (lo + CL < L) ? lo + CL : L;
+  const float* xr = x + row * L;
+  const float* dr = dact + row * L;
+  float a = 0.0f, bs = 0.0f;
+  for (int64_t l = lo + 4 * li; l < hi; l += 4 * TPR) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + l);
+    const f32x4 dv = *reinterpret_cast<const f32x4*>(dr + l);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xh = (xv[k] - mean) * rstd;
+      const float ds = dv[k] * adp_dsilu_fast(fmaf(xv[k], ga, be));
+      a = fmaf(ds, xh, a);
+      bs += ds;
+    }
+  }
+  a = gn_seg_sum<TPR>(a, sh);
+  bs = gn_seg_sum<TPR>(bs, sh);
+  if (li == 0 && live) *reinterpret_cast<f32x2*>(ab + (row * NS + split) * 2) = f32x2{a, bs};
+}
+
+template <int TPR>
+__global__ __launch_bounds__(256) void gn_bwd_apply_vec_kernel(const float* x, const float* dact, const float* stats,
+                                                               const float* gamma, const float* beta, const float* ab,
+                                                               const float* dres, int64_t C, int64_t L, int64_t G,
+                                                               int64_t NS, int64_t CL, int64_t nseg, float* dx, int64_t B,
+                                                               float* dgamma, float* dbeta, int accumulate) {
+  __shared__ float sh[4];
+  const int sl = threadIdx.x / TPR, li = threadIdx.x % TPR;
+  const int64_t seg = (int64_t)blockIdx.x * (256 / TPR) + sl;
+  const bool live = seg < nseg;
+  const int64_t sg = live ? seg : nseg - 1;
+  const int64_t row = sg / NS, split = sg % NS;
+  const int64_t b = row / C, c = row % C, Cg = C / G, g = c / Cg;
+  if (dgamma) {  // parameter gradients of this channel: dgamma = sum_{b,s} A, dbeta = sum_{b,s} B (batch 0's segments)
+    const bool mine = (b == 0 && split == 0);
+    float pa = 0.0f, pb = 0.0f;
+    if (TPR == 256 ? mine : true) {  // (sub-wave segments: every lane walks, only batch 0's keep the result)
+      for (int64_t e = li; e < B * NS; e += TPR) {
+        const int64_t bb = e / NS, spx = e % NS;
+        const f32x2 p = *reinterpret_cast<const f32x2*>(ab + ((bb * C + c) * NS + spx) * 2);
+        pa += p[0];
+        pb += p[1];
+      }
+      pa = gn_seg_sum<TPR>(pa, sh);
+      pb = gn_seg_sum<TPR>(pb, sh);
+      if (li == 0 && live && mine) {
+        dgamma[c] = accumulate ? dgamma[c] + pa : pa;
+        dbeta[c] = accumulate ? dbeta[c] + pb : pb;
+      }
+    }
+  }
+  const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+  float sa = 0.0f, sb = 0.0f;
+  for (int64_t e = li; e < Cg * NS; e += TPR) {
+    const int64_t cc = g * Cg + e / NS, spx = e % NS;
+    const float gm = gamma[cc];
+    const f32x2 p = *reinterpret_cast<const f32x2*>(ab + ((b * C + cc) * NS + spx) * 2);
+    sa = fmaf(gm, p[0], sa);
+    sb = fmaf(gm, p[1], sb);
+  }
+  const float inv = 1.0f / ((float)Cg * (float)L);
+  const float m2 = gn_seg_sum<TPR>(sa, sh) * inv;
+  const float m1 = gn_seg_sum<TPR>(sb, sh) * inv;
+  const float gam = gamma[c];
+  const float ga = gam * rstd, be = beta[c] - mean * ga;
+  const int64_t lo = split * CL, hi = (lo + CL < L) ? lo + CL : L;
+  const float* xr = x + row * L;
+  const float* dr = dact + row * L;
+  if (!live) return;
+  for (int64_t l = lo + 4 * li; l < hi; l += 4 * TPR) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + l);
+    const f32x4 dv = *reinterpret_cast<const f32x4*>(dr + l);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xh = (xv[k] - mean) * rstd;
+      const float ds = dv[k] * adp_dsilu_fast(fmaf(xv[k], ga, be));
+      o[k] = rstd * (gam * ds - m1 - xh * m2);
+    }
+    if (dres) {
+      const f32x4 r = *reinterpret_cast<const f32x4*>(dres + row * L + l);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] += r[k];
+    }
+    *reinterpret_cast<f32x4*>(dx + row * L + l) = o;
+  }
+}
+
+// threads per (row, split) segment of the vector form: one float4 per lane up to a wave, the whole workgroup beyond
+static int gn_bwd_tpr(int64_t CL) { return CL <= 64 ? 16 : (CL <= 128 ? 32 : (CL <= 1024 ? 64 : 256)); }
+static bool gn_bwd_vec_ok(const float* x, const float* dact, const float* dres, const float* dx, int64_t L, int64_t CL) {
+  return (L & 3) == 0 && (CL & 3) == 0 &&
+         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dact) | reinterpret_cast<uintptr_t>(dres) |
+           reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
 }
 
 __global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* ab, int64_t B, int64_t C, int64_t NS,
@@ -689,6 +899,8 @@ extern "C" int adp_gn_stats_act(const float* x, int64_t B, int64_t C, int64_t L,
   const int64_t NG = (C / G) * L, nchunks = adp_cdiv(NG, GN_CHUNK);
   if (B * G > 65535 || B * C > 65535) return ADP_ERR_SHAPE;
   ADP_LAUNCH(gn_partial_kernel, dim3((unsigned)nchunks, (unsigned)(B * G)), dim3(256), stream, x, NG, nchunks, ws);
+  if ((L & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(act)) & 15) == 0)
+    return launch_gn_act_slab<2>(x, ws, gamma, beta, B, C, L, G, nchunks, eps, stats, act, stream);
   ADP_LAUNCH(gn_apply_kernel, dim3((unsigned)adp_cdiv(L, 1024), (unsigned)(B * C)), dim3(256), stream, x,
              (const float*)ws, gamma, beta, C, L, G, nchunks, eps, stats, act);
   return ADP_LAUNCH_OK();
@@ -701,7 +913,21 @@ extern "C" int adp_gn_silu_bwd_reduce(const float* x, const float* dact, const f
                                       float* ab, void* stream) {
   if (!x || !dact || !stats || !gamma || !beta || !ab) return ADP_ERR_NULL;
   if (B <= 0 || C <= 0 || L <= 0 || G <= 0 || C % G || NS < 1 || NS > 65535 || B * C > 65535) return ADP_ERR_SHAPE;
-  const int64_t CL = adp_cdiv(L, NS);
+  int64_t CL = adp_cdiv(L, NS);
+  if ((L & 3) == 0) CL = (CL + 3) & ~(int64_t)3;  // (both stages derive the same segment length from L and NS)
+  if (gn_bwd_vec_ok(x, dact, nullptr, nullptr, L, CL) && (reinterpret_cast<uintptr_t>(ab) & 7) == 0) {
+    const int64_t nseg = B * C * NS;
+    const int tpr = gn_bwd_tpr(CL);
+    const dim3 grid((unsigned)adp_cdiv(nseg, 256 / tpr));
+#define ADP_GN_RED(T) \
+  ADP_LAUNCH((gn_bwd_reduce_vec_kernel<T>), grid, dim3(256), stream, x, dact, stats, gamma, beta, C, L, G, NS, CL, nseg, ab)
+    if (tpr == 16) ADP_GN_RED(16);
+    else if (tpr == 32) ADP_GN_RED(32);
+    else if (tpr == 64) ADP_GN_RED(64);
+    else ADP_GN_RED(256);
+#undef ADP_GN_RED
+    return ADP_LAUNCH_OK();
+  }
   ADP_LAUNCH(gn_bwd_reduce_kernel, dim3((unsigned)NS, (unsigned)(B * C)), dim3(256), stream, x, dact, stats, gamma,
              beta, C, L, G, NS, CL, ab);
   return ADP_LAUNCH_OK();
@@ -713,7 +939,22 @@ extern "C" int adp_gn_silu_bwd_apply(const float* x, const float* dact, const fl
                                      int64_t accumulate, void* stream) {
   if (!x || !dact || !stats || !gamma || !beta || !ab || !dx || (!dgamma != !dbeta)) return ADP_ERR_NULL;
   if (B <= 0 || C <= 0 || L <= 0 || G <= 0 || C % G || NS < 1 || NS > 65535 || B * C > 65535) return ADP_ERR_SHAPE;
-  const int64_t CL = adp_cdiv(L, NS);
+  int64_t CL = adp_cdiv(L, NS);
+  if ((L & 3) == 0) CL = (CL + 3) & ~(int64_t)3;
+  if (gn_bwd_vec_ok(x, dact, dres, dx, L, CL) && (reinterpret_cast<uintptr_t>(ab) & 7) == 0) {
+    const int64_t nseg = B * C * NS;
+    const int tpr = gn_bwd_tpr(CL);
+    const dim3 grid((unsigned)adp_cdiv(nseg, 256 / tpr));
+#define ADP_GN_APP(T)                                                                                                  \
+  ADP_LAUNCH((gn_bwd_apply_vec_kernel<T>), grid, dim3(256), stream, x, dact, stats, gamma, beta, ab, dres, C, L, G, NS, \
+             CL, nseg, dx, B, dgamma, dbeta, (int)accumulate)
+    if (tpr == 16) ADP_GN_APP(16);
+    else if (tpr == 32) ADP_GN_APP(32);
+    else if (tpr == 64) ADP_GN_APP(64);
+    else ADP_GN_APP(256);
+#undef ADP_GN_APP
+    return ADP_LAUNCH_OK();
+  }
   ADP_LAUNCH(gn_bwd_apply_kernel, dim3((unsigned)NS, (unsigned)(B * C)), dim3(256), stream, x, dact, stats, gamma,
              beta, ab, dres, C, L, G, NS, CL, dx, B, dgamma, dbeta, (int)accumulate);
   return ADP_LAUNCH_OK();
@@ -749,6 +990,8 @@ extern "C" int adp_gn_finalize_act(const float* x, const float* part, int64_t B,
                                    float* act, void* stream) {
   if (!x || !part || !gamma || !beta || !stats || !act) return ADP_ERR_NULL;
   if (B <= 0 || C <= 0 || L <= 0 || E <= 0 || G <= 0 || C % G || (C / G) % 4 || B * C > 65535) return ADP_ERR_SHAPE;
+  if ((L & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(act)) & 15) == 0)
+    return launch_gn_act_slab<1>(x, part, gamma, beta, B, C, L, G, E, eps, stats, act, stream);
   ADP_LAUNCH(gn_finalize_act_kernel, dim3((unsigned)adp_cdiv(L, 1024), (unsigned)(B * C)), dim3(256), stream, x, part,
              gamma, beta, C, L, G, E, eps, stats, act);
   return ADP_LAUNCH_OK();
@@ -758,6 +1001,8 @@ extern "C" int adp_gn_act(const float* x, const float* stats, const float* gamma
                           int64_t C, int64_t L, int64_t G, float* act, void* stream) {
   if (!x || !stats || !gamma || !beta || !act) return ADP_ERR_NULL;
   if (B <= 0 || C <= 0 || L <= 0 || G <= 0 || C % G || B * C > 65535) return ADP_ERR_SHAPE;
+  if ((L & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(act)) & 15) == 0)
+    return launch_gn_act_slab<0>(x, stats, gamma, beta, B, C, L, G, 0, 0.0f, (float*)nullptr, act, stream);
   ADP_LAUNCH(gn_act_kernel, dim3((unsigned)adp_cdiv(L, 1024), (unsigned)(B * C)), dim3(256), stream, x, stats, gamma,
              beta, C, L, G, act);
   return ADP_LAUNCH_OK();
