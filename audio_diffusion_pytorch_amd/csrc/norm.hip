@@ -5,6 +5,7 @@
 //   * SkipModulate backward                                              (components.py:99)
 // Layout [B, C, L], L fastest: lanes always run along L so every global access is a coalesced 256-B wave load.
 // All cross-workgroup reductions are two-stage through a caller-provided workspace (deterministic, no atomics).
+#include <stdlib.h>
 #include "adp_rt.h"
 #include "adp.h"
 
@@ -662,6 +663,233 @@ __global__ __launch_bounds__(NT) void chan_ln_bwd_kernel(const float* x, const f
   }
 }
 
+// ---- the same two kernels with 16-byte accesses (L % 4 == 0, 16-byte aligned tensors) ------------------------------------
+// A lane holds FOUR consecutive positions of a channel row (one float4), LPR lanes cover a row segment of TL = 4 * LPR
+// positions, the remaining lane bits and the waves stride the channels (RPP = NT / LPR rows per pass, VPT passes, all in
+// registers).  For the same tile width a wave instruction touches a quarter of the cache lines per byte of the 4-byte
+// form, and the deep layers (1024 channels x 128-256 positions: 2-4 MB tensors) get 16- or 32-byte row segments
+// from ONE lane each instead of 4 lanes x 4 bytes.  Reductions: per position over channels = xor-shuffles across the
+// row groups of a wave + one LDS round across waves; per channel over the tile's positions (backward) = the lane's four
+// components + xor-shuffles across the LPR lanes of the segment.
+template <int LPR, int NT, int VPT>
+__global__ __launch_bounds__(NT) void chan_lnv_fwd_kernel(const float* x, const float* ss, int64_t bstride, int C, int L,
+                                                          float eps, float* y, float* stats, const float* gam,
+                                                          const float* bet, const float* gam2, const float* bet2,
+                                                          float* y2) {
+  constexpr int TL = 4 * LPR, RPP = NT / LPR, NW = NT / 64;
+  __shared__ float red[NW][TL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = tid % LPR, rg = tid / LPR;
+  const int l0 = blockIdx.x * TL + 4 * lr, b = blockIdx.y;
+  const bool valid = l0 < L;  // L % 4 == 0: a quad is inside or outside
+  const float* xb = x + (int64_t)b * C * L + l0;
+  f32x4 v[VPT];
+  float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = rg + i * RPP;
+    if (valid && c < C) {
+      v[i] = *reinterpret_cast<const f32x4*>(xb + (int64_t)c * L);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[i][k] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] += v[i][k];
+  }
+  auto over_channels = [&](float (&t)[4]) {  // sum over every row group of the workgroup; result in all threads
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] += __shfl_xor(t[k], o, 64);
+    if (NW > 1) {
+      __syncthreads();
+      if (lane < LPR)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[wave][4 * lr + k] = t[k];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float a = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) a += red[w][4 * lr + k];
+        t[k] = a;
+      }
+    }
+  };
+  over_channels(s);
+  float mean[4], q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) mean[k] = s[k] / (float)C;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const bool in = rg + i * RPP < C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float dlt = in ? v[i][k] - mean[k] : 0.0f;
+      q[k] = fmaf(dlt, dlt, q[k]);
+    }
+  }
+  over_channels(q);
+  float rstd[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rstd[k] = 1.0f / sqrtf(q[k] / (float)C + eps);
+  if (tid < LPR && valid) {
+    float* sp = stats + ((int64_t)b * L + l0) * 2;
+    *reinterpret_cast<f32x4*>(sp) = f32x4{mean[0], rstd[0], mean[1], rstd[1]};
+    *reinterpret_cast<f32x4*>(sp + 4) = f32x4{mean[2], rstd[2], mean[3], rstd[3]};
+  }
+  if (y == nullptr || !valid) return;
+  float* yb = y + (int64_t)b * C * L + l0;
+  float* yb2 = y2 ? y2 + (int64_t)b * C * L + l0 : nullptr;
+  const float* sb = ss ? ss + b * bstride : nullptr;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = rg + i * RPP;
+    if (c >= C) continue;
+    const float mul = gam ? gam[c] : 1.0f + sb[c], add = gam ? bet[c] : sb[C + c];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = fmaf((v[i][k] - mean[k]) * rstd[k], mul, add);
+    *reinterpret_cast<f32x4*>(yb + (int64_t)c * L) = o;
+    if (yb2) {
+      const float m2 = gam2[c], a2 = bet2[c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = fmaf((v[i][k] - mean[k]) * rstd[k], m2, a2);
+      *reinterpret_cast<f32x4*>(yb2 + (int64_t)c * L) = o;
+    }
+  }
+}
+
+template <int LPR, int NT, int VPT>
+__global__ __launch_bounds__(NT) void chan_lnv_bwd_kernel(const float* x, const float* dy, const float* ss,
+                                                          int64_t bstride, const float* gamma, const float* stats,
+                                                          const float* dres, int C, int L, int NTL, float* dx, float* ws) {
+  constexpr int TL = 4 * LPR, RPP = NT / LPR, NW = NT / 64;
+  __shared__ float red[2][NW][TL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = tid % LPR, rg = tid / LPR;
+  const int tile = blockIdx.x, l0 = tile * TL + 4 * lr, b = blockIdx.y;
+  const bool valid = l0 < L;
+  const int64_t boff = (int64_t)b * C * L + l0;
+  float mean[4] = {0.0f, 0.0f, 0.0f, 0.0f}, rstd[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (valid) {
+    const float* sp = stats + ((int64_t)b * L + l0) * 2;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(sp), c4 = *reinterpret_cast<const f32x4*>(sp + 4);
+    mean[0] = a[0], rstd[0] = a[1], mean[1] = a[2], rstd[1] = a[3];
+    mean[2] = c4[0], rstd[2] = c4[1], mean[3] = c4[2], rstd[3] = c4[3];
+  }
+  f32x4 xh[VPT], g[VPT];
+  float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = rg + i * RPP;
+    const bool ok = valid && c < C;
+    f32x4 d;
+    if (ok) {
+      d = *reinterpret_cast<const f32x4*>(dy + boff + (int64_t)c * L);
+      xh[i] = *reinterpret_cast<const f32x4*>(x + boff + (int64_t)c * L);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] = xh[i][k] = 0.0f;
+    }
+    const float mul = (c < C) ? (gamma ? gamma[c] : 1.0f + ss[b * bstride + c]) : 0.0f;
+    float pa = 0.0f, pb = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      xh[i][k] = ok ? (xh[i][k] - mean[k]) * rstd[k] : 0.0f;
+      g[i][k] = d[k] * mul;
+      s1[k] += g[i][k];
+      s2[k] = fmaf(g[i][k], xh[i][k], s2[k]);
+      pa = fmaf(d[k], xh[i][k], pa);
+      pb += d[k];
+    }
+    // per-channel sums over the tile's positions: the LPR lanes of this row segment
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) {
+      pa += __shfl_xor(pa, o, 64);
+      pb += __shfl_xor(pb, o, 64);
+    }
+    if (lr == 0 && c < C) {
+      ws[(((int64_t)b * 2 + 0) * NTL + tile) * C + c] = pa;
+      ws[(((int64_t)b * 2 + 1) * NTL + tile) * C + c] = pb;
+    }
+  }
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s1[k] += __shfl_xor(s1[k], o, 64);
+      s2[k] += __shfl_xor(s2[k], o, 64);
+    }
+  float m1[4], m2[4];
+  if (NW > 1) {
+    if (lane < LPR)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        red[0][wave][4 * lr + k] = s1[k];
+        red[1][wave][4 * lr + k] = s2[k];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float a = 0.0f, c2 = 0.0f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        a += red[0][w][4 * lr + k];
+        c2 += red[1][w][4 * lr + k];
+      }
+      m1[k] = a / (float)C;
+      m2[k] = c2 / (float)C;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      m1[k] = s1[k] / (float)C;
+      m2[k] = s2[k] / (float)C;
+    }
+  }
+  if (!valid) return;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = rg + i * RPP;
+    if (c >= C) continue;
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = rstd[k] * (g[i][k] - m1[k] - xh[i][k] * m2[k]);
+    if (dres) {
+      const f32x4 r = *reinterpret_cast<const f32x4*>(dres + boff + (int64_t)c * L);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] += r[k];
+    }
+    *reinterpret_cast<f32x4*>(dx + boff + (int64_t)c * L) = o;
+  }
+}
+
+// vector-form tile by channel count: (lanes per row segment, threads, passes); RPP * VPT >= C
+struct LnvCfg {
+  int lpr, nt, vpt;
+};
+static LnvCfg lnv_cfg(int64_t C, int64_t B, int64_t L) {
+  if (C <= 8) return {64, 256, 2};     // 1 KB row segments, 4 rows per pass
+  if (C <= 32) return {32, 256, 4};    // 512 B, 8 rows per pass
+  if (C <= 64) return {16, 256, 4};    // 256 B, 16 rows per pass
+  if (C <= 128) return {8, 256, 4};    // 128 B, 32 rows per pass
+  if (C <= 256) return {8, 1024, 2};   // 128 B, 128 rows per pass
+  // 512 / 1024 channels, 1024-thread workgroups: few positions (depth 8 at batch 4: 512), so the segment narrows until
+  // enough workgroups exist; ADP_LN_LPR pins it (kernel work)
+  static const int pin = getenv("ADP_LN_LPR") ? atoi(getenv("ADP_LN_LPR")) : 0;
+  int lpr = 4;
+  while (lpr > 1 && B * adp_cdiv(L, 4 * lpr) < 32) lpr >>= 1;  // (batch 4: 16 positions at depths 5-8 measured best)
+  if (pin == 1 || pin == 2 || pin == 4) lpr = pin;
+  if (C <= 512) return {lpr == 1 ? 2 : lpr, 1024, lpr == 4 ? 2 : 1};
+  return {lpr, 1024, lpr};  // RPP = 1024 / lpr rows per pass -> lpr passes cover 1024 channels
+}
+static bool lnv_ok(int64_t L, const void* a, const void* b, const void* c, const void* d, const void* e) {
+  return (L & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+                           reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(e)) & 15) == 0;
+}
+
 // tile shape by channel count (registers: VPT = ceil(C / CG) values per thread) and by how many tiles there are
 struct LnCfg {
   int tl, nt;
@@ -681,6 +909,19 @@ constexpr int64_t LN_CMAX = 1024;
 int launch_ln_fwd(const float* x, const float* ss, int64_t bstride, int64_t B, int64_t C, int64_t L, float eps, float* y,
                   float* stats, void* stream, const float* gam = nullptr, const float* bet = nullptr,
                   const float* gam2 = nullptr, const float* bet2 = nullptr, float* y2 = nullptr) {
+  if (lnv_ok(L, x, y, y2, stats, nullptr)) {
+    const LnvCfg v = lnv_cfg(C, B, L);
+    dim3 vgrid((unsigned)adp_cdiv(L, 4 * v.lpr), (unsigned)B);
+#define ADP_LNV_FWD(LPR, NT, VPT)                                                                                     \
+  if (v.lpr == LPR && v.nt == NT && v.vpt == VPT) {                                                                   \
+    ADP_LAUNCH((chan_lnv_fwd_kernel<LPR, NT, VPT>), vgrid, dim3(NT), stream, x, ss, bstride, (int)C, (int)L, eps, y, \
+               stats, gam, bet, gam2, bet2, y2);                                                                      \
+    return ADP_LAUNCH_OK();                                                                                           \
+  }
+    ADP_LNV_FWD(64, 256, 2) ADP_LNV_FWD(32, 256, 4) ADP_LNV_FWD(16, 256, 4) ADP_LNV_FWD(8, 256, 4) ADP_LNV_FWD(8, 1024, 2)
+    ADP_LNV_FWD(4, 1024, 2) ADP_LNV_FWD(2, 1024, 1) ADP_LNV_FWD(4, 1024, 4) ADP_LNV_FWD(2, 1024, 2) ADP_LNV_FWD(1, 1024, 1)
+#undef ADP_LNV_FWD
+  }
   const LnCfg k = ln_cfg(C, B, L);
   dim3 grid((unsigned)adp_cdiv(L, k.tl), (unsigned)B);
   if (k.tl == 8)
@@ -702,9 +943,24 @@ int launch_ln_fwd(const float* x, const float* ss, int64_t bstride, int64_t B, i
   return ADP_LAUNCH_OK();
 }
 
+// returns the number of position tiles the launch wrote partial channel sums for (ws [b][2][tile][c])
 int launch_ln_bwd(const float* x, const float* dy, const float* ss, int64_t bstride, const float* gamma,
                   const float* stats, const float* dres, int64_t B, int64_t C, int64_t L, float* dx, float* ws,
                   void* stream) {
+  if (lnv_ok(L, x, dy, dres, dx, stats)) {
+    const LnvCfg v = lnv_cfg(C, B, L);
+    const int VNTL = (int)adp_cdiv(L, 4 * v.lpr);
+    dim3 vgrid((unsigned)VNTL, (unsigned)B);
+#define ADP_LNV_BWD(LPR, NT, VPT)                                                                                      \
+  if (v.lpr == LPR && v.nt == NT && v.vpt == VPT) {                                                                    \
+    ADP_LAUNCH((chan_lnv_bwd_kernel<LPR, NT, VPT>), vgrid, dim3(NT), stream, x, dy, ss, bstride, gamma, stats, dres,  \
+               (int)C, (int)L, VNTL, dx, ws);                                                                          \
+    return VNTL;                                                                                                       \
+  }
+    ADP_LNV_BWD(64, 256, 2) ADP_LNV_BWD(32, 256, 4) ADP_LNV_BWD(16, 256, 4) ADP_LNV_BWD(8, 256, 4) ADP_LNV_BWD(8, 1024, 2)
+    ADP_LNV_BWD(4, 1024, 2) ADP_LNV_BWD(2, 1024, 1) ADP_LNV_BWD(4, 1024, 4) ADP_LNV_BWD(2, 1024, 2) ADP_LNV_BWD(1, 1024, 1)
+#undef ADP_LNV_BWD
+  }
   const LnCfg k = ln_cfg(C, B, L);
   const int NTL = (int)adp_cdiv(L, k.tl);
   dim3 grid((unsigned)NTL, (unsigned)B);
@@ -732,7 +988,7 @@ int launch_ln_bwd(const float* x, const float* dy, const float* ss, int64_t bstr
   else
     ADP_LAUNCH((chan_ln_bwd_kernel<16, 1024, 16>), grid, dim3(1024), stream, x, dy, ss, bstride, gamma, stats, dres,
                (int)C, (int)L, NTL, dx, ws);
-  return ADP_LAUNCH_OK();
+  return NTL;
 }
 
 // out[b*bstride + j] (or out[j] summed over b) = sum_t ws[(b*W + j)*NT + t]; one wave per row
@@ -1028,7 +1284,9 @@ extern "C" int adp_ln_affine_fwd(const float* x, int64_t B, int64_t C, int64_t L
 
 extern "C" int64_t adp_chan_ln_bwd_ws_bytes(int64_t B, int64_t C, int64_t L) {
   if (B <= 0 || C <= 0 || L <= 0) return ADP_ERR_SHAPE;
-  return B * 2 * C * adp_cdiv(L, ln_cfg(C, B, L).tl) * (int64_t)sizeof(float);
+  // (room for whichever form the launch takes: the 16-byte form needs aligned tensors, which are not known here)
+  const int64_t t_old = adp_cdiv(L, ln_cfg(C, B, L).tl), t_vec = adp_cdiv(L, 4 * lnv_cfg(C, B, L).lpr);
+  return B * 2 * C * (t_old > t_vec ? t_old : t_vec) * (int64_t)sizeof(float);
 }
 
 extern "C" int adp_modulation_bwd(const float* x, const float* dy, const float* ss, int64_t ss_bstride,
@@ -1037,8 +1295,8 @@ extern "C" int adp_modulation_bwd(const float* x, const float* dy, const float* 
   if (!x || !dy || !ss || !stats || !dx || !dss || !ws) return ADP_ERR_NULL;
   if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
   if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
-  const int64_t NT = adp_cdiv(L, ln_cfg(C, B, L).tl);
-  launch_ln_bwd(x, dy, ss, ss_bstride, (const float*)nullptr, stats, (const float*)nullptr, B, C, L, dx, ws, stream);
+  const int64_t NT = launch_ln_bwd(x, dy, ss, ss_bstride, (const float*)nullptr, stats, (const float*)nullptr, B, C, L, dx,
+                                   ws, stream);
   launch_reduce_tiles((const float*)ws, B, C, NT, dss_bstride, 0, 0, dss, stream);
   return ADP_LAUNCH_OK();
 }
@@ -1049,8 +1307,7 @@ extern "C" int adp_ln_bwd(const float* x, const float* dxn, const float* stats, 
   if (!x || !dxn || !stats || !gamma || !dx || !dgamma_dbeta || !ws) return ADP_ERR_NULL;
   if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
   if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
-  const int64_t NT = adp_cdiv(L, ln_cfg(C, B, L).tl);
-  launch_ln_bwd(x, dxn, (const float*)nullptr, (int64_t)0, gamma, stats, dres, B, C, L, dx, ws, stream);
+  const int64_t NT = launch_ln_bwd(x, dxn, (const float*)nullptr, (int64_t)0, gamma, stats, dres, B, C, L, dx, ws, stream);
   // dgamma_dbeta = [dgamma (C) | dbeta (C)]
   launch_reduce_tiles((const float*)ws, B, C, NT, (int64_t)0, 1, (int)accumulate, dgamma_dbeta, stream);
   return ADP_LAUNCH_OK();
