@@ -20,7 +20,9 @@ bool mm_use64(const adp_conv_desc& d) {
   // first-load latency / K-group exchange / epilogue with the other's MFMAs (microbench at batch 4, 32- vs 64-row
   // tiles: C=256 42.7 vs 46.7 us, C=512 L=1024 68.9 vs 74.2, dgrad C=1024 L=256 61.1 vs 63.4); with the GroupNorm+SiLU
   // prologue the doubled activation recompute loses instead
-  if (d.prologue == 0 && d.KT == 3 && d.stride == 1 && d.up == 1 && d.R >= 256 &&
+  // (direct form only: the Winograd variant's blocks stage the same bytes for two thirds of the MFMAs, and the 64-row
+  // block -- half the weight staging per flop -- is the faster one there: 14.37 -> 14.31 ms per step interleaved)
+  if (!adp_conv_mm_winograd(d) && d.prologue == 0 && d.KT == 3 && d.stride == 1 && d.up == 1 && d.R >= 256 &&
       (d.M / 32) * adp_cdiv(d.N, 64) * d.B >= 512)
     return false;
   return (d.M / 64) * adp_cdiv(d.N, 64) * d.B >= 200;
