@@ -28,7 +28,12 @@ def attention_item(run, p, x: Tensor, context: Optional[Tensor]) -> Tensor:
     wq = p.to_q.weight.view(mid, C, 1)
     if is_cross:
         assert context.shape[0] == B, "embedding batch mismatch"
-        ctx = context.transpose(1, 2).contiguous()  # [B, E, m] channel-major (layout change only)
+        # [B, E, m] channel-major (layout change only), made ONCE per forward: every cross-attention item of the
+        # U-Net reads the same embedding (32 items in BASELINE config 4)
+        cached = getattr(run, "_ctx_cm", None)
+        if cached is None or cached[0] is not context:
+            cached = run._ctx_cm = (context, context.transpose(1, 2).contiguous())
+        ctx = cached[1]
         xn, _, st_x = ops.ln_affine_fwd(x, p.norm.weight, p.norm.bias)
         cn, _, st_c = ops.ln_affine_fwd(ctx, p.norm_context.weight, p.norm_context.bias)
     else:  # self attention: one pass over x yields both normalisations (same statistics, two affine maps)
