@@ -238,6 +238,27 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ni][r] = 0.0f;
 
+  // WN epilogue operands of the rows this wave finishes (accumulator registers kg * RPW ..): fetched NOW, so that their
+  // global-memory latency lies under the K loop instead of on the launch's tail (every block of a launch reaches its
+  // epilogue at the same time: elimination build, depth 7 forward with residual: 8.8 of 55 us)
+  constexpr int RPW_ = 16 / NKG;
+  f32x2 pre_res[WN ? RPW_ : 1];
+  float pre_bias[WN ? RPW_ : 1], pre_scale[WN ? RPW_ : 1];
+  if constexpr (WN) {
+    const int n = n0 + 2 * l31;
+#pragma unroll
+    for (int rr = 0; rr < RPW_; ++rr) {
+      const int r = kg * RPW_ + rr;
+      const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const bool ok = (m < M) && (n < N);
+      const int mc = m < M ? m : M - 1;
+      pre_bias[rr] = d.bias ? d.bias[mc] : 0.0f;
+      pre_scale[rr] = d.e_scale ? d.e_scale[b * (d.e_bstride ? d.e_bstride : M) + mc] : 1.0f;
+      pre_res[rr] = f32x2{0.0f, 0.0f};
+      if (d.res && ok && KS == 1 && d.store == 0) pre_res[rr] = *reinterpret_cast<const f32x2*>(d.res + ((int64_t)b * M + m) * N + n);
+    }
+  }
+
   // lane-constant fragment offsets
   const int xfrag = WN ? 4 * hi * XSP + 2 * l31 + 2                   // 8-byte pieces at +0, +2, +4: x[2j-2 .. 2j+3]
                        : 4 * hi * XSP + l31 * S + 4 - pad;            // + ni*32*S + (ci + c) * XSP + t * dil
@@ -268,13 +289,19 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
 #pragma unroll
               for (int t = 0; t < KT; ++t) av[cc * KT + t] = Ab[afrag + (ci + cc) * AS + (KT - 1 - t)];
           }
+          // every fragment read of the K group's four channel pairs is issued before the first MFMA (36 registers): the
+          // LDS latency is paid once per chunk instead of once per channel pair (elimination build: the barrier +
+          // fragment-read + transform skeleton of a depth-7 launch was 16 of 55 us, not overlapped with the MFMAs)
+          f32x2 px[4][3];
 #pragma unroll
           for (int cc = 0; cc < 4; ++cc) {
             const float* xp = Xb + xfrag + (ci + cc) * XSP;
-            const f32x2 p0 = *reinterpret_cast<const f32x2*>(xp);
-            const f32x2 p1 = *reinterpret_cast<const f32x2*>(xp + 2);
-            const f32x2 p2 = *reinterpret_cast<const f32x2*>(xp + 4);
-            const float d0 = p0[1], d1 = p1[0], d2 = p1[1], d3 = p2[0];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) px[cc][q] = *reinterpret_cast<const f32x2*>(xp + 2 * q);
+          }
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const float d0 = px[cc][0][1], d1 = px[cc][1][0], d2 = px[cc][1][1], d3 = px[cc][2][0];
             const float g0 = av[cc * KT], g1 = av[cc * KT + 1], g2 = av[cc * KT + 2];
             const float gs = g0 + g2;
             acc[0] = adp_mfma32(g0, d0 - d2, acc[0]);
@@ -381,22 +408,11 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
         continue;
       }
       const int64_t o = ((int64_t)b * M + m) * N + n;
-      if (d.bias) {
-        const float bv = d.bias[m];
-        v0 += bv;
-        v1 += bv;
-      }
+      v0 += pre_bias[rr];
+      v1 += pre_bias[rr];
       if (d.out_pre) *reinterpret_cast<f32x2*>(d.out_pre + o) = f32x2{v0, v1};
-      if (d.e_scale) {
-        const float sc = d.e_scale[b * ebs + m];
-        v0 *= sc;
-        v1 *= sc;
-      }
-      if (d.res) {
-        const f32x2 rv = *reinterpret_cast<const f32x2*>(d.res + o);
-        v0 += rv[0];
-        v1 += rv[1];
-      }
+      v0 = fmaf(v0, pre_scale[rr], pre_res[rr][0]);
+      v1 = fmaf(v1, pre_scale[rr], pre_res[rr][1]);
       *reinterpret_cast<f32x2*>(d.out + o) = f32x2{v0, v1};
       vfin[0][rr] = v0;
       vfin[1][rr] = v1;
