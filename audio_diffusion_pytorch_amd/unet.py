@@ -317,7 +317,8 @@ def _grad_buffer(shape, device) -> Tensor:
 
 
 # channel count from which SiLU(GroupNorm(x)) is materialised instead of recomputed in the conv loaders
-ACT_MATERIALIZE_MIN_C = int(os.environ.get("ADP_ACT_MATERIALIZE_MIN_C", "512"))
+# (round 3, with the Winograd variants: 128 -> 14.14, 256 -> 14.15, 512 -> 14.20, 64 -> 14.21, 1024 -> 14.37 ms per step)
+ACT_MATERIALIZE_MIN_C = int(os.environ.get("ADP_ACT_MATERIALIZE_MIN_C", "128"))
 
 
 class _Run:
@@ -458,7 +459,7 @@ class _Run:
         return y
 
     def resnet_wide(self, p, x: Tensor) -> Tensor:
-        """ResnetBlock of the wide layers (C >= 512): same arithmetic, but SiLU(GroupNorm(.)) is materialised once by
+        """ResnetBlock of the wide layers (C >= ACT_MATERIALIZE_MIN_C): same arithmetic, but SiLU(GroupNorm(.)) is materialised once by
         the statistics' second stage instead of being recomputed by each of the 8-16 conv / weight-gradient
         workgroups that stage a tile of it (the tensors are 2-8 MB here; see gn_apply_kernel in csrc/norm.hip)."""
         G = self.net.groups

@@ -341,6 +341,8 @@ def main():
                          "0 = weak scaling with --batch per GPU (the default the driver runs)")
     ap.add_argument("--graph", type=int, default=-1, help="1: replay the step from a hipGraph, 0: eager; "
                                                           "default: graph on 1 GPU, eager with RCCL")
+    ap.add_argument("--dp-overlap", action="store_true",
+                    help="N > 1: also report dp_overlap = {step, step without all-reduce, all-reduce alone, hidden_frac}")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch-1 / sampler / attention legs")
@@ -436,8 +438,9 @@ def main():
                    "collective_world_size": (dist.get_world_size() if world > 1 else 1),
                    "optimizer": "none (the metric is fwd+bwd; gradients for all 176M parameters are produced)"},
     }
-    if world > 1 and not args.no_extras:
+    if world > 1 and args.dp_overlap:
         # outside the timed region, every rank in lockstep: how much of the gradient all-reduce hides under backward
+        # (opt-in: three more untimed phases with collectives -- kept out of the default multi-GPU run)
         try:
             def dp_step():
                 zero()

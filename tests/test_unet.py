@@ -73,6 +73,26 @@ def test_unet_forward_backward_tiny(dev, B, L):
     compare_grads(net, oracle)
 
 
+def test_unet_materialised_activation_path(dev, monkeypatch):
+    """ResnetBlocks at and above ACT_MATERIALIZE_MIN_C channels (default 128: depths 3-8 of the README model) write
+    SiLU(GroupNorm(x)) once (from the producing conv's partial statistics where they nest into the groups, from a pass
+    over the tensor otherwise) and feed plain convs / weight gradients; the threshold is lowered here so that the tiny
+    CPU-sized model takes that path at every depth."""
+    from audio_diffusion_pytorch_amd import unet
+    monkeypatch.setattr(unet, "ACT_MATERIALIZE_MIN_C", 8)
+    cfg = dict(in_channels=2, channels=[8, 32, 64], factors=[1, 4, 2], items=[1, 2, 1], modulation_features=64)
+    oracle, net = build_pair(cfg, dev)
+    g = torch.Generator().manual_seed(3)
+    x, t = torch.randn(2, 2, 512, generator=g), torch.tensor([0.2, 0.9])
+    y_ref = oracle(x, t)
+    y = net(x.to(dev), t.to(dev))
+    assert rel_err(y, y_ref) < TOL
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    y.backward(gy.to(dev))
+    compare_grads(net, oracle)
+
+
 def test_unet_inference_matches_training_forward(dev):
     oracle, net = build_pair(TINY, dev)
     x = torch.randn(1, 2, 128)
