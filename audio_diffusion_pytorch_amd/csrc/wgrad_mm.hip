@@ -23,6 +23,14 @@
 
 namespace {
 
+struct __attribute__((packed, aligned(4))) adp_f32x3 {  // 12-byte global access (global_store_dwordx3)
+  float a, b, c;
+};
+template <int K>
+struct __attribute__((packed, aligned(4))) adp_taps {  // K adjacent taps of one (m, r) pair at a 4-byte aligned address
+  float v[K];
+};
+
 constexpr int WG_BKN = 64;  // positions per staged chunk
 
 // S: conv stride (1, or kernel = stride = 2 / 4: DownsampleItem, no halo, lane reads 4*S consecutive floats);
@@ -324,14 +332,47 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
 
   if (kg == 0) {
     float* base = direct ? d.dw : d.ws + (int64_t)split * cnt;
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
+    const bool accum = direct && d.accumulate;
+    if constexpr (KT == 3) {
+      // the three taps of an (m, r) pair are adjacent in dw[M][R][3]: ONE 12-byte store per accumulator row -- the 32
+      // lanes of a half-wave then write 384 contiguous bytes (the per-tap 4-byte form scattered them over three
+      // instructions at a 12-byte stride: every cache line written three times, partially)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi, rr = r0 + wr0 + l31;
-        float* o = base + ((int64_t)m * R + rr) * KT + t;
-        *o = (direct && d.accumulate) ? *o + acc[t][r] : acc[t][r];
+        adp_f32x3* o = reinterpret_cast<adp_f32x3*>(base + ((int64_t)m * R + rr) * 3);
+        adp_f32x3 v{acc[0][r], acc[1][r], acc[2][r]};
+        if (accum) {
+          const adp_f32x3 old = *o;
+          v.a += old.a, v.b += old.b, v.c += old.c;
+        }
+        *o = v;
       }
+    } else if constexpr (KT == 2 || KT == 4) {  // DownsampleItem (kernel = stride): 8- / 16-byte tap groups
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi, rr = r0 + wr0 + l31;
+        adp_taps<KT>* o = reinterpret_cast<adp_taps<KT>*>(base + ((int64_t)m * R + rr) * KT);
+        adp_taps<KT> v;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) v.v[t] = acc[t][r];
+        if (accum) {
+          const adp_taps<KT> old = *o;
+#pragma unroll
+          for (int t = 0; t < KT; ++t) v.v[t] += old.v[t];
+        }
+        *o = v;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi, rr = r0 + wr0 + l31;
+          float* o = base + ((int64_t)m * R + rr) * KT + t;
+          *o = accum ? *o + acc[t][r] : acc[t][r];
+        }
+    }
   }
 }
 

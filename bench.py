@@ -185,7 +185,11 @@ def roofline_leg(model, x, top: int = 14):
     if hb["launches"]:
         hb = {"launches": max(1, hb["launches"] // NREP), "ms": hb["ms"] / NREP, "flops": 0, "bytes": hb["bytes"] // NREP}
         hbm = entry(" | ".join(sorted(names)), hb)
-        hbm["traffic"] = None
+        # HBM-side bytes per launch of each kernel in the group, from the stored PMC passes (the depth-0 and depth-1
+        # launches move the same algorithmic bytes; NB the counters include Infinity-Cache hits)
+        per = {n: pmc[n]["hbm_bytes_per_launch"] for n in sorted(names) if n in pmc}
+        hbm["traffic"] = per or None
+        hbm["traffic_source"] = "stored rocprofv3 PMC pass (profiles/pmc_traffic.json), per kernel instantiation" if per else None
         hbm["what"] = "forward ConvBlock convs (GroupNorm+SiLU prologue, k=3) of depths 0-1: A_in + A_out (+A_res) bytes"
     table = {}
     for k, a in order[:top]:
