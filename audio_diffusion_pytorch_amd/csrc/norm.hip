@@ -877,11 +877,9 @@ static LnvCfg lnv_cfg(int64_t C, int64_t B, int64_t L) {
   if (C <= 128) return {8, 256, 4};    // 128 B, 32 rows per pass
   if (C <= 256) return {8, 1024, 2};   // 128 B, 128 rows per pass
   // 512 / 1024 channels, 1024-thread workgroups: few positions (depth 8 at batch 4: 512), so the segment narrows until
-  // enough workgroups exist; ADP_LN_LPR pins it (kernel work)
-  static const int pin = getenv("ADP_LN_LPR") ? atoi(getenv("ADP_LN_LPR")) : 0;
+  // enough workgroups exist (measured at batch 4, step time: 16 positions 14.38 ms, 8 positions 14.42, 4 positions 14.53)
   int lpr = 4;
   while (lpr > 1 && B * adp_cdiv(L, 4 * lpr) < 32) lpr >>= 1;  // (batch 4: 16 positions at depths 5-8 measured best)
-  if (pin == 1 || pin == 2 || pin == 4) lpr = pin;
   if (C <= 512) return {lpr == 1 ? 2 : lpr, 1024, lpr == 4 ? 2 : 1};
   return {lpr, 1024, lpr};  // RPP = 1024 / lpr rows per pass -> lpr passes cover 1024 channels
 }
