@@ -137,6 +137,8 @@ int64_t adp_conv_mm_ksplit(const adp_conv_desc& d) {
   const int64_t blocks = (d.M / bm) * adp_cdiv(d.N, 64) * d.B;
   const int64_t nchunks = d.R / (d.stride == 4 ? 16 : MM_BKT);
   int64_t ks = 1;
+  // (the 200-workgroup target re-measured in round 3 with the Winograd variants, batch-1 step / sampler step in ms:
+  //  130-200 -> 7.34 / 2.47, 300-400 -> 7.68 / 2.75, 520 -> 7.97 / 2.93, 100 -> 7.85 / 2.68, no split -> 8.16 / 2.82)
   while (ks < 8 && blocks * ks < 200 && nchunks / (ks * 2) >= 4) ks *= 2;
   // the kernel gives slice i the chunks [i * ceil(n / ks), ...): every slice must own at least one (n = 33, ks = 8 would
   // leave the last two slices empty -- they would launch, restage a ghost chunk and park an all-zero partial tile)
