@@ -9,6 +9,7 @@ int adp_conv_mm(const adp_conv_desc& d, void* stream);
 int64_t adp_conv_mm_tile(const adp_conv_desc& d);  // NKG * 1000000 + BM * 1000 + BN
 int64_t adp_conv_mm_ksplit(const adp_conv_desc& d);  // cross-workgroup K split the dispatcher picks (1 = none)
 bool adp_conv_mm_winograd(const adp_conv_desc& d);   // this conv runs conv_mm's Winograd F(2,3) variant (WN)
+int adp_conv_mm_nsp(const adp_conv_desc& d);         // 64-position tiles per block of that variant (1, 2 or 4)
 bool adp_winograd_enabled();                         // ADP_CONV_WINO switch (shared with the weight gradients)
 
 int adp_conv_splitk_reduce(const adp_conv_desc& d, int64_t ks, void* stream);  // sum of d.ws partial tiles + epilogue

@@ -14,6 +14,13 @@ constexpr int MM_BKT = 32;        // channels per staged chunk (16 for the strid
 constexpr int MM_PRO_RMAX = 1024; // channels whose GroupNorm constants fit the LDS table
 
 // 64 x 64 block tiles (8 MMA waves + 4 loaders) unless that leaves most of the 256 CUs without a block
+// workgroups a launch should have before the larger tile is chosen (ADP_MM_MIN_BLOCKS: tests reach the large-tile
+// variants with small problems through it)
+static int64_t mm_min_blocks() {
+  const char* e = getenv("ADP_MM_MIN_BLOCKS");
+  return e ? atoll(e) : 200;
+}
+
 bool mm_use64(const adp_conv_desc& d) {
   if (d.M % 64 != 0) return false;
   // plain (no prologue) kernel-3 convs of the wide layers: two co-resident 32-row blocks per CU overlap one block's
@@ -25,7 +32,7 @@ bool mm_use64(const adp_conv_desc& d) {
   if (!adp_conv_mm_winograd(d) && d.prologue == 0 && d.KT == 3 && d.stride == 1 && d.up == 1 && d.R >= 256 &&
       (d.M / 32) * adp_cdiv(d.N, 64) * d.B >= 512)
     return false;
-  return (d.M / 64) * adp_cdiv(d.N, 64) * d.B >= 200;
+  return (d.M / 64) * adp_cdiv(d.N, 64) * d.B >= mm_min_blocks();
 }
 
 // sum of the KS split-K partial tiles (fixed order) + the conv epilogue of store mode 0:
@@ -170,6 +177,20 @@ bool adp_conv_mm_winograd(const adp_conv_desc& d) {
   return true;
 }
 
+// Wide-N blocks of the Winograd variant (NSP, conv_mm_impl.h): 64 rows x 256 positions, 128 when that leaves fewer than 200
+// workgroups, else the 64-position block.  ADP_MM_NSP caps it (1 = the 64-position block everywhere: A/B and tests).
+// Isolated launches at batch 4, 64 -> 128 / 256 positions, us (tools/nsp_micro.py): C=64 L=16384 conv1 (GroupNorm+SiLU
+// prologue) 33.7 -> 27.2 / 26.7, data gradient 27.6 -> 21.7 / 19.3; C=128 L=4096 19.9 -> 16.4; C=256 L=2048 30.1 -> 26.5;
+// C=512 L=1024 50.5 -> 45.5 (142 TF in direct-form flops).  Batch 1 keeps the 64-position block (grid too small).
+int adp_conv_mm_nsp(const adp_conv_desc& d) {
+  if (!adp_conv_mm_winograd(d) || !mm_use64(d) || d.up != 1 || d.stride != 1) return 1;
+  if (d.ws && adp_conv_mm_ksplit(d) > 1) return 1;
+  const char* e = getenv("ADP_MM_NSP");
+  int want = e ? atoi(e) : 4;
+  while (want > 1 && (d.M / 64) * adp_cdiv(d.N, 64 * want) * d.B < mm_min_blocks()) want /= 2;
+  return want < 1 ? 1 : want;
+}
+
 bool adp_conv_mm_eligible(const adp_conv_desc& d) {
   if (d.R1 != d.R) return false;
   const bool plain = d.stride == 1 && (d.KT == 1 || d.KT == 3) && d.up == 1;                    // ConvBlock family
@@ -190,7 +211,8 @@ bool adp_conv_mm_eligible(const adp_conv_desc& d) {
 // NKG * 1e6 + BM * 1e3 + BN of the tile the dispatcher picks
 int64_t adp_conv_mm_tile(const adp_conv_desc& d) {
   const int64_t nkg = d.stride == 4 ? 2 : 4;
-  return (adp_conv_mm_winograd(d) ? 40000000 : 0) + nkg * 1000000 + (mm_use64(d) ? 64064 : 32064);
+  const int64_t nsp = adp_conv_mm_nsp(d);
+  return (adp_conv_mm_winograd(d) ? 40000000 : 0) + (nkg / nsp) * 1000000 + (mm_use64(d) ? 64000 : 32000) + 64 * nsp;
 }
 
 int adp_conv_splitk_reduce(const adp_conv_desc& d, int64_t ks, void* stream) {

@@ -46,7 +46,8 @@ constexpr int MM_BN = 64;         // output positions per block
 // loader waves per block: the GroupNorm+SiLU prologue is VALU work (two transcendentals per element) on the
 // loaders' critical path, so those variants get twice the loaders -- except the one-chunk 32-row blocks of the
 // HBM-bound shallow layers, where more resident blocks per CU matter more (measured: depth 1, 54 vs 63 us)
-constexpr int mm_nld(int PRO, int BM, int PD) { return (PRO == 1 && !(BM == 32 && PD == 1)) ? 8 : 4; }
+// (the wide-N blocks, NSP > 1, keep 4: their 8 MMA waves need the 168-register budget of a 12-wave block)
+constexpr int mm_nld(int PRO, int BM, int PD, int NSP = 1) { return (PRO == 1 && NSP == 1 && !(BM == 32 && PD == 1)) ? 8 : 4; }
 // K groups (MMA wave groups that split the channels of a staged chunk): 8 channels each up to BKT = 32; a 64-channel
 // chunk (half the barriers per K) keeps 4 groups of 16 channels
 constexpr int mm_nkg(int BKT) { return BKT >= 32 ? 4 : BKT / 8; }
@@ -93,15 +94,20 @@ struct cmax {
 // Two thirds of the matrix work of the direct form in plain fp32 arithmetic; the loaders stay pure copies, so the
 // overlap of staging and MFMAs that conv_mm measures is kept (the first Winograd kernel of this repository
 // transformed in the loader waves and lost its MFMA saving to exactly that: DESIGN.md section 4).
-template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD, bool WN = false>
-__global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 64) void conv_mm_kernel(adp_conv_desc d,
-                                                                                                    int KS) {
+//
+// NSP > 1 (2 / 4; short K, long N: the mid-depth layers): the block covers NSP adjacent 64-position tiles and the MMA
+// waves trade K groups for positions (NKG = 4 / NSP), so a block stages the same weight chunk once for NSP times the
+// outputs, half / none of the K-group exchange remains, and a wave issues NSP times the MFMAs per barrier.
+template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD, bool WN = false, int NSP = 1>
+__global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD, NSP)) * 64) void conv_mm_kernel(
+    adp_conv_desc d, int KS) {
   static_assert(!WN || (KT == 3 && S == 1), "Winograd F(2,3): kernel 3, stride 1 (any upsample factor: the LDS tile "
                                             "holds virtual positions)");
-  constexpr int MM_NLD = mm_nld(PRO, BM, PD);
-  constexpr int BN = MM_BN, NKG = mm_nkg(BKT), NQM = BM / 32;
-  constexpr int CPK = BKT / NKG;                    // channels of a chunk one K group multiplies (8 or 16)
-  constexpr int NMMA = NQM * NKG;                   // MMA waves
+  static_assert(NSP == 1 || (mm_nkg(BKT) % NSP == 0 && S == 1 && UP == 1), "wide-N blocks: plain stride-1 convs");
+  constexpr int MM_NLD = mm_nld(PRO, BM, PD, NSP);
+  constexpr int BN = MM_BN * NSP, NKG = mm_nkg(BKT) / NSP, NQM = BM / 32;
+  constexpr int CPK = BKT / NKG;                    // channels of a chunk one K group multiplies (8, 16 or 32)
+  constexpr int NMMA = NQM * NKG * NSP;             // MMA waves
   constexpr int NLT = MM_NLD * 64;                  // loader threads
   constexpr int QK = BKT * KT;
   constexpr int AS = TR ? (BM * KT + 4) : (QK + 4);  // A row stride in floats
@@ -229,8 +235,9 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
   }
 
   // =========================== MMA waves ===========================
-  const int mq = wave % NQM, kg = wave / NQM;
+  const int mq = wave % NQM, kg = (wave / NQM) % NKG, nq = wave / (NQM * NKG);
   const int wm0 = mq * 32;
+  const int nw0 = n0 + nq * MM_BN;  // first output position of this wave's 64-position tile
   constexpr int NACC = WN ? 4 : 2;
   f32x16 acc[NACC];
 #pragma unroll
@@ -241,11 +248,13 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
   // WN epilogue operands of the rows this wave finishes (accumulator registers kg * RPW ..): fetched NOW, so that their
   // global-memory latency lies under the K loop instead of on the launch's tail (every block of a launch reaches its
   // epilogue at the same time: elimination build, depth 7 forward with residual: 8.8 of 55 us)
+  // (not the NKG = 1 wide-N blocks: all 16 rows of a lane would cost 64 registers; their K loop is two to four chunks)
   constexpr int RPW_ = 16 / NKG;
-  f32x2 pre_res[WN ? RPW_ : 1];
-  float pre_bias[WN ? RPW_ : 1], pre_scale[WN ? RPW_ : 1];
-  if constexpr (WN) {
-    const int n = n0 + 2 * l31;
+  constexpr bool PRE = WN && RPW_ <= 8;
+  f32x2 pre_res[PRE ? RPW_ : 1];
+  float pre_bias[PRE ? RPW_ : 1], pre_scale[PRE ? RPW_ : 1];
+  if constexpr (PRE) {
+    const int n = nw0 + 2 * l31;
 #pragma unroll
     for (int rr = 0; rr < RPW_; ++rr) {
       const int r = kg * RPW_ + rr;
@@ -260,8 +269,9 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
   }
 
   // lane-constant fragment offsets
-  const int xfrag = WN ? 4 * hi * XSP + 2 * l31 + 2                   // 8-byte pieces at +0, +2, +4: x[2j-2 .. 2j+3]
-                       : 4 * hi * XSP + l31 * S + 4 - pad;            // + ni*32*S + (ci + c) * XSP + t * dil
+  const int xfrag = nq * MM_BN * S +
+                    (WN ? 4 * hi * XSP + 2 * l31 + 2                  // 8-byte pieces at +0, +2, +4: x[2j-2 .. 2j+3]
+                        : 4 * hi * XSP + l31 * S + 4 - pad);          // + ni*32*S + (ci + c) * XSP + t * dil
   const int afrag = TR ? 4 * hi * AS + (wm0 + l31) * KT                // + (ci + c) * AS + (KT - 1 - t)
                        : (wm0 + l31) * AS + 4 * hi * KT;               // + ci * KT + (c * KT + t)
   if (PRO == 1) __syncthreads();
@@ -358,7 +368,7 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
   if (NKG > 1) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-      float* rp = smem + ((kg * NQM + mq) * 2 + ni) * 1024 + lane;
+      float* rp = smem + (((nq * NKG + kg) * NQM + mq) * 2 + ni) * 1024 + lane;
 #pragma unroll
       for (int r = 0; r < 16; ++r) rp[r * 64] = acc[ni][r];
     }
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
   if constexpr (WN) {
     // tiles 0 / 1 hold the even / odd position of the lane's output pair: 8-byte accesses, 256 contiguous bytes per
     // output row and half-wave
-    const int n = n0 + 2 * l31;
+    const int n = nw0 + 2 * l31;
     const bool nok = n < N;  // N is even: a pair is inside or outside
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
@@ -382,8 +392,8 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
         v0 = v1 = 0.0f;
 #pragma unroll
         for (int g = 0; g < NKG; ++g) {
-          v0 += smem[((g * NQM + mq) * 2 + 0) * 1024 + r * 64 + lane];
-          v1 += smem[((g * NQM + mq) * 2 + 1) * 1024 + r * 64 + lane];
+          v0 += smem[(((nq * NKG + g) * NQM + mq) * 2 + 0) * 1024 + r * 64 + lane];
+          v1 += smem[(((nq * NKG + g) * NQM + mq) * 2 + 1) * 1024 + r * 64 + lane];
         }
       } else {
         v0 = acc[0][rr];
@@ -408,11 +418,22 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
         continue;
       }
       const int64_t o = ((int64_t)b * M + m) * N + n;
-      v0 += pre_bias[rr];
-      v1 += pre_bias[rr];
+      float e_bias, e_sc;
+      f32x2 e_res;
+      if constexpr (PRE) {
+        e_bias = pre_bias[rr];
+        e_sc = pre_scale[rr];
+        e_res = pre_res[rr];
+      } else {
+        e_bias = d.bias ? d.bias[m] : 0.0f;
+        e_sc = d.e_scale ? d.e_scale[b * ebs + m] : 1.0f;
+        e_res = d.res ? *reinterpret_cast<const f32x2*>(d.res + o) : f32x2{0.0f, 0.0f};
+      }
+      v0 += e_bias;
+      v1 += e_bias;
       if (d.out_pre) *reinterpret_cast<f32x2*>(d.out_pre + o) = f32x2{v0, v1};
-      v0 = fmaf(v0, pre_scale[rr], pre_res[rr][0]);
-      v1 = fmaf(v1, pre_scale[rr], pre_res[rr][1]);
+      v0 = fmaf(v0, e_sc, e_res[0]);
+      v1 = fmaf(v1, e_sc, e_res[1]);
       *reinterpret_cast<f32x2*>(d.out + o) = f32x2{v0, v1};
       vfin[0][rr] = v0;
       vfin[1][rr] = v1;
@@ -420,7 +441,7 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
   } else {
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
-    const int n = n0 + ni * 32 + l31;
+    const int n = nw0 + ni * 32 + l31;
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int r = kg * RPW + rr;
@@ -428,7 +449,7 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
       if (NKG > 1) {
         v = 0.0f;
 #pragma unroll
-        for (int g = 0; g < NKG; ++g) v += smem[((g * NQM + mq) * 2 + ni) * 1024 + r * 64 + lane];
+        for (int g = 0; g < NKG; ++g) v += smem[(((nq * NKG + g) * NQM + mq) * 2 + ni) * 1024 + r * 64 + lane];
       } else {
         v = acc[ni][rr];
       }
@@ -473,9 +494,9 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
   // ---- GroupNorm partial statistics of the tile just stored (store 0, no K split): one (mean, M2, count) entry per
   // ROW QUAD (the 4 consecutive output channels a lane holds in accumulator registers 4q .. 4q+3) over the tile's
   // <= 64 positions: 8 values per lane, then the 32 lanes of the half-wave; two passes in registers.
-  if (d.gn_part != nullptr && KS == 1 && d.store == 0) {
-    const int cntv = (N - n0) < BN ? (N - n0) : BN;
-    const bool ok0 = WN ? (n0 + 2 * l31 < N) : (n0 + l31 < N), ok1 = WN ? ok0 : (n0 + 32 + l31 < N);
+  if (d.gn_part != nullptr && KS == 1 && d.store == 0 && nw0 < N) {
+    const int cntv = (N - nw0) < MM_BN ? (N - nw0) : MM_BN;
+    const bool ok0 = WN ? (nw0 + 2 * l31 < N) : (nw0 + l31 < N), ok1 = WN ? ok0 : (nw0 + 32 + l31 < N);
     const float fcnt = 4.0f * (float)cntv;
 #pragma unroll
     for (int q = 0; q < RPW / 4; ++q) {
@@ -496,7 +517,7 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
       if (l31 == 0) {
         const int r = kg * RPW + 4 * q;
         const int m = m0 + wm0 + 8 * (r >> 2) + 4 * hi;  // first channel of the quad
-        float* e = d.gn_part + (((int64_t)b * (M / 4) + (m >> 2)) * ntn + nt) * 3;
+        float* e = d.gn_part + (((int64_t)b * (M / 4) + (m >> 2)) * ((N + MM_BN - 1) / MM_BN) + nt * NSP + nq) * 3;
         e[0] = mean;
         e[1] = qv;
         e[2] = fcnt;
@@ -505,12 +526,12 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 6
   }
 }
 
-template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD, bool WN = false>
+template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD, bool WN = false, int NSP = 1>
 int launch_mm(const adp_conv_desc& d, void* stream) {
-  const int64_t blocks = (d.M / BM) * adp_cdiv(d.N, MM_BN) * d.B;
+  const int64_t blocks = (d.M / BM) * adp_cdiv(d.N, MM_BN * NSP) * d.B;
   const int KS = d.ws ? (int)adp_conv_mm_ksplit(d) : 1;
-  ADP_LAUNCH((conv_mm_kernel<BM, KT, S, UP, TR, PRO, BKT, PD, WN>), dim3((unsigned)blocks, (unsigned)KS),
-             dim3(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD)) * 64), stream, d, KS);
+  ADP_LAUNCH((conv_mm_kernel<BM, KT, S, UP, TR, PRO, BKT, PD, WN, NSP>), dim3((unsigned)blocks, (unsigned)KS),
+             dim3(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD, NSP)) * 64), stream, d, KS);
   return ADP_LAUNCH_OK();
 }
 
@@ -518,6 +539,11 @@ int launch_mm(const adp_conv_desc& d, void* stream) {
 template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, bool WN = false>
 int launch_pd(const adp_conv_desc& d, void* stream) {
   const int64_t KS = d.ws ? adp_conv_mm_ksplit(d) : 1;
+  if constexpr (BM == 64 && WN && S == 1 && UP == 1) {  // wide-N blocks (one register stage: their chunks are long)
+    const int nsp = adp_conv_mm_nsp(d);
+    if (nsp == 4) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1, WN, 4>(d, stream);
+    if (nsp == 2) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1, WN, 2>(d, stream);
+  }
   // (a 64-channel chunk already is two 32-channel register stages; a second one does not fit the register file)
   // (a third register stage for the short Winograd chunks was measured: 14.37 -> 15.17 ms per step, rejected)
   if (BKT < 64 && d.R / BKT / KS >= 4) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 2, WN>(d, stream);

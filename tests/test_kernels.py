@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from audio_diffusion_pytorch_amd import ops
+from audio_diffusion_pytorch_amd import _C, ops
 from conftest import rel_err
 
 TOL = 1e-4  # tighter than the 1e-3 contract on purpose: these are single ops
@@ -135,6 +135,50 @@ def test_conv1d_winograd_with_groupnorm_prologue(dev, C, L, tr, monkeypatch):
     out = ops.conv1d(xd, w.to(dev), b.to(dev), pad=1, transposed=tr, prologue=1, pro_stats=stats,
                      pro_gamma=gamma.to(dev), pro_beta=beta.to(dev), groups=G, res=res.to(dev))
     assert rel_err(out, ref) < TOL
+
+
+@pytest.mark.parametrize("nsp", [2, 4])
+@pytest.mark.parametrize("B,C,M,L,tr,pro", [(2, 64, 64, 300, False, True), (1, 64, 128, 520, True, False),
+                                            (2, 128, 64, 256, False, False), (1, 96, 64, 68, True, True)])
+def test_conv1d_winograd_wide_blocks(dev, nsp, B, C, M, L, tr, pro, monkeypatch):
+    """Wide-N blocks of the Winograd variant (NSP = 2 / 4: 64 rows x 128 / 256 positions, K groups traded for position
+    tiles): ragged last block (whole 64-position tiles of a block beyond the row's end), GroupNorm+SiLU prologue,
+    transposed weight view, full epilogue, GroupNorm partial statistics -- against fp64 and, bit for bit where the K
+    order is the same (NSP = 4 sums a row's channels in one wave: not the same order), against the 64-position block."""
+    monkeypatch.setenv("ADP_CONV_WINO", "1")
+    monkeypatch.setenv("ADP_MM_MIN_BLOCKS", "1")
+    G = 8
+    x = rnd(B, C, L, seed=1) * 1.3 + 0.2
+    w = rnd(C, M, 3, seed=2, scale=0.1) if tr else rnd(M, C, 3, seed=2, scale=0.1)
+    b, res, sc = rnd(M, seed=3), rnd(B, M, L, seed=4), rnd(B * M, seed=5)
+    gamma, beta = rnd(C, seed=6) * 0.5 + 1, rnd(C, seed=7) * 0.1
+    a64 = (ref_gn_silu(x.double(), G, gamma.double(), beta.double()) if pro else x.double())
+    ref = F.conv_transpose1d(a64, w.double(), None, padding=1) if tr else F.conv1d(a64, w.double(), None, padding=1)
+    pre_ref = ref + b.double()[None, :, None]
+    ref = pre_ref * sc.double().view(B, M, 1) + res.double()
+    xd = x.to(dev)
+    kw = dict(pad=1, transposed=tr, e_scale=sc.to(dev), res=res.to(dev))
+    if pro:
+        kw.update(prologue=1, pro_stats=ops.gn_stats(xd, G), pro_gamma=gamma.to(dev), pro_beta=beta.to(dev), groups=G)
+    from ctypes import byref
+    d = _C.ConvDesc(_C.ptr(xd), None, _C.ptr(w.to(dev)), None, None, None, None, None, None, _C.ptr(xd), None, B, C, C,
+                    L, M, L, 3, 1, 1, 1, 1, int(tr), 0, 1, 0, 1, 0)
+    outs = {}
+    for n in (1, nsp):
+        monkeypatch.setenv("ADP_MM_NSP", str(n))
+        tile = _C.query("adp_conv1d_tile", byref(d))
+        assert tile // 10000000 == 4 and tile % 1000 == 64 * n and (tile // 1000) % 1000 == 64, tile
+        pre = torch.empty(B, M, L).to(dev)
+        gn = ops.GnPart()
+        out = ops.conv1d(xd, w.to(dev), b.to(dev), out_pre=pre, gn=gn, **kw)
+        outs[n] = (out, pre, gn)
+    err = lambda a, r: ((a.cpu().double() - r).abs().max() / r.abs().max()).item()  # noqa: E731
+    out, pre, gn = outs[nsp]
+    assert err(out, ref) < 1e-5 and err(pre, pre_ref) < 1e-5
+    assert gn.part is not None and gn.part[..., 2].sum(dim=2).eq(4 * L).all()
+    st, ref_st = ops.gn_finalize(gn.part, 8), ops.gn_stats(out, 8)
+    assert rel_err(st[..., 1], ref_st[..., 1]) < 1e-5 and (st[..., 0] - ref_st[..., 0]).abs().max() < 1e-5
+    assert err(out, outs[1][0].cpu().double()) < 2e-6
 
 
 def test_conv1d_big_tile(dev):
