@@ -177,16 +177,20 @@ bool adp_conv_mm_winograd(const adp_conv_desc& d) {
   return true;
 }
 
-// Wide-N blocks of the Winograd variant (NSP, conv_mm_impl.h): 64 rows x 256 positions, 128 when that leaves fewer than 200
+// Wide-N blocks of the Winograd variant and of the 1x1 convs (NSP, conv_mm_impl.h): 64 rows x 256 positions, 128 when that leaves fewer than 200
 // workgroups, else the 64-position block.  ADP_MM_NSP caps it (1 = the 64-position block everywhere: A/B and tests).
 // Isolated launches at batch 4, 64 -> 128 / 256 positions, us (tools/nsp_micro.py): C=64 L=16384 conv1 (GroupNorm+SiLU
 // prologue) 33.7 -> 27.2 / 26.7, data gradient 27.6 -> 21.7 / 19.3; C=128 L=4096 19.9 -> 16.4; C=256 L=2048 30.1 -> 26.5;
 // C=512 L=1024 50.5 -> 45.5 (142 TF in direct-form flops).  Batch 1 keeps the 64-position block (grid too small).
 int adp_conv_mm_nsp(const adp_conv_desc& d) {
-  if (!adp_conv_mm_winograd(d) || !mm_use64(d) || d.up != 1 || d.stride != 1) return 1;
+  if (!(adp_conv_mm_winograd(d) || (d.KT == 1 && d.up == 1)) || !mm_use64(d) || d.stride != 1) return 1;
   if (d.ws && adp_conv_mm_ksplit(d) > 1) return 1;
   const char* e = getenv("ADP_MM_NSP");
   int want = e ? atoi(e) : 4;
+  // the 1x1 convs are short of work per byte, not of weight reuse (tools/nsp_micro2.py, batch 4, 64 / 128 / 256 positions:
+  // 64 -> 128 channels at L = 16384 40.4 / 36.4 / 49.9 us, 256 -> 256 at L = 2048 20.0 / 22.3 / 22.2): 128 positions up to
+  // 128 input channels, the 64-position block above; the upsample convs gain like the plain ones (512 -> 256 x2: 49.8 -> 43.7)
+  if (d.KT == 1 && want > 1) want = d.R <= 128 ? 2 : 1;
   while (want > 1 && (d.M / 64) * adp_cdiv(d.N, 64 * want) * d.B < mm_min_blocks()) want /= 2;
   return want < 1 ? 1 : want;
 }

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD, NSP)
     adp_conv_desc d, int KS) {
   static_assert(!WN || (KT == 3 && S == 1), "Winograd F(2,3): kernel 3, stride 1 (any upsample factor: the LDS tile "
                                             "holds virtual positions)");
-  static_assert(NSP == 1 || (mm_nkg(BKT) % NSP == 0 && S == 1 && UP == 1), "wide-N blocks: plain stride-1 convs");
+  static_assert(NSP == 1 || (mm_nkg(BKT) % NSP == 0 && S == 1), "wide-N blocks: stride-1 convs");
   constexpr int MM_NLD = mm_nld(PRO, BM, PD, NSP);
   constexpr int BN = MM_BN * NSP, NKG = mm_nkg(BKT) / NSP, NQM = BM / 32;
   constexpr int CPK = BKT / NKG;                    // channels of a chunk one K group multiplies (8, 16 or 32)
@@ -539,9 +539,11 @@ int launch_mm(const adp_conv_desc& d, void* stream) {
 template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, bool WN = false>
 int launch_pd(const adp_conv_desc& d, void* stream) {
   const int64_t KS = d.ws ? adp_conv_mm_ksplit(d) : 1;
-  if constexpr (BM == 64 && WN && S == 1 && UP == 1) {  // wide-N blocks (one register stage: their chunks are long)
+  if constexpr (BM == 64 && S == 1 && (WN || KT == 1)) {  // wide-N blocks (one register stage: their chunks are long)
     const int nsp = adp_conv_mm_nsp(d);
-    if (nsp == 4) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1, WN, 4>(d, stream);
+    if constexpr (WN) {  // (the 1x1 convs stop at 128 positions: adp_conv_mm_nsp)
+      if (nsp == 4) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1, WN, 4>(d, stream);
+    }
     if (nsp == 2) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1, WN, 2>(d, stream);
   }
   // (a 64-channel chunk already is two 32-channel register stages; a second one does not fit the register file)

@@ -181,6 +181,33 @@ def test_conv1d_winograd_wide_blocks(dev, nsp, B, C, M, L, tr, pro, monkeypatch)
     assert err(out, outs[1][0].cpu().double()) < 2e-6
 
 
+@pytest.mark.parametrize("nsp", [2, 4])
+@pytest.mark.parametrize("B,R,M,L,KT,tr,up", [(2, 64, 128, 300, 1, True, 1), (1, 96, 64, 516, 1, False, 1),
+                                               (1, 64, 64, 130, 3, False, 2), (2, 128, 64, 36, 3, False, 4)])
+def test_conv1d_wide_blocks_1x1_and_upsample(dev, nsp, B, R, M, L, KT, tr, up, monkeypatch):
+    """The wide-N blocks under the 1x1 convs (direct form, both weight views) and the nearest-upsample Winograd convs."""
+    monkeypatch.setenv("ADP_CONV_WINO", "1")
+    monkeypatch.setenv("ADP_MM_MIN_BLOCKS", "1")
+    pad = (KT - 1) // 2
+    x = rnd(B, R, L, seed=1)
+    w = rnd(R, M, KT, seed=2, scale=0.1) if tr else rnd(M, R, KT, seed=2, scale=0.1)
+    N = L * up
+    b, res, sc = rnd(M, seed=3), rnd(B, M, N, seed=4), rnd(B * M, seed=5)
+    xr = F.interpolate(x.double(), scale_factor=up, mode="nearest") if up > 1 else x.double()
+    ref = F.conv_transpose1d(xr, w.double(), None, padding=pad) if tr else F.conv1d(xr, w.double(), None, padding=pad)
+    ref = (ref + b.double()[None, :, None]) * sc.double().view(B, M, 1) + res.double()
+    xd, wd = x.to(dev), w.to(dev)
+    from ctypes import byref
+    d = _C.ConvDesc(_C.ptr(xd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(xd), None, B, R, R,
+                    L, M, N, KT, 1, 1, pad, up, int(tr), 0, 1, 0, 1, 0)
+    monkeypatch.setenv("ADP_MM_NSP", str(nsp))
+    tile = _C.query("adp_conv1d_tile", byref(d))
+    want = min(nsp, 2) if KT == 1 else nsp  # the 1x1 convs stop at 128 positions per block
+    assert tile % 1000 == 64 * want and (tile // 1000) % 1000 == 64, tile
+    out = ops.conv1d(xd, wd, b.to(dev), pad=pad, up=up, transposed=tr, e_scale=sc.to(dev), res=res.to(dev))
+    assert ((out.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+
+
 def test_conv1d_big_tile(dev):
     # enough workgroups to select the 128x128 tile on the dispatcher
     B, R, M, L = 6, 32, 128, 1024 if dev.type == "cuda" else 1024
@@ -365,13 +392,16 @@ def test_conv_mm_resample(dev, B, R, M, L, KT, stride, pad, up, wino, monkeypatc
     assert rel_err(out, skip + scale[:, :, None] * ref) < TOL
 
 
-@pytest.mark.parametrize("wino", ["0", "1"])
+@pytest.mark.parametrize("wino", ["0", "1", "wide"])
 @pytest.mark.parametrize("B,Rf,Mf,L,up", [(2, 64, 96, 72, 2), (1, 32, 64, 40, 4), (2, 64, 32, 64, 4)])
 def test_conv_mm_upsample_dgrad_pooled_store(dev, B, Rf, Mf, L, up, wino, monkeypatch):
     """Data gradient of UpsampleItem (nearest x up, then k3 conv) on conv_mm: the transposed-weight conv over dy with
-    the pooled store (sum of the `up` replicas of each source position) + the residual epilogue, direct and Winograd."""
-    monkeypatch.setenv("ADP_CONV_WINO", wino)
+    the pooled store (sum of the `up` replicas of each source position) + the residual epilogue, direct and Winograd
+    ("wide": the Winograd variant's 256-position blocks)."""
+    monkeypatch.setenv("ADP_CONV_WINO", "0" if wino == "0" else "1")
     monkeypatch.setenv("ADP_WINO_MIN_R", "32")
+    if wino == "wide":
+        monkeypatch.setenv("ADP_MM_MIN_BLOCKS", "1")
     x = rnd(B, Rf, L, seed=1).requires_grad_()
     w = rnd(Mf, Rf, 3, seed=2, scale=0.2)
     y = F.conv1d(F.interpolate(x, scale_factor=up, mode="nearest"), w, None, padding=1)
