@@ -137,16 +137,26 @@ int64_t adp_conv_splitk_gn_entries(const adp_conv_desc& d) { return adp_cdiv(d.N
 // Cross-workgroup K split: when the output tiles alone leave most of the 256 CUs idle (batch-1 deep layers: depth 8
 // has 64 tiles of 32 x 64) the reduction over input channels is cut into 2 / 4 / 8 slices run by separate
 // workgroups (>= 4 chunks of 32 channels each), combined by conv_splitk_reduce_kernel (deterministic order).
+static int64_t env_or(const char* name, int64_t dflt) {
+  const char* e = getenv(name);
+  return e ? atoll(e) : dflt;
+}
+
 int64_t adp_conv_mm_ksplit(const adp_conv_desc& d) {
   static const bool off = getenv("ADP_MM_NO_KSPLIT") != nullptr;  // A/B switch for kernel work
   if (off || d.store != 0) return 1;  // pixel-shuffle / pooled stores keep their in-kernel epilogue
   const int64_t bm = mm_use64(d) ? 64 : 32;
-  const int64_t blocks = (d.M / bm) * adp_cdiv(d.N, 64) * d.B;
+  const int64_t blocks = (d.M / bm) * adp_cdiv(d.N, 64 * adp_conv_mm_nsp(d)) * d.B;
   const int64_t nchunks = d.R / (d.stride == 4 ? 16 : MM_BKT);
   int64_t ks = 1;
   // (the 200-workgroup target re-measured in round 3 with the Winograd variants, batch-1 step / sampler step in ms:
   //  130-200 -> 7.34 / 2.47, 300-400 -> 7.68 / 2.75, 520 -> 7.97 / 2.93, 100 -> 7.85 / 2.68, no split -> 8.16 / 2.82)
-  while (ks < 8 && blocks * ks < 200 && nchunks / (ks * 2) >= 4) ks *= 2;
+  // (batch 1, larger tiles + deeper splits instead, tools/b1_micro.py, forward us incl. the reduce launch: C=1024 L=256
+  //  32-row x ks 2 23.5 | 64-row x ks 4 24.1 | 64 x 128 positions x ks 8 29.9 | 64 x 256 x ks 16 38.6; C=512 L=1024 18.2 | 29.0 |
+  //  39.1 | 58.9: at batch 1 the small tile with the shallow split wins everywhere -- the knobs below are for that tool)
+  const int64_t target = env_or("ADP_MM_KS_TARGET", 200), ksmax = env_or("ADP_MM_KS_MAX", 8);
+  const int64_t minch = env_or("ADP_MM_KS_MINCH", 4);
+  while (ks < ksmax && blocks * ks < target && nchunks / (ks * 2) >= minch) ks *= 2;
   // the kernel gives slice i the chunks [i * ceil(n / ks), ...): every slice must own at least one (n = 33, ks = 8 would
   // leave the last two slices empty -- they would launch, restage a ghost chunk and park an all-zero partial tile)
   while (ks > 1 && (ks - 1) * adp_cdiv(nchunks, ks) >= nchunks) ks /= 2;
@@ -184,14 +194,14 @@ bool adp_conv_mm_winograd(const adp_conv_desc& d) {
 // C=512 L=1024 50.5 -> 45.5 (142 TF in direct-form flops).  Batch 1 keeps the 64-position block (grid too small).
 int adp_conv_mm_nsp(const adp_conv_desc& d) {
   if (!(adp_conv_mm_winograd(d) || (d.KT == 1 && d.up == 1)) || !mm_use64(d) || d.stride != 1) return 1;
-  if (d.ws && adp_conv_mm_ksplit(d) > 1) return 1;
   const char* e = getenv("ADP_MM_NSP");
   int want = e ? atoi(e) : 4;
   // the 1x1 convs are short of work per byte, not of weight reuse (tools/nsp_micro2.py, batch 4, 64 / 128 / 256 positions:
   // 64 -> 128 channels at L = 16384 40.4 / 36.4 / 49.9 us, 256 -> 256 at L = 2048 20.0 / 22.3 / 22.2): 128 positions up to
   // 128 input channels, the 64-position block above; the upsample convs gain like the plain ones (512 -> 256 x2: 49.8 -> 43.7)
   if (d.KT == 1 && want > 1) want = d.R <= 128 ? 2 : 1;
-  while (want > 1 && (d.M / 64) * adp_cdiv(d.N, 64 * want) * d.B < mm_min_blocks()) want /= 2;
+  const int64_t nsp_min = env_or("ADP_MM_NSP_MIN_BLOCKS", mm_min_blocks());
+  while (want > 1 && (d.M / 64) * adp_cdiv(d.N, 64 * want) * d.B < nsp_min) want /= 2;
   return want < 1 ? 1 : want;
 }
 
