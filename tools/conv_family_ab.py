@@ -37,7 +37,7 @@ def timeit(fn, n=20):
 
 
 def setenv(env):
-    for k in ("ADP_CONV_WINO", "ADP_WINO_MIN_R", "ADP_WINO_WGRAD_MIN_R", "ADP_ACT_MATERIALIZE_MIN_C", "ADP_MM_PD3", "ADP_MM_WN64"):
+    for k in ("ADP_CONV_WINO", "ADP_WINO_MIN_R", "ADP_WINO_WGRAD_MIN_R", "ADP_ACT_MATERIALIZE_MIN_C", "ADP_MM_NSP"):
         os.environ.pop(k, None)
     os.environ.update(env)
 
