@@ -355,6 +355,38 @@ def test_conv_stream32(dev, B, L, pro, res):
     assert rel_err(dx, dx_ref + (r if res else 0)) < TOL
 
 
+@pytest.mark.parametrize("wpb", [1, 2, 3])
+@pytest.mark.parametrize("B,L,pro,res", [(1, 1280, 1, 1), (2, 1536, 0, 0), (1, 256, 1, 0)])
+def test_conv_stream32_tile_pipeline(dev, wpb, B, L, pro, res, monkeypatch):
+    """The two MMA wave groups of conv_stream32 take a workgroup's tiles alternately, half a period apart (one multiplies
+    tile i while the other stores tile i-1): 1 to 6 tiles per workgroup (odd counts: ghost iteration; a group without a
+    tile: empty statistics entry), outputs and GroupNorm partial statistics."""
+    monkeypatch.setenv("ADP_STREAM_WPB", str(wpb))
+    C, G = 32, 8
+    x = rnd(B, C, L, seed=1) * 1.3 + 0.2
+    w, b = rnd(C, C, 3, seed=2, scale=0.2), rnd(C, seed=3)
+    gamma, beta = rnd(C, seed=4) * 0.5 + 1, rnd(C, seed=5) * 0.1
+    r = rnd(B, C, L, seed=6) if res else None
+    xd, wd = x.to(dev), w.to(dev)
+    gn = ops.GnPart()
+    if pro:
+        ref = F.conv1d(ref_gn_silu(x, G, gamma, beta), w, b, padding=1)
+        out = ops.conv1d(xd, wd, b.to(dev), pad=1, prologue=1, pro_stats=ops.gn_stats(xd, G), pro_gamma=gamma.to(dev),
+                         pro_beta=beta.to(dev), groups=G, res=r.to(dev) if res else None, gn=gn)
+    else:
+        ref = F.conv1d(x, w, b, padding=1)
+        out = ops.conv1d(xd, wd, b.to(dev), pad=1, res=r.to(dev) if res else None, gn=gn)
+    if res:
+        ref = ref + r
+    assert rel_err(out, ref) < TOL
+    assert gn.part is not None and gn.part.shape[2] == 8 * min(wpb, L // 256)
+    assert gn.part[..., 2].sum(dim=2).eq(4 * L).all()
+    st, ref_st = ops.gn_finalize(gn.part, G), ops.gn_stats(out, G)
+    assert rel_err(st[..., 1], ref_st[..., 1]) < 1e-5 and (st[..., 0] - ref_st[..., 0]).abs().max() < 1e-5
+    dx = ops.conv1d(xd, wd, None, pad=1, transposed=True)
+    assert rel_err(dx, F.conv_transpose1d(x, w, None, padding=1)) < TOL
+
+
 MM_RESAMPLE_CASES = [
     # B, R, M, Lin, KT, stride, pad, up -- DownsampleItem (kernel = stride) and UpsampleItem (nearest + k3) on conv_mm
     (2, 32, 64, 256, 2, 2, 0, 1),
