@@ -277,26 +277,6 @@ __global__ __launch_bounds__(256) void attn_sum_splits_kernel(const float* part,
   }
 }
 
-// delta[b,h,i] = sum_d dO[d,i] * O[d,i].  One workgroup = 64 queries x 4 channel groups (lanes along the queries:
-// coalesced rows; each wave sums a quarter of the D channels, LDS adds the four in a fixed order) -- a thread per
-// query walked all D rows in one dependent chain (20 us for 2 MB of traffic).
-__global__ __launch_bounds__(256) void attn_delta_kernel(const float* o, const float* dout, int H, int D, int64_t n,
-                                                         float* delta) {
-  __shared__ float part[4][64];
-  const int lane = threadIdx.x & 63, dg = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-  const int64_t bh = blockIdx.y;
-  float s = 0.0f;
-  if (i < n) {
-    const float* op = o + bh * D * n + i;
-    const float* dp = dout + bh * D * n + i;
-    for (int dd = dg; dd < D; dd += 4) s = fmaf(op[dd * n], dp[dd * n], s);
-  }
-  part[dg][lane] = s;
-  __syncthreads();
-  if (dg == 0 && i < n) delta[bh * n + i] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-}
-
 // ---------------------------------------------------------------------------------------------------
 // backward, key-major pass: one wave owns 32 keys and a slice of the query tiles:
 //   S[i][j] (rows i in regs, cols j across lanes), P = exp(S - lse_i), dP = dO^T V, dS = P (dP - delta_i) scale
@@ -450,9 +430,10 @@ __global__ __launch_bounds__(256) void attn_kv_reduce_kernel(const float* pk, co
 // ---------------------------------------------------------------------------------------------------
 template <bool D64>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* q, const float* k, const float* v,
-                                                         const float* dout, const float* lse, const float* delta,
-                                                         int H, int D, int n, int m, int64_t qbs, int64_t kvbs,
-                                                         float scale, float* dq, int tps, int64_t pstride) {
+                                                         const float* o, const float* dout, const float* lse,
+                                                         float* delta, int H, int D, int n, int m, int64_t qbs,
+                                                         int64_t kvbs, float scale, float* dq, int tps,
+                                                         int64_t pstride) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int64_t b = blockIdx.z, h = blockIdx.y;
   const int qblocks = (n + 127) / 128;
@@ -477,7 +458,20 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* q, const f
     }
   }
   const float li = qok ? lse[(b * H + h) * (int64_t)n + iq] : 0.0f;
-  const float di = qok ? delta[(b * H + h) * (int64_t)n + iq] : 0.0f;
+  // delta_i = sum_d dO[d][i] O[d][i]: the wave holds the dO columns of its 32 queries anyway (each half-wave every other
+  // channel), so the O columns are 32 more loads per lane and the separate delta kernel (a launch per attention layer)
+  // is gone; the first key slice publishes delta for the key-major pass, which runs after this one
+  float di;
+  {
+    const float* oh = o + (b * H + h) * (int64_t)D * n;
+    const int qcol = hi * n + (qok ? iq : n - 1);
+    float part = 0.0f;
+#pragma unroll
+    for (int s = 0; s < DMAX / 2; ++s)
+      if (D64 || 2 * s < D) part = fmaf(df[s], ld_col<D64>(oh, n, s, hi, D, qcol, qok), part);
+    di = part + __shfl_xor(part, 32, 64);
+    if (sp == 0 && hi == 0 && qok) delta[(b * H + h) * (int64_t)n + iq] = di;
+  }
   f32x16 dqa[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -617,8 +611,6 @@ extern "C" int adp_attn_bwd(const float* q, const float* k, const float* v, cons
   if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || !ws) return ADP_ERR_NULL;
   if (!attn_shape_ok(B, H, D, n, m)) return ADP_ERR_SHAPE;
   const float scale = 1.0f / sqrtf((float)D);
-  ADP_LAUNCH(attn_delta_kernel, dim3((unsigned)adp_cdiv(n, 64), (unsigned)(B * H)), dim3(256), stream, o, dout,
-             (int)H, (int)D, n, ws);
   const int64_t ns = kv_nsplit(B, H, n, m), ktiles = adp_cdiv(m, 32), qtiles = adp_cdiv(n, 32);
   const int64_t tps = adp_cdiv(qtiles, ns);  // query tiles per split
   float* pk = dk;
@@ -630,17 +622,8 @@ extern "C" int adp_attn_bwd(const float* q, const float* k, const float* v, cons
     pk = ws + B * H * n;
     pv = pk + ns * pstride;
   }
-  const dim3 gkv((unsigned)adp_cdiv(ktiles * ns, 4), (unsigned)H, (unsigned)B);
-  if (D == 64)
-    ADP_LAUNCH(attn_bwd_kv_kernel<true>, gkv, dim3(256), stream, q, k, v, dout, lse, (const float*)ws, (int)H, (int)D,
-               (int)n, (int)m, q_bstride, kv_bstride, scale, (int)ns, (int)tps, pstride, pk, pv);
-  else
-    ADP_LAUNCH(attn_bwd_kv_kernel<false>, gkv, dim3(256), stream, q, k, v, dout, lse, (const float*)ws, (int)H, (int)D,
-               (int)n, (int)m, q_bstride, kv_bstride, scale, (int)ns, (int)tps, pstride, pk, pv);
-  if (ns > 1)  // dk and dv are [H*D, m] slabs inside each batch stride
-    ADP_LAUNCH(attn_kv_reduce_kernel, dim3((unsigned)adp_cdiv(H * D * m, 256), (unsigned)(2 * B)), dim3(256), stream,
-               (const float*)pk, (const float*)pv, (int)ns, pstride, kv_bstride, H * D * m, dk, dv);
-  // query-major pass, key-split when the query tiles alone do not fill the chip (needs packed q: one partial copy is
+  // query-major pass first: it also computes delta = rowsum(dO * O) for its queries and leaves it in ws[0 .. B*H*n) for the
+  // key-major pass.  Key-split when the query tiles alone do not fill the chip (needs packed q: one partial copy is
   // addressed exactly like dq)
   int64_t qtps = ktiles;
   int64_t nq = (q_bstride == H * D * n) ? q_nsplit(B, H, n, m, &qtps) : 1;
@@ -653,13 +636,23 @@ extern "C" int adp_attn_bwd(const float* q, const float* k, const float* v, cons
   }
   const dim3 gq2((unsigned)(adp_cdiv(n, 128) * nq), (unsigned)H, (unsigned)B);
   if (D == 64)
-    ADP_LAUNCH(attn_bwd_q_kernel<true>, gq2, dim3(256), stream, q, k, v, dout, lse, (const float*)ws, (int)H, (int)D,
-               (int)n, (int)m, q_bstride, kv_bstride, scale, pq, (int)qtps, qstride);
+    ADP_LAUNCH(attn_bwd_q_kernel<true>, gq2, dim3(256), stream, q, k, v, o, dout, lse, ws, (int)H, (int)D, (int)n, (int)m,
+               q_bstride, kv_bstride, scale, pq, (int)qtps, qstride);
   else
-    ADP_LAUNCH(attn_bwd_q_kernel<false>, gq2, dim3(256), stream, q, k, v, dout, lse, (const float*)ws, (int)H, (int)D,
-               (int)n, (int)m, q_bstride, kv_bstride, scale, pq, (int)qtps, qstride);
+    ADP_LAUNCH(attn_bwd_q_kernel<false>, gq2, dim3(256), stream, q, k, v, o, dout, lse, ws, (int)H, (int)D, (int)n, (int)m,
+               q_bstride, kv_bstride, scale, pq, (int)qtps, qstride);
   if (nq > 1)
     ADP_LAUNCH(attn_sum_splits_kernel, dim3((unsigned)adp_cdiv(H * D * n, 256), (unsigned)B), dim3(256), stream,
                (const float*)pq, (int)nq, qstride, q_bstride, H * D * n, dq);
+  const dim3 gkv((unsigned)adp_cdiv(ktiles * ns, 4), (unsigned)H, (unsigned)B);
+  if (D == 64)
+    ADP_LAUNCH(attn_bwd_kv_kernel<true>, gkv, dim3(256), stream, q, k, v, dout, lse, (const float*)ws, (int)H, (int)D,
+               (int)n, (int)m, q_bstride, kv_bstride, scale, (int)ns, (int)tps, pstride, pk, pv);
+  else
+    ADP_LAUNCH(attn_bwd_kv_kernel<false>, gkv, dim3(256), stream, q, k, v, dout, lse, (const float*)ws, (int)H, (int)D,
+               (int)n, (int)m, q_bstride, kv_bstride, scale, (int)ns, (int)tps, pstride, pk, pv);
+  if (ns > 1)  // dk and dv are [H*D, m] slabs inside each batch stride
+    ADP_LAUNCH(attn_kv_reduce_kernel, dim3((unsigned)adp_cdiv(H * D * m, 256), (unsigned)(2 * B)), dim3(256), stream,
+               (const float*)pk, (const float*)pv, (int)ns, pstride, kv_bstride, H * D * m, dk, dv);
   return ADP_LAUNCH_OK();
 }

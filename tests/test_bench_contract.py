@@ -41,7 +41,7 @@ def test_roofline_objects_from_instrumented_steps(monkeypatch):
 def test_attention_summary_per_kernel_and_per_call():
     recs = [("adp_attn_fwd", "attn_fwd_kernel<true>(args)", {"flops": 4_000_000_000}, 0.020),
             ("adp_attn_fwd", "attn_fwd_combine_kernel(args)", {}, 0.008),
-            ("adp_attn_bwd", "attn_delta_kernel(args)", {"flops": 14_000_000_000}, 0.008),
+            ("adp_attn_bwd", "attn_sum_splits_kernel(args)", {"flops": 14_000_000_000}, 0.008),
             ("adp_attn_bwd", "attn_bwd_kv_kernel<true>(args)", {}, 0.040),
             ("adp_attn_bwd", "attn_bwd_q_kernel<true>(args)", {}, 0.022),
             ("adp_conv1d", "conv_mm_kernel<32>(args)", {"flops": 1}, 1.0)]
