@@ -35,7 +35,21 @@ constexpr int ST_NX4 = (ST_C * ST_XQ + 255) / 256;  // staging quads per loader 
 template <bool TR, int PRO>
 __global__ __launch_bounds__(768) void conv_stream32_kernel(adp_conv_desc d, int tiles_per_b, int wpb) {
   __shared__ __attribute__((aligned(16))) float smem[2 * ST_C * ST_XS];
+  // the 32 x 32 x 3 weights, staged ONCE per workgroup with coalesced 16-byte loads (rows of 96 floats at a stride of 97:
+  // the fragment reads below are conflict-free).  Each of the eight MMA waves used to gather its 48 A operands straight
+  // from global memory -- 48 load instructions with a 384-byte lane stride, 1536 cache-line requests per wave: most of the
+  // 7-9 us launch skeleton the round-3 elimination builds showed.
+  constexpr int ST_WS = ST_C * ST_KT + 1;
+  __shared__ float wsm[ST_C * ST_WS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  f32x4 wq = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  const bool wvec = (reinterpret_cast<uintptr_t>(d.w) & 15) == 0;
+  if (wvec) {  // 768 threads x 4 floats = the whole matrix
+    wq = *reinterpret_cast<const f32x4*>(d.w + 4 * tid);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wq[k] = d.w[4 * tid + k];
+  }
   const int hi = lane >> 5, l31 = lane & 31;
   const int L = (int)d.Lin;
   // contiguous tile range of this workgroup, inside ONE batch element (wpb workgroups per batch element): the
@@ -92,6 +106,9 @@ __global__ __launch_bounds__(768) void conv_stream32_kernel(adp_conv_desc d, int
     // arrived at barrier B_{it-1} after issuing them, and this wave passed B_{it-1} before starting iteration it
     load_tile(rxs[0], oks[0], 0);
     load_tile(rxs[1], oks[1], 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wsm[((4 * tid + k) / (ST_C * ST_KT)) * ST_WS + (4 * tid + k) % (ST_C * ST_KT)] = wq[k];
+    __syncthreads();  // weights staged (pairs with the MMA waves' barrier below)
     if (PRO == 1) {  // (after the first tiles' loads are on their way: these constants come from memory too)
 #pragma unroll
       for (int i = 0; i < ST_NX4; ++i) {
@@ -118,8 +135,12 @@ __global__ __launch_bounds__(768) void conv_stream32_kernel(adp_conv_desc d, int
   // accumulates the statistics of the tile it multiplied one interval earlier -- so every SIMD has one wave on the
   // matrix cores and one on the memory pipes at any time (elimination build of the one-group form: 10.5 of 31.8 us were
   // MFMAs nothing else ran under).
-  const int grp = wave >> 2, wq = wave & 3;
-  // A operands: av[g][c*KT + t] = A(m = l31, channel 8g + c + 4hi, tap t)
+  const int grp = wave >> 2, wqt = wave & 3;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) wsm[((4 * tid + k) / (ST_C * ST_KT)) * ST_WS + (4 * tid + k) % (ST_C * ST_KT)] = wq[k];
+  __syncthreads();  // weights staged
+  // A operands: av[g][c*KT + t] = A(m = l31, channel 8g + c + 4hi, tap t), from the staged copy (w[M][R][KT], or w[R][M][KT]
+  // with the taps flipped for the data gradient)
   float av[4][4 * ST_KT];
 #pragma unroll
   for (int g = 0; g < 4; ++g)
@@ -128,13 +149,12 @@ __global__ __launch_bounds__(768) void conv_stream32_kernel(adp_conv_desc d, int
 #pragma unroll
       for (int t = 0; t < ST_KT; ++t) {
         const int r = 8 * g + c + 4 * hi;
-        av[g][c * ST_KT + t] = TR ? d.w[((int64_t)r * ST_C + l31) * ST_KT + (ST_KT - 1 - t)]
-                                  : d.w[((int64_t)l31 * ST_C + r) * ST_KT + t];
+        av[g][c * ST_KT + t] = TR ? wsm[r * ST_WS + l31 * ST_KT + (ST_KT - 1 - t)] : wsm[l31 * ST_WS + r * ST_KT + t];
       }
   // the bias enters through one extra MFMA step per accumulator tile (A = bias[m] in the k = 0 half, B = 1): one register
   // instead of the 16 a per-row add in the epilogue would hold for the lifetime of the workgroup
   const float bias_a = (d.bias && hi == 0) ? d.bias[l31] : 0.0f;
-  const int xfrag = 4 * hi * ST_XS + 64 * wq + l31 + 4 - 1;  // + ni*32 + (8g + c) * XS + t
+  const int xfrag = 4 * hi * ST_XS + 64 * wqt + l31 + 4 - 1;  // + ni*32 + (8g + c) * XS + t
   const bool has_res = d.res != nullptr;
   const bool want_gn = d.gn_part != nullptr;
   float gs[4], gq[4];  // running sum / sum of squares of this lane's share of each output ROW QUAD (GroupNorm partials)
@@ -193,7 +213,7 @@ __global__ __launch_bounds__(768) void conv_stream32_kernel(adp_conv_desc d, int
     } else if (it < niter && (it & 1) == grp) {
       const int t = t_beg + it;
       const int n0 = (t - wb * tiles_per_b) * ST_TN;
-      pbase = (int64_t)wb * ST_C * L + n0 + 64 * wq;
+      pbase = (int64_t)wb * ST_C * L + n0 + 64 * wqt;
       const float* Xb = smem + (it & 1) * (ST_C * ST_XS);
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
