@@ -63,6 +63,8 @@ SIGNATURES = {
     "adp_modulation_fwd": (c_int, [P, P, I, I, I, I, F, P, P, P]),
     "adp_chan_ln_bwd_ws_bytes": (I, [I, I, I]),
     "adp_modulation_bwd": (c_int, [P, P, P, I, P, I, I, I, P, P, I, P, P]),
+    "adp_modulation_bwd_partial": (I, [P, P, P, I, P, I, I, I, P, P, P]),
+    "adp_modulation_bwd_reduce": (c_int, [P, P, I, I, I, I, I, P]),
     "adp_ln_stats": (c_int, [P, I, I, I, F, P, P]),
     "adp_ln_affine_fwd": (c_int, [P, I, I, I, F, P, P, P, P, P, P, P, P]),
     "adp_ln_bwd": (c_int, [P, P, P, P, P, I, I, I, I, P, P, P, P]),
@@ -202,6 +204,24 @@ def call(name: str, *args):
     kernels = [k for k in _decode_trace(buf.value.decode()).split(" + ") if k]
     PROFILE.append([name, kernels, _TAG or {}, None])   # the last slot receives the per-kernel times
     _TAG = None
+
+
+def call_value(name: str, *args) -> int:
+    """`call` for entry points that launch AND return a non-negative value (negative: error code)."""
+    global _TAG
+    l = lib()
+    if PROFILE is not None:
+        l.adp_launch_trace(1, None, 0)
+    v = getattr(l, name)(*args)
+    if PROFILE is not None:
+        buf = ctypes.create_string_buffer(4096)
+        l.adp_launch_trace(0, buf, 4096)
+        kernels = [k for k in _decode_trace(buf.value.decode()).split(" + ") if k]
+        PROFILE.append([name, kernels, _TAG or {}, None])
+        _TAG = None
+    if v < 0:
+        raise RuntimeError(f"{name} failed: {ERRORS.get(v, v)} ({v})")
+    return int(v)
 
 
 def profile_collect():

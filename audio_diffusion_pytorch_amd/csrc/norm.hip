@@ -1077,6 +1077,52 @@ static void launch_reduce_tiles(const float* ws, int64_t B, int64_t C, int64_t N
                stream, ws, B, C, NT, bstride, sum_over_b, accumulate, out);
 }
 
+// The same second stage for up to MOD_BATCH Modulation backwards of ONE shape in one launch (blockIdx.z = which one): the
+// Modulation items of a U-Net depth share (B, C, L), and nothing reads their scale / shift gradients before the depth's
+// conditioning-bank rows are formed at the end of the block -- 42 launches of a step become 9.  Same sums, same order.
+constexpr int MOD_BATCH = 8;
+struct adp_mod_batch {
+  const float* ws[MOD_BATCH];
+  float* out[MOD_BATCH];
+};
+
+__global__ __launch_bounds__(1024) void reduce_tiles_batch_kernel(adp_mod_batch q, int64_t C, int64_t NT, int64_t bstride) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int64_t W = 2 * C;
+  const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t b = blockIdx.y;
+  const float* ws = q.ws[blockIdx.z];
+  float s = 0.0f;
+  if (j < W) {
+    const int64_t which = j / C, c = j % C;
+    const float* p = ws + ((b * 2 + which) * NT) * C + c;
+    for (int64_t t = tg; t < NT; t += 16) s += p[t * C];
+  }
+  part[tg][lane] = s;
+  __syncthreads();
+  if (tg == 0 && j < W) {
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += part[k][lane];
+    q.out[blockIdx.z][b * bstride + j] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_tiles_wave_batch_kernel(adp_mod_batch q, int64_t B, int64_t C, int64_t NT,
+                                                                      int64_t bstride) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t W = 2 * C;
+  if (i >= B * W) return;
+  const int64_t j = i % W, which = j / C, c = j % C, b = i / W;
+  const float* p = q.ws[blockIdx.z] + ((b * 2 + which) * NT) * C + c;
+  float s = 0.0f;
+  for (int64_t t = lane; t < NT; t += 64) s += p[t * C];
+  s = adp_wave_sum(s);
+  if (lane == 0) q.out[blockIdx.z][b * bstride + j] = s;
+}
+
 // ---- SkipModulate backward: dx = scale[b,c] * g ; partial dot(g, x) per (row, split) -------------------------
 __global__ __launch_bounds__(256) void skipmod_bwd_kernel(const float* g, const float* x, const float* scale,
                                                           int64_t sbstride, int64_t C, int64_t L, int64_t NS,
@@ -1296,6 +1342,39 @@ extern "C" int adp_modulation_bwd(const float* x, const float* dy, const float* 
   const int64_t NT = launch_ln_bwd(x, dy, ss, ss_bstride, (const float*)nullptr, stats, (const float*)nullptr, B, C, L, dx,
                                    ws, stream);
   launch_reduce_tiles((const float*)ws, B, C, NT, dss_bstride, 0, 0, dss, stream);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int64_t adp_modulation_bwd_partial(const float* x, const float* dy, const float* ss, int64_t ss_bstride,
+                                              const float* stats, int64_t B, int64_t C, int64_t L, float* dx, float* ws,
+                                              void* stream) {
+  if (!x || !dy || !ss || !stats || !dx || !ws) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
+  if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
+  const int64_t NT = launch_ln_bwd(x, dy, ss, ss_bstride, (const float*)nullptr, stats, (const float*)nullptr, B, C, L, dx,
+                                   ws, stream);
+  return ADP_LAUNCH_OK() == ADP_OK ? NT : (int64_t)ADP_ERR_LAUNCH;
+}
+
+extern "C" int adp_modulation_bwd_reduce(const float* const* ws, float* const* dss, int64_t n, int64_t B, int64_t C,
+                                         int64_t NT, int64_t dss_bstride, void* stream) {
+  if (!ws || !dss) return ADP_ERR_NULL;
+  if (n < 1 || B <= 0 || C <= 0 || NT <= 0 || B > 65535) return ADP_ERR_SHAPE;
+  for (int64_t at = 0; at < n; at += MOD_BATCH) {
+    adp_mod_batch q;
+    const int m = (int)(n - at < MOD_BATCH ? n - at : MOD_BATCH);
+    for (int i = 0; i < MOD_BATCH; ++i) {
+      q.ws[i] = ws[at + (i < m ? i : 0)];
+      q.out[i] = dss[at + (i < m ? i : 0)];
+      if (!q.ws[i] || !q.out[i]) return ADP_ERR_NULL;
+    }
+    if (NT >= 128 && C <= 64)  // (the choice launch_reduce_tiles makes)
+      ADP_LAUNCH(reduce_tiles_wave_batch_kernel, dim3((unsigned)adp_cdiv(B * 2 * C, 4), 1, (unsigned)m), dim3(256), stream, q,
+                 B, C, NT, dss_bstride);
+    else
+      ADP_LAUNCH(reduce_tiles_batch_kernel, dim3((unsigned)adp_cdiv(2 * C, 64), (unsigned)B, (unsigned)m), dim3(1024),
+                 stream, q, C, NT, dss_bstride);
+  }
   return ADP_LAUNCH_OK();
 }
 

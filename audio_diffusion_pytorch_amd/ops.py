@@ -4,6 +4,7 @@ These only marshal tensors (device pointers, shapes, the current HIP stream) int
 gfx950 kernels; they hold no arithmetic of their own and have no fallback.  Outputs are allocated by
 the caller or with torch.empty on the input's device (PyTorch = device memory + streams only).
 """
+import ctypes
 from ctypes import byref
 from typing import Optional
 
@@ -208,6 +209,41 @@ def modulation_bwd(x: Tensor, dy: Tensor, ss: Tensor, ss_bstride: int, stats: Te
     _C.call("adp_modulation_bwd", ptr(x), ptr(dy), ptr(ss), ss_bstride, ptr(stats), B, C, L, ptr(dx), ptr(dss),
             dss_bstride, ptr(ws), _C.stream())
     return dx
+
+
+class ModulationSums:
+    """Parked second stages of Modulation backwards (adp_modulation_bwd_partial / _reduce): the per-tile channel sums of
+    each backward stay in its workspace until `flush`, which sums every parked item whose scale / shift gradient slice
+    lies in [lo, hi) of the conditioning-bank row -- the items of one U-Net depth, which share their shape -- in one
+    launch per eight."""
+
+    def __init__(self):
+        self.items = []  # (offset into the bank row, ws, dss view, B, C, NT, dss_bstride)
+
+    def partial(self, off: int, x: Tensor, dy: Tensor, ss: Tensor, ss_bstride: int, stats: Tensor, dss: Tensor,
+                dss_bstride: int) -> Tensor:
+        B, C, L = x.shape
+        dx = torch.empty_like(x)
+        ws = _ws(_C.query("adp_chan_ln_bwd_ws_bytes", B, C, L), x)
+        _C.tag(bytes=12 * x.numel(), shape=f"B{B} C{C} L{L}")
+        NT = _C.call_value("adp_modulation_bwd_partial", ptr(x), ptr(dy), ptr(ss), ss_bstride, ptr(stats), B, C, L, ptr(dx),
+                           ptr(ws), _C.stream())
+        self.items.append((off, ws, dss, B, C, NT, dss_bstride))
+        return dx
+
+    def flush(self, lo: Optional[int] = None, hi: Optional[int] = None) -> None:
+        take = [it for it in self.items if lo is None or lo <= it[0] < hi]
+        if not take:
+            return
+        self.items = [it for it in self.items if not (lo is None or lo <= it[0] < hi)]
+        groups = {}
+        for it in take:
+            groups.setdefault(it[3:], []).append(it)
+        for (B, C, NT, bstride), its in groups.items():
+            n = len(its)
+            wsp = (ctypes.c_void_p * n)(*[ptr(it[1]) for it in its])
+            dsp = (ctypes.c_void_p * n)(*[ptr(it[2]) for it in its])
+            _C.call("adp_modulation_bwd_reduce", wsp, dsp, n, B, C, NT, bstride, _C.stream())
 
 
 def ln_stats(x: Tensor, eps: float = LN_EPS) -> Tensor:

@@ -331,6 +331,7 @@ class _Run:
         self.grads: Dict[str, Tensor] = {}
         self.pnames = {id(p): n for n, p in net.named_parameters()}
         self.gn: Optional[ops.GnPart] = None  # GroupNorm partial statistics of the tensor produced last (if any)
+        self.mod_sums = ops.ModulationSums()  # parked second stages of the Modulation backwards
 
     # -- gradient destination views -------------------------------------------------------
     def g(self, p: nn.Parameter) -> Tensor:
@@ -390,6 +391,7 @@ class _Run:
         Returns the (start, end) row range."""
         n = self.net
         a, b = n.bank_depth_rows[d] if n.bank_total > 0 else (0, 0)
+        self.mod_sums.flush(a, b)
         if b > a:
             K = n.mf
             ops.linear_bwd_weight(self.dss_all.view(-1)[a:], self.feats, act=ACT_SILU,
@@ -491,7 +493,9 @@ class _Run:
         self.gn = None
         y, stats = ops.modulation_fwd(x, ss, NT)
         if self.need_grad:
-            self.tape.append((lambda gy: ops.modulation_bwd(x, gy, ss, NT, stats, dss, NT), None))
+            off = self.net.bank_slices[key][0]
+            # (second stage parked: the depth's Modulation items are summed together when its bank rows are formed)
+            self.tape.append((lambda gy: self.mod_sums.partial(off, x, gy, ss, NT, stats, dss, NT), None))
         return y
 
     def inject(self, p, x: Tensor, ctx: Tensor, ctx_index: int) -> Tensor:
@@ -686,6 +690,7 @@ class _UNetFn(torch.autograd.Function):
                     if rb > ra:  # this depth's weight rows of the conditioning bank (the small bias goes out at the end)
                         w0 = offs["bank_weight"][0]
                         hook(flat, w0 + ra * net.mf, w0 + rb * net.mf)
+        run.mod_sums.flush()  # (nothing is left when every Modulation belongs to a tagged block)
         dfeat = run.conditioning_backward()
         if hook is not None:
             for a, b in net.nonblock_param_ranges():

@@ -184,6 +184,16 @@ int64_t adp_chan_ln_bwd_ws_bytes(int64_t B, int64_t C, int64_t L);
 int adp_modulation_bwd(const float* x, const float* dy, const float* ss, int64_t ss_bstride, const float* stats,
                        int64_t B, int64_t C, int64_t L, float* dx, float* dss, int64_t dss_bstride, float* ws,
                        void* stream);
+/* The two stages of adp_modulation_bwd separately.  adp_modulation_bwd_partial: dx and the per-tile channel sums in ws
+ * (adp_chan_ln_bwd_ws_bytes); returns the tile count NT (> 0) or a negative error.  adp_modulation_bwd_reduce: the second
+ * stage of n Modulation backwards of ONE shape (B, C, NT) in one launch per 8 -- ws[i] / dss[i] are host arrays of device
+ * pointers; dss_i[b*dss_bstride + {c | C + c}] as above.  The Modulation items of a U-Net depth share their shape, and their
+ * scale / shift gradients are first read when the depth's conditioning rows are formed. */
+int64_t adp_modulation_bwd_partial(const float* x, const float* dy, const float* ss, int64_t ss_bstride,
+                                   const float* stats, int64_t B, int64_t C, int64_t L, float* dx, float* ws,
+                                   void* stream);
+int adp_modulation_bwd_reduce(const float* const* ws, float* const* dss, int64_t n, int64_t B, int64_t C, int64_t NT,
+                              int64_t dss_bstride, void* stream);
 
 /* LayerNorm-over-channels statistics only (LayerNorm prologue of the attention projections, components.py:92-93) */
 int adp_ln_stats(const float* x, int64_t B, int64_t C, int64_t L, float eps, float* stats, void* stream);

@@ -737,6 +737,30 @@ def test_modulation_fwd_bwd(dev, B, C, L):
     assert rel_err(dbank, dbank_ref) < TOL
 
 
+@pytest.mark.parametrize("B,C,L,n", [(2, 64, 200, 3), (1, 32, 9000, 2), (2, 1024, 12, 9)])
+def test_modulation_bwd_parked_sums(dev, B, C, L, n):
+    """adp_modulation_bwd_partial + adp_modulation_bwd_reduce: n Modulation backwards of one shape, second stages summed by
+    one launch per eight (both reduce forms: tile-major workgroups, and a wave per output for narrow + long), have the bits
+    of n separate adp_modulation_bwd calls; a flush by bank-row range takes only the items inside it."""
+    NT = n * 2 * C + 5
+    bank = (rnd(B, NT, seed=2) * 0.5).to(dev)
+    xs = [(rnd(B, C, L, seed=10 + i) * 1.5 + 0.4).to(dev) for i in range(n)]
+    dys = [rnd(B, C, L, seed=30 + i).to(dev) for i in range(n)]
+    offs = [3 + i * 2 * C for i in range(n)]
+    stats = [ops.modulation_fwd(xs[i], bank.view(-1)[offs[i]:], NT)[1] for i in range(n)]
+    d0 = torch.zeros(B, NT, device=dev)
+    dx0 = [ops.modulation_bwd(xs[i], dys[i], bank.view(-1)[offs[i]:], NT, stats[i], d0.view(-1)[offs[i]:], NT) for i in range(n)]
+    d1 = torch.zeros(B, NT, device=dev)
+    sums = ops.ModulationSums()
+    dx1 = [sums.partial(offs[i], xs[i], dys[i], bank.view(-1)[offs[i]:], NT, stats[i], d1.view(-1)[offs[i]:], NT)
+           for i in range(n)]
+    sums.flush(offs[1], NT)          # everything but the first item
+    assert len(sums.items) == 1 and d1[:, offs[0]:offs[0] + 2 * C].eq(0).all()
+    sums.flush()
+    assert not sums.items
+    assert torch.equal(d0, d1) and all(torch.equal(a, b) for a, b in zip(dx0, dx1))
+
+
 def test_ln_bwd(dev):
     B, C, L = 2, 40, 70
     x = (rnd(B, C, L, seed=1) * 2 + 1).requires_grad_()
