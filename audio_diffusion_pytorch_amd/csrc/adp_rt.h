@@ -53,6 +53,54 @@ __device__ __forceinline__ void adp_barrier_consume() {
   asm volatile("" ::: "memory");
 }
 
+// Workgroup barrier that publishes LDS writes only: waits for this wave's LDS operations (lgkmcnt) and nothing else, so
+// global LOADS issued before it stay in flight across it (__syncthreads() carries an s_waitcnt vmcnt(0)).
+__device__ __forceinline__ void adp_barrier_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Ordering point for LDS data a wave hands to ITSELF (lane A writes, lane B of the same wave reads): the LDS executes one
+// wave's instructions in order, so the hardware needs nothing; the compiler must not move the reads above the writes.
+__device__ __forceinline__ void adp_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Issue priority of this wave among the waves of its SIMD (0-3; s_setprio takes an immediate)
+__device__ __forceinline__ void adp_setprio(int p) {
+  if (p >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+
+// wave-uniform value as a scalar (v_readfirstlane): addresses built from it use SGPR bases instead of per-lane 64-bit math
+__device__ __forceinline__ int adp_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// value of lane `src` (compile-time constant) in every lane
+__device__ __forceinline__ float adp_read_lane(float v, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+// sum over the 32 lanes of each half-wave with five DPP adds (no LDS, no bpermute); VALID IN LANES 16-31 AND 48-63 only
+__device__ __forceinline__ float adp_half_sum(float v) {
+#define ADP_DPP_ADD(ctrl, rmask) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+  ADP_DPP_ADD(0xB1, 0xf);   // quad_perm [1,0,3,2]
+  ADP_DPP_ADD(0x4E, 0xf);   // quad_perm [2,3,0,1]
+  ADP_DPP_ADD(0x141, 0xf);  // row_half_mirror
+  ADP_DPP_ADD(0x140, 0xf);  // row_mirror: every lane of a 16-lane row holds the row sum
+  ADP_DPP_ADD(0x142, 0xa);  // row_bcast15 into rows 1 and 3: lanes 16-31 / 48-63 hold the half-wave sum
+#undef ADP_DPP_ADD
+  return v;
+}
+__device__ __forceinline__ float adp_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+
+// 100 MHz wall clock (s_memrealtime) and a parked wait on it: staggers the waves that share a SIMD without a barrier.
+__device__ __forceinline__ long long adp_clock() { return (long long)wall_clock64(); }
+__device__ __forceinline__ void adp_wait_until(long long t) {
+  while ((long long)wall_clock64() < t) __builtin_amdgcn_s_sleep(2);
+}
+
 #endif
 
 // Launch trace (introspection only, see adp_launch_trace / adp_launch_times in adp.h): when tracing is on, every

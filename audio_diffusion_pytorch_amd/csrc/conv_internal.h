@@ -27,6 +27,11 @@ bool adp_conv_stream_eligible(const adp_conv_desc& d);
 int adp_conv_stream(const adp_conv_desc& d, void* stream);
 int64_t adp_conv_stream_gn_entries(const adp_conv_desc& d);  // GroupNorm partial slices per output row (gn_part)
 
+// conv_tile.hip: barrier-free wave-tile kernel (wave-private LDS tile, Winograd F(2,3)) for the same 32 -> 32 channel layers
+bool adp_conv_tile_eligible(const adp_conv_desc& d);
+int adp_conv_tile(const adp_conv_desc& d, void* stream);
+int64_t adp_conv_tile_gn_entries(const adp_conv_desc& d);  // GroupNorm partial slices per output row quad (gn_part)
+
 // conv_direct.hip: VALU direct convolution for the narrow (2-8 channel) ends of the U-Net
 bool adp_conv_direct_eligible(const adp_conv_desc& d);
 int adp_conv_direct(const adp_conv_desc& d, void* stream);

@@ -1,0 +1,353 @@
+// Barrier-free ConvBlock convolution for the HBM-bound depth-1 layers: 32 -> 32 channels, kernel 3, stride 1, 'same'
+// (ResnetItem ConvBlocks at channels = 32 and their data gradients; /root/reference/audio_diffusion_pytorch/
+// components.py:89, SURVEY.md 8a row a13, 8d "HBM-bound" rows).
+//
+// At [4, 32, 65536] a ConvBlock conv moves 67-100 MB (A_in + A_out (+A_res)) for 1.6 GFLOP -- arithmetic intensity ~20
+// flop/B, the MI355X ridge.  The persistent LDS-pipeline kernel (conv_stream.hip) ran it at 0.37 of the HBM peak: four 256-
+// position tiles per workgroup = ramp + four barrier-paced intervals + drain, every interval paced by the slower of its
+// loader and MMA waves.  This kernel has no pipeline to fill and no workgroup barrier in the data path:
+//   * ONE WAVE owns one 32-channel x 64-position output tile from its first load to its last store.  It fetches the 32 x 64
+//     input tile with eight coalesced 16-byte loads per lane (every row piece is two whole cache lines) plus one 4-byte halo
+//     load, applies GroupNorm+SiLU in registers, parks the tile in a wave-PRIVATE LDS region (the LDS runs one wave's
+//     instructions in order: no barrier, adp_wave_sync is a compiler fence), reads it back in the matrix cores' fragment
+//     shape, and stores straight from the accumulators.
+//   * 16 waves per CU (four per SIMD, <= 128 registers) cover the whole [4, 32, 65536] problem in ONE resident generation of
+//     4096 waves: the chip's own wave scheduler overlaps one wave's HBM latency with another's MFMAs and a third's stores;
+//     nothing is synchronised, so nothing waits for the slowest participant.
+//   * Winograd F(2,3) in the wave's registers (as conv_mm's WN variant): column l31 of the MFMA tile is an output PAIR;
+//     per input channel the lane reads the four inputs around its pair (two 8-byte LDS reads), forms
+//     V = (d0-d2, d1+d2, d2-d1, d1-d3) with four VALU ops and issues FOUR exact-f32 MFMAs where the direct form issues six:
+//     64 MFMAs per tile = 4096 matrix-pipe cycles per wave, ~52 % of a SIMD's time at the HBM-bound tile rate.  The
+//     transformed weights U = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) are built once per workgroup into 16 KB of LDS (the one
+//     workgroup barrier, reached while the tile loads are already in flight) and read as 16-byte A fragments.
+//   * y0 = P0+P1+P2, y1 = P1-P2-P3 per pair: 8-byte stores, 256 contiguous bytes per half-wave row; the bias enters through
+//     one MFMA step on P1 (it is in both sums).  GroupNorm partial statistics of the output: shifted sums per 4-channel row
+//     quad (shift = a sample of the quad, so |mean| >> sigma costs no digits), Chan-combined over the workgroup's waves.
+// Algorithmic bytes per launch: 4 * B * 32 * L * (2 + has_res) + 12 KB of weights.
+#include <stdlib.h>
+#include "adp_rt.h"
+#include "adp.h"
+#include "conv_internal.h"
+
+// tools/probe/tile_probe.hip builds this file with -DADP_TILE_TRACE: every wave stamps its phase boundaries (100 MHz
+// wall clock) and its hardware placement into d.ws; the product build compiles the stamps away.
+#ifdef ADP_TILE_TRACE
+#define WT_STAMP(k)                                                                                  \
+  do {                                                                                               \
+    if (lane == 0) reinterpret_cast<long long*>(d.ws)[((int64_t)blockIdx.x * NW + wave) * 8 + (k)] = \
+        (k) == 7 ? (long long)__builtin_amdgcn_s_getreg(63492) : (long long)wall_clock64();          \
+  } while (0)
+#else
+#define WT_STAMP(k)
+#endif
+
+namespace {
+
+constexpr int WT_C = 32;            // channels in = channels out
+constexpr int WT_KT = 3;
+constexpr int WT_TN = 64;           // positions per wave tile (32 output pairs)
+constexpr int WT_RS = WT_TN + 2;    // LDS row: index i <-> position n0 - 1 + i, i = 0 .. 65
+constexpr int WT_XT = WT_C * WT_RS;  // floats of one wave's tile
+
+// SiLU of two values: packed multiplies / adds around the two transcendental pairs (v_exp_f32, v_rcp_f32)
+__device__ __forceinline__ f32x2 wt_silu2(f32x2 h) {
+  const f32x2 t = h * -1.4426950408889634f;
+  const f32x2 den = f32x2{adp_exp2(t[0]), adp_exp2(t[1])} + 1.0f;
+  return h * f32x2{adp_rcp(den[0]), adp_rcp(den[1])};
+}
+
+template <bool TR, int PRO, int NW, bool RES, bool GN>
+__global__ __launch_bounds__(64 * NW) void conv_tile32_kernel(adp_conv_desc d, int tiles_per_b, int cfg) {
+  // One LDS block, U first: its fragment reads (and the tile's) then take their K-step offsets as 16-bit immediates.
+  //   U[r][m][4] | (pa, pb) per input channel | statistics scratch [NW][8][2] | NW wave tiles [32][66]
+  __shared__ __attribute__((aligned(16))) float lds[WT_C * WT_C * 4 + 2 * WT_C + NW * 16 + NW * WT_XT];
+  float* const us = lds;
+  float* const pab = lds + WT_C * WT_C * 4;
+  float* const gsh = pab + 2 * WT_C;
+  float* const xs = gsh + NW * 16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = adp_uniform(tid >> 6);  // scalar: everything addressed per tile sits on SGPR bases + 32-bit lane offsets
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int L = (int)d.Lin;
+  // the workgroup's NW tiles are consecutive and lie in one batch element (tiles_per_b % NW == 0)
+  const int t = (int)blockIdx.x * NW + wave;
+  const int b = t / tiles_per_b;
+  const int n0 = (t - b * tiles_per_b) * WT_TN;
+  const int64_t tbase = (int64_t)b * WT_C * L + n0;  // element (channel 0, position n0) of this tile
+  const unsigned Lb = 4u * (unsigned)L;              // row pitch in bytes (32 rows < 2^32 bytes: eligibility)
+
+  // ---- tile loads: lane -> quads q = lane + 64 i of the 32 x 16 body (row = q >> 4), one halo scalar.
+  // Waves w, w + 4, w + 8, w + 12 of a workgroup share a SIMD (cyclic placement; tools/probe/tile_probe prints it).  On this
+  // chip the exact-f32 MFMA and the f32 VALU ops of a SIMD ADD (tile_probe: a stage that runs its SiLU while two others
+  // multiply needs 5-7 us for 0.5 us of work), so the kernel is bound by the instructions a SIMD issues: everything around
+  // the 65 MFMAs of a tile is written for instruction count (scalar bases, packed f32 ops, DPP reductions).  Stage
+  // s = w >> 2 asks for its tile s * `gap` after the launch, so that the tiles of a SIMD land one after the other.
+  const char* xt = reinterpret_cast<const char*>(d.x + tbase);
+  const int stage = wave >> 2;
+  const long long t_start = adp_clock();
+  WT_STAMP(0);
+  WT_STAMP(7);
+  f32x4 rx[8];
+  const int hrel = hi ? WT_TN : -1;  // right / left halo of row l31
+  const bool hok = n0 + hrel >= 0 && n0 + hrel < L;
+  float hx = 0.0f;
+  const unsigned ldb = (unsigned)(lane >> 4) * Lb + 16u * (unsigned)(lane & 15);
+  const unsigned hb = (unsigned)l31 * Lb + 4u * (unsigned)(hok ? hrel + 1 : 1);  // relative to position n0 - 1 (offsets are unsigned)
+  auto load_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rx[i] = *reinterpret_cast<const f32x4*>(xt + (ldb + 4u * (unsigned)i * Lb));
+    hx = *reinterpret_cast<const float*>(xt - 4 + hb);
+  };
+#ifdef ADP_TILE_TRACE
+  const int elim = cfg >> 16;  // probe builds only: elimination runs (1: no MFMAs, 2: no stores / residual, 4: no tile loads)
+#else
+  constexpr int elim = 0;
+#endif
+  const int gap = cfg & 0xffff;  // stagger between the stages in 10 ns ticks
+  if (elim & 4) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rx[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+  // Who builds U and the GroupNorm constants: with staged waves (NW > 4) stages 1.. -- they have nothing else to do yet, and
+  // stage 0 reaches the barrier with nothing but its tile loads in flight (a use of weight registers behind those loads would
+  // make it wait for the tile first: vmcnt counts in order).  All weight loads of a thread are issued before the first use.
+  constexpr bool STAGED = NW > 4;
+  constexpr int NST = STAGED ? 64 * NW - 256 : 64 * NW, NIT = (WT_C * WT_C + NST - 1) / NST;
+  const int sid = STAGED ? tid - 256 : tid;
+  if (STAGED && stage == 0 && !(elim & 4)) load_tile();
+  if (!STAGED || stage > 0) {
+    float wv[NIT][3];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int p = sid + k * NST;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) wv[k][j] = p < WT_C * WT_C ? d.w[3 * p + j] : 0.0f;
+    }
+    float pg = 1.0f, pbt = 0.0f, pmean = 0.0f, prstd = 1.0f;
+    if (PRO == 1 && sid < WT_C) {
+      const int64_t sg = ((int64_t)b * d.groups + sid / (WT_C / (int)d.groups)) * 2;
+      if (d.pro_gamma) pg = d.pro_gamma[sid];
+      if (d.pro_beta) pbt = d.pro_beta[sid];
+      pmean = d.pro_stats[sg];
+      prstd = d.pro_stats[sg + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int p = sid + k * NST;
+      if (p < WT_C * WT_C) {
+        // p = m * 32 + r reads w[m][r][0..2]; the data gradient (w[r][m][.], taps flipped) takes p = r * 32 + m
+        const float a = wv[k][0], c = wv[k][1], e = wv[k][2];
+        const float g0 = TR ? e : a, g2 = TR ? a : e;
+        const int m = TR ? (p & 31) : (p >> 5), r = TR ? (p >> 5) : (p & 31);
+        f32x4 u;
+        u[0] = g0;
+        u[1] = 0.5f * (g0 + c + g2);
+        u[2] = 0.5f * (g0 - c + g2);
+        u[3] = g2;
+        *reinterpret_cast<f32x4*>(us + (r * WT_C + m) * 4) = u;
+      }
+    }
+    if (PRO == 1 && sid < WT_C) {
+      pab[2 * sid] = pg * prstd;
+      pab[2 * sid + 1] = pbt - pmean * pg * prstd;
+    }
+  }
+  WT_STAMP(1);
+  adp_barrier_lds();  // (not __syncthreads(): its vmcnt(0) would hold every wave until stage 0's tiles have landed)
+  if (!STAGED || stage > 0) {
+    if (STAGED) adp_wait_until(t_start + (long long)stage * gap);
+    if (!(elim & 4)) load_tile();
+  }
+  WT_STAMP(2);
+
+  // ---- activate and park the tile in this wave's LDS region: index i of a row <-> position n0 - 1 + i
+  float* X = xs + wave * WT_XT;
+  {
+    float* o = X + (lane >> 4) * WT_RS + 4 * (lane & 15) + 1;  // + 4 i rows: immediates
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f32x2 lo = f32x2{rx[i][0], rx[i][1]}, hp = f32x2{rx[i][2], rx[i][3]};
+      if (PRO == 1) {
+        const f32x2 ab = *reinterpret_cast<const f32x2*>(pab + 2 * ((lane >> 4) + 4 * i));
+        lo = wt_silu2(lo * ab[0] + ab[1]);
+        hp = wt_silu2(hp * ab[0] + ab[1]);
+      }
+      o[4 * i * WT_RS] = lo[0];
+      *reinterpret_cast<f32x2*>(o + 4 * i * WT_RS + 1) = f32x2{lo[1], hp[0]};  // even index: 8-byte aligned
+      o[4 * i * WT_RS + 3] = hp[1];
+    }
+    if (PRO == 1) {
+      const f32x2 ab = *reinterpret_cast<const f32x2*>(pab + 2 * l31);
+      const float h = fmaf(hx, ab[0], ab[1]);
+      hx = h * adp_rcp(1.0f + adp_exp2(-1.4426950408889634f * h));
+    }
+    X[l31 * WT_RS + (hi ? WT_RS - 1 : 0)] = hok ? hx : 0.0f;  // zero padding is applied after the activation
+  }
+  adp_wave_sync();
+  WT_STAMP(3);
+
+  // ---- 16 K steps of two channels: four MFMAs each on the four Winograd planes
+  f32x16 P0, P1, P2, P3;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) P0[r] = P1[r] = P2[r] = P3[r] = 0.0f;
+  {
+    const float bias_a = (d.bias && hi == 0) ? d.bias[l31] : 0.0f;
+    P1 = adp_mfma32(bias_a, 1.0f, P1);  // bias[m] in both y0 = P0+P1+P2 and y1 = P1-P2-P3
+  }
+  const float* Xr = X + hi * WT_RS + 2 * l31;
+  const float* Ur = us + (hi * WT_C + l31) * 4;
+  if (!(elim & 1)) {
+    // fragments of step k + 1 are requested before the MFMAs of step k are issued: a wave that has the SIMD's matrix pipe to
+    // itself keeps it busy (tile_probe: 3.5 us per tile with just-in-time reads against 1.7 us of MFMA issue)
+    f32x4 u = *reinterpret_cast<const f32x4*>(Ur);
+    f32x2 da = *reinterpret_cast<const f32x2*>(Xr), db = *reinterpret_cast<const f32x2*>(Xr + 2);
+#pragma unroll
+    for (int k = 0; k < WT_C / 2; ++k) {
+      f32x4 un = u;
+      f32x2 dan = da, dbn = db;
+      if (k + 1 < WT_C / 2) {
+        un = *reinterpret_cast<const f32x4*>(Ur + (k + 1) * 2 * WT_C * 4);
+        dan = *reinterpret_cast<const f32x2*>(Xr + (k + 1) * 2 * WT_RS);
+        dbn = *reinterpret_cast<const f32x2*>(Xr + (k + 1) * 2 * WT_RS + 2);
+      }
+      adp_sched_fence();  // (the reads stay AHEAD of the four MFMAs: the scheduler otherwise sinks them behind the third)
+      // V = (d0 - d2, d1 + d2, d2 - d1, d1 - d3).  (A hand-written packed form -- v_pk_add_f32 with op_sel / neg_hi through
+      // inline asm -- fed the MFMA a stale register: the compiler's hazard recogniser does not see into the asm.)
+      P0 = adp_mfma32(u[0], da[0] - db[0], P0);
+      P1 = adp_mfma32(u[1], da[1] + db[0], P1);
+      P2 = adp_mfma32(u[2], db[0] - da[1], P2);
+      P3 = adp_mfma32(u[3], da[1] - db[1], P3);
+      adp_sched_fence();
+      u = un;
+      da = dan;
+      db = dbn;
+    }
+  }
+
+  WT_STAMP(4);
+  // ---- epilogue: accumulator register i <-> row (i & 3) + 8 (i >> 2) + 4 hi, column l31 = output pair
+  char* ot = reinterpret_cast<char*>(d.out + tbase);
+  const char* rt = reinterpret_cast<const char*>(RES ? d.res + tbase : d.out + tbase);
+  const unsigned ob = 4u * (unsigned)hi * Lb + 8u * (unsigned)l31;  // lane part; rows add scalar multiples of the pitch
+  const bool has_res = RES && !(elim & 2);
+  constexpr bool want_gn = GN;
+  float gk[4];
+  f32x2 gs[4], gq[4];  // per row quad: shift, shifted sums / sums of squares of this lane's (even, odd) positions
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {  // two halves of eight rows: 16 residual registers live at a time
+    f32x2 rv[8];
+    if (has_res) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = 8 * h + i;
+        rv[i] = *reinterpret_cast<const f32x2*>(rt + (ob + (unsigned)((r & 3) + 8 * (r >> 2)) * Lb));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = 8 * h + i;
+      const float s12 = P1[r] + P2[r], d12 = P1[r] - P2[r];
+      f32x2 y = f32x2{P0[r] + s12, d12 - P3[r]};
+      if (has_res) y = y + rv[i];
+      if (!(elim & 2))
+        *reinterpret_cast<f32x2*>(ot + (ob + (unsigned)((r & 3) + 8 * (r >> 2)) * Lb)) = y;
+      if (want_gn) {
+        const int q = r >> 2;
+        if ((r & 3) == 0) {  // shift of this row quad: its first value in lane 0 / 32 of the half-wave
+          const float k0 = adp_read_lane(y[0], 0), k1 = adp_read_lane(y[0], 32);
+          gk[q] = hi ? k1 : k0;
+          gs[q] = gq[q] = f32x2{0.0f, 0.0f};
+        }
+        const f32x2 e = y - gk[q];
+        gs[q] = gs[q] + e;
+        gq[q] = e * e + gq[q];
+      }
+    }
+  }
+  WT_STAMP(5);
+  if (want_gn) {
+    // one (mean, M2) per (wave, row quad) -> Chan-combined over the workgroup's NW waves -> one gn_part entry per quad
+    constexpr float cnt = 4.0f * WT_TN;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float sv = adp_half_sum(gs[q][0] + gs[q][1]), qv = adp_half_sum(gq[q][0] + gq[q][1]);
+      if (l31 == 31) {  // (the DPP sums are complete in the upper lanes of each half-wave)
+        float* e = gsh + (wave * 8 + 2 * q + hi) * 2;  // row quad index (8 q + 4 hi) / 4
+        e[0] = gk[q] + sv / cnt;
+        e[1] = fmaxf(qv - sv * (sv / cnt), 0.0f);
+      }
+    }
+    __syncthreads();
+    if (tid < 8) {
+      float mean = gsh[tid * 2], m2 = gsh[tid * 2 + 1], n = cnt;
+      for (int w = 1; w < NW; ++w) {
+        const float mw = gsh[(w * 8 + tid) * 2], dl = mw - mean, nn = n + cnt;
+        mean += dl * (cnt / nn);
+        m2 += gsh[(w * 8 + tid) * 2 + 1] + dl * dl * (n * cnt / nn);
+        n = nn;
+      }
+      const int E = tiles_per_b / NW;
+      float* e = d.gn_part + (((int64_t)b * (WT_C / 4) + tid) * E + ((int)blockIdx.x - b * E)) * 3;
+      e[0] = mean;
+      e[1] = m2;
+      e[2] = n;
+    }
+  }
+}
+
+// waves per workgroup: 16 (one resident generation of 4096 waves at [4, 32, 65536]) down to 1 for short rows / small
+// grids; the workgroup's tiles must lie in one batch element
+static int tile_nw(const adp_conv_desc& d) {
+  const int64_t tiles_per_b = d.N / WT_TN, tiles = tiles_per_b * d.B;
+  const char* e = getenv("ADP_TILE_NW");  // tests: every variant on small problems
+  const int want = e ? atoi(e) : 16;
+  for (int nw : {16, 4})
+    if (nw <= want && tiles_per_b % nw == 0 && (e || tiles / nw >= 256)) return nw;
+  return 1;
+}
+
+template <bool TR, int PRO, bool RES, bool GN>
+int launch_tile(const adp_conv_desc& d, void* stream) {
+  const int tiles_per_b = (int)(d.N / WT_TN);
+  const int nw = tile_nw(d);
+  const unsigned grid = (unsigned)(d.B * tiles_per_b / nw);
+  int cfg = 120;  // stagger between the wave stages: 1.2 us
+  if (const char* e = getenv("ADP_TILE_CFG")) cfg = atoi(e);  // kernel work: gap | elimination bits << 16 (probe builds)
+  switch (nw) {
+    case 16: ADP_LAUNCH((conv_tile32_kernel<TR, PRO, 16, RES, GN>), dim3(grid), dim3(1024), stream, d, tiles_per_b, cfg); break;
+    case 4: ADP_LAUNCH((conv_tile32_kernel<TR, PRO, 4, RES, GN>), dim3(grid), dim3(256), stream, d, tiles_per_b, cfg); break;
+    default: ADP_LAUNCH((conv_tile32_kernel<TR, PRO, 1, RES, GN>), dim3(grid), dim3(64), stream, d, tiles_per_b, cfg); break;
+  }
+  return ADP_LAUNCH_OK();
+}
+
+template <bool TR, int PRO>
+int launch_tile2(const adp_conv_desc& d, void* stream) {
+  if (d.res) return d.gn_part ? launch_tile<TR, PRO, true, true>(d, stream) : launch_tile<TR, PRO, true, false>(d, stream);
+  return d.gn_part ? launch_tile<TR, PRO, false, true>(d, stream) : launch_tile<TR, PRO, false, false>(d, stream);
+}
+
+}  // namespace
+
+bool adp_conv_tile_eligible(const adp_conv_desc& d) {
+  if (const char* e = getenv("ADP_CONV_TILE"))  // A/B switch against conv_stream.hip (read per call: one process measures both)
+    if (e[0] == '0') return false;
+  if (d.R != WT_C || d.R1 != d.R || d.M != WT_C || d.KT != WT_KT) return false;
+  if (d.stride != 1 || d.dil != 1 || d.pad != 1 || d.up != 1 || d.store != 0) return false;
+  if (d.out_pre || d.e_scale || d.x2) return false;
+  if (d.prologue != 0 && d.prologue != 1) return false;
+  if (d.prologue == 1 && (d.groups < 1 || WT_C % d.groups != 0)) return false;
+  if (d.N != d.Lin || d.N % WT_TN != 0) return false;
+  if (reinterpret_cast<uintptr_t>(d.x) & 15) return false;
+  if ((reinterpret_cast<uintptr_t>(d.out) | reinterpret_cast<uintptr_t>(d.res)) & 7) return false;
+  if (d.B * (d.N / WT_TN) >= (int64_t)1 << 30 || d.B * WT_C * d.Lin >= (int64_t)1 << 40) return false;
+  if ((WT_C + 1) * d.Lin * 4 >= (int64_t)1 << 32) return false;  // a tile's rows are addressed by 32-bit byte offsets
+  return true;
+}
+
+int64_t adp_conv_tile_gn_entries(const adp_conv_desc& d) { return d.N / WT_TN / tile_nw(d); }
+
+int adp_conv_tile(const adp_conv_desc& d, void* stream) {
+  if (d.transposed) return d.prologue == 1 ? launch_tile2<true, 1>(d, stream) : launch_tile2<true, 0>(d, stream);
+  return d.prologue == 1 ? launch_tile2<false, 1>(d, stream) : launch_tile2<false, 0>(d, stream);
+}

@@ -46,6 +46,13 @@ struct f32x2 {
   float& operator[](int i) { return v[i]; }
   const float& operator[](int i) const { return v[i]; }
 };
+// elementwise arithmetic of the clang vector type (the product build compiles these to packed-f32 VALU ops)
+static inline f32x2 operator+(f32x2 a, f32x2 b) { return f32x2{{a[0] + b[0], a[1] + b[1]}}; }
+static inline f32x2 operator-(f32x2 a, f32x2 b) { return f32x2{{a[0] - b[0], a[1] - b[1]}}; }
+static inline f32x2 operator*(f32x2 a, f32x2 b) { return f32x2{{a[0] * b[0], a[1] * b[1]}}; }
+static inline f32x2 operator*(f32x2 a, float b) { return f32x2{{a[0] * b, a[1] * b}}; }
+static inline f32x2 operator+(f32x2 a, float b) { return f32x2{{a[0] + b, a[1] + b}}; }
+static inline f32x2 operator-(f32x2 a, float b) { return f32x2{{a[0] - b, a[1] - b}}; }
 struct f32x4 {
   float v[4];
   float& operator[](int i) { return v[i]; }
@@ -346,7 +353,19 @@ static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
 
 static inline void adp_barrier_consume() { adp_emul::sync_block(); }
+static inline void adp_barrier_lds() { adp_emul::sync_block(); }
 static inline void adp_sched_fence() {}
+static inline void adp_wave_sync() { adp_emul::sync_wave(); }
+static inline void adp_setprio(int) {}
+static inline float adp_exp2(float x) { return exp2f(x); }
+static inline int adp_uniform(int v) { return v; }
+static inline float adp_read_lane(float v, int src) { return adp_emul::shfl_idx(v, src); }
+static inline float adp_half_sum(float v) {  // (valid in every lane here; the hardware form only in lanes 16-31 / 48-63)
+  for (int o = 1; o < 32; o <<= 1) v += adp_emul::shfl_idx(v, adp_emul::lane_id() ^ o);
+  return v;
+}
+static inline long long adp_clock() { return 0; }
+static inline void adp_wait_until(long long) {}  // (the emulator runs a workgroup's waves one after another)
 
 #define ADP_LAUNCH(kern, grid, block, stream, ...) \
   do {                                             \

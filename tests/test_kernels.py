@@ -322,10 +322,11 @@ def test_conv_mm_family(dev, B, R, M, L, KT, pad, dil):
 
 
 @pytest.mark.parametrize("B,L,pro,res", [(1, 256, 0, 0), (2, 1024, 1, 1), (3, 768, 1, 0), (1, 256 * 300, 1, 1)])
-def test_conv_stream32(dev, B, L, pro, res):
+def test_conv_stream32(dev, B, L, pro, res, monkeypatch):
     """conv_stream.hip: persistent 32 -> 32 channel kernel-3 conv (depth-1 ConvBlocks), forward and data gradient,
     with / without the GroupNorm+SiLU prologue and the residual; the last case gives every workgroup > 1 tile."""
     from audio_diffusion_pytorch_amd import _C
+    monkeypatch.setenv("ADP_CONV_TILE", "0")  # (the wave-tile kernel of conv_tile.hip takes these shapes by default)
     if dev.type != "cuda" and L > 4096:
         pytest.skip("emulator: large case runs on the GPU only")
     C, G = 32, 8
@@ -355,6 +356,48 @@ def test_conv_stream32(dev, B, L, pro, res):
     assert rel_err(dx, dx_ref + (r if res else 0)) < TOL
 
 
+@pytest.mark.parametrize("nw", [1, 4, 16])
+@pytest.mark.parametrize("B,L,pro,res,shift", [(1, 256, 0, 0, 0.0), (2, 1024, 1, 1, 0.0), (3, 192, 1, 0, 100.0),
+                                               (1, 64 * 300, 1, 1, 0.0)])
+def test_conv_tile32(dev, nw, B, L, pro, res, shift, monkeypatch):
+    """conv_tile.hip: barrier-free wave-tile kernel (one wave = one 32 x 64 output tile through a wave-private LDS region,
+    Winograd F(2,3)) for the 32 -> 32 channel kernel-3 ConvBlock convs: forward with / without GroupNorm+SiLU prologue and
+    residual, data gradient, and the GroupNorm partial statistics of the output (shifted sums per row quad, Chan-combined
+    over the 1-16 waves of a workgroup) -- `shift` puts the output mean at 100 sigma: the statistics must keep their digits
+    (the one-pass sum-of-squares form this replaced lost them)."""
+    from ctypes import byref
+    if dev.type != "cuda" and L > 4096:
+        pytest.skip("emulator: large case runs on the GPU only")
+    monkeypatch.setenv("ADP_TILE_NW", str(nw))
+    C, G = 32, 8
+    x = rnd(B, C, L, seed=1) * 1.3 + 0.2
+    w, b = rnd(C, C, 3, seed=2, scale=0.2), rnd(C, seed=3) + shift
+    gamma, beta = rnd(C, seed=4) * 0.5 + 1, rnd(C, seed=5) * 0.1
+    r = rnd(B, C, L, seed=6) if res else None
+    xd, wd = x.to(dev), w.to(dev)
+    d = _C.ConvDesc(_C.ptr(xd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(xd), None, B, C, C, L, C, L,
+                    3, 1, 1, 1, 1, 0, 0, 1, 0, 1, 0)
+    assert _C.query("adp_conv1d_tile", byref(d)) == 32064, "case must dispatch to the wave-tile kernel"
+    gn = ops.GnPart()
+    if pro:
+        ref = F.conv1d(ref_gn_silu(x, G, gamma, beta), w, b, padding=1)
+        out = ops.conv1d(xd, wd, b.to(dev), pad=1, prologue=1, pro_stats=ops.gn_stats(xd, G), pro_gamma=gamma.to(dev),
+                         pro_beta=beta.to(dev), groups=G, res=r.to(dev) if res else None, gn=gn)
+    else:
+        ref = F.conv1d(x, w, b, padding=1)
+        out = ops.conv1d(xd, wd, b.to(dev), pad=1, res=r.to(dev) if res else None, gn=gn)
+    if res:
+        ref = ref + r
+    assert rel_err(out, ref) < TOL
+    assert gn.part is not None and gn.part[..., 2].sum(dim=2).eq(4 * L).all()
+    st = ops.gn_finalize(gn.part, G)
+    g64 = ref.double().view(B, G, -1)
+    assert rel_err(st[..., 0], g64.mean(-1)) < 2e-6
+    assert rel_err(st[..., 1], (g64.var(-1, unbiased=False) + 1e-5).rsqrt()) < 2e-5
+    dx = ops.conv1d(xd, wd, None, pad=1, transposed=True)
+    assert rel_err(dx, F.conv_transpose1d(x, w, None, padding=1)) < TOL
+
+
 @pytest.mark.parametrize("wpb", [1, 2, 3])
 @pytest.mark.parametrize("B,L,pro,res", [(1, 1280, 1, 1), (2, 1536, 0, 0), (1, 256, 1, 0)])
 def test_conv_stream32_tile_pipeline(dev, wpb, B, L, pro, res, monkeypatch):
@@ -362,6 +405,7 @@ def test_conv_stream32_tile_pipeline(dev, wpb, B, L, pro, res, monkeypatch):
     tile i while the other stores tile i-1): 1 to 6 tiles per workgroup (odd counts: ghost iteration; a group without a
     tile: empty statistics entry), outputs and GroupNorm partial statistics."""
     monkeypatch.setenv("ADP_STREAM_WPB", str(wpb))
+    monkeypatch.setenv("ADP_CONV_TILE", "0")
     C, G = 32, 8
     x = rnd(B, C, L, seed=1) * 1.3 + 0.2
     w, b = rnd(C, C, 3, seed=2, scale=0.2), rnd(C, seed=3)
