@@ -45,7 +45,7 @@ __device__ __forceinline__ float adp_rcp(float x) { return __builtin_amdgcn_rcpf
 // __syncthreads() carries a workgroup-scope release fence, which on gfx9-family hardware waits (vmcnt) for every
 // outstanding global STORE of the wave to be acknowledged by L2 -- microseconds of HBM write latency per loop
 // iteration in a streaming kernel whose epilogue stores precede the next tile's barrier (measured in
-// conv_stream.hip: 10 of 26 us).  The waves that PRODUCE the LDS data use __syncthreads() (their ds_writes are
+// the round-2 streaming conv: 10 of 26 us).  The waves that PRODUCE the LDS data use __syncthreads() (their ds_writes are
 // complete before they arrive); this variant is the bare s_barrier plus a compiler-level ordering point.
 __device__ __forceinline__ void adp_barrier_consume() {
   asm volatile("" ::: "memory");

@@ -22,12 +22,8 @@ int adp_wgrad_mm(const adp_wgrad_desc& d, void* stream);
 int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, float* dw, float* dbias, int accumulate,
                      void* stream);
 
-// conv_stream.hip: persistent streaming kernel for the HBM-bound 32 -> 32 channel kernel-3 ConvBlock convs (depth 1)
-bool adp_conv_stream_eligible(const adp_conv_desc& d);
-int adp_conv_stream(const adp_conv_desc& d, void* stream);
-int64_t adp_conv_stream_gn_entries(const adp_conv_desc& d);  // GroupNorm partial slices per output row (gn_part)
-
-// conv_tile.hip: barrier-free wave-tile kernel (wave-private LDS tile, Winograd F(2,3)) for the same 32 -> 32 channel layers
+// conv_tile.hip: barrier-free wave-tile kernel (wave-private LDS tile, Winograd F(2,3)) for the HBM-bound 32 -> 32 channel
+// kernel-3 ConvBlock convs and their data gradients (depth 1)
 bool adp_conv_tile_eligible(const adp_conv_desc& d);
 int adp_conv_tile(const adp_conv_desc& d, void* stream);
 int64_t adp_conv_tile_gn_entries(const adp_conv_desc& d);  // GroupNorm partial slices per output row quad (gn_part)

@@ -3,9 +3,10 @@
 // components.py:89, SURVEY.md 8a row a13, 8d "HBM-bound" rows).
 //
 // At [4, 32, 65536] a ConvBlock conv moves 67-100 MB (A_in + A_out (+A_res)) for 1.6 GFLOP -- arithmetic intensity ~20
-// flop/B, the MI355X ridge.  The persistent LDS-pipeline kernel (conv_stream.hip) ran it at 0.37 of the HBM peak: four 256-
-// position tiles per workgroup = ramp + four barrier-paced intervals + drain, every interval paced by the slower of its
-// loader and MMA waves.  This kernel has no pipeline to fill and no workgroup barrier in the data path:
+// flop/B, the MI355X ridge.  The persistent LDS-pipeline kernel of rounds 1-3 (tools/rejected/conv_stream32_lds_pipeline.hip)
+// ran it at 0.37 of the HBM peak: four 256-position tiles per workgroup = ramp + four barrier-paced intervals + drain, every
+// interval paced by the slower of its loader and MMA waves.  This kernel has no pipeline to fill and no workgroup barrier
+// in the data path:
 //   * ONE WAVE owns one 32-channel x 64-position output tile from its first load to its last store.  It fetches the 32 x 64
 //     input tile with eight coalesced 16-byte loads per lane (every row piece is two whole cache lines) plus one 4-byte halo
 //     load, applies GroupNorm+SiLU in registers, parks the tile in a wave-PRIVATE LDS region (the LDS runs one wave's
@@ -330,8 +331,6 @@ int launch_tile2(const adp_conv_desc& d, void* stream) {
 }  // namespace
 
 bool adp_conv_tile_eligible(const adp_conv_desc& d) {
-  if (const char* e = getenv("ADP_CONV_TILE"))  // A/B switch against conv_stream.hip (read per call: one process measures both)
-    if (e[0] == '0') return false;
   if (d.R != WT_C || d.R1 != d.R || d.M != WT_C || d.KT != WT_KT) return false;
   if (d.stride != 1 || d.dil != 1 || d.pad != 1 || d.up != 1 || d.store != 0) return false;
   if (d.out_pre || d.e_scale || d.x2) return false;

@@ -8,7 +8,7 @@ import bench
 def _fake_records():
     conv = ("adp_conv1d", "conv_mm_kernel<32, 3, 1, 1, true, 0, 32, 2>",
             {"flops": 2 * 4 * 1024 * 256 * 1024 * 3, "bytes": 17_000_000, "shape": "B4 R1024 M1024 N256 KT3 s1 up1 tr1 pro0"}, 0.050)
-    shallow = ("adp_conv1d", "conv_stream32_kernel<false, 1>",
+    shallow = ("adp_conv1d", "conv_tile32_kernel<false, 1, 16, true, false>",
                {"flops": 2 * 4 * 32 * 65536 * 32 * 3, "bytes": 100_000_000, "shape": "B4 R32 M32 N65536 KT3 s1 up1 tr0 pro1"}, 0.030)
     norm = ("adp_gn_silu_bwd_apply", "gn_bwd_apply_kernel", {"bytes": 50_000_000, "shape": "B4 C32 L65536"}, 0.012)
     return [conv] * 10 + [shallow] * 2 + [norm] * 4

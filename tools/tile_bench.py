@@ -1,10 +1,9 @@
-"""Depth-1 ConvBlock conv A/B on the GPU box: conv_tile.hip (barrier-free wave tiles) vs conv_stream.hip (persistent LDS
-pipeline), ADP_CONV_TILE = 1 / 0, every launch replayed from a hipGraph (no host launch time in the numbers).
-  micro : conv1 (GroupNorm+SiLU prologue, statistics epilogue), conv2 (+ residual), data gradient at [B, 32, 65536];
-          `warm` re-runs on one buffer set (input in the Infinity Cache, as behind its producer in the step),
-          `cold` rotates four sets (400 MB: past the 256 MB cache)
-  step  : the headline training step, interleaved
-usage: python tools/tile_bench.py [micro|step|all]"""
+"""Depth-1 ConvBlock conv microbench on the GPU box (conv_tile.hip), every launch replayed from a hipGraph (no host launch
+time in the numbers): conv1 (GroupNorm+SiLU prologue, statistics epilogue), conv2 (+ residual), data gradient at
+[B, 32, 65536], next to a plain 2-read-1-write streaming kernel (adp_add) of the same tensors.  `warm` re-runs on one buffer
+set (input in the Infinity Cache, as behind its producer in the step), `cold` rotates four sets (400 MB: past the cache).
+TILE_CFGS = comma list of ADP_TILE_CFG values (stage gap in 10 ns ticks), TILE_BATCHES = comma list of batch sizes.
+usage: python tools/tile_bench.py"""
 import os
 import sys
 
@@ -12,7 +11,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402
 from audio_diffusion_pytorch_amd import ops  # noqa: E402
 
 
@@ -41,10 +39,10 @@ def graph_time(fns, reps=5):
     return a.elapsed_time(b) / reps / len(fns) * 1e3
 
 
-def micro():
+def main():
     dev = torch.device("cuda:0")
     C, L, G = 32, 65536, 8
-    for B in [int(v) for v in os.environ.get('TILE_BATCHES', '4').split(',')]:
+    for B in [int(v) for v in os.environ.get("TILE_BATCHES", "4").split(",")]:
         sets = []
         for _ in range(4):
             x = torch.randn(B, C, L, device=dev)
@@ -53,63 +51,31 @@ def micro():
         w = torch.randn(C, C, 3, device=dev) * 0.1
         bias, gamma, beta = torch.randn(C, device=dev), torch.ones(C, device=dev), torch.zeros(C, device=dev)
         A = 4 * B * C * L
-        leads = os.environ.get("TILE_LEADS", "1").split(",")  # low 4 bits: lead; bits 4-6: elimination builds (conv_tile.hip)
-        for mode, lead in [("0", "")] + [("1", l) for l in leads]:
-            os.environ["ADP_CONV_TILE"] = mode
-            os.environ["ADP_TILE_CFG"] = lead or "1"
+
+        def conv1(s):
+            return lambda: ops.conv1d(s["x"], w, bias, pad=1, prologue=1, pro_stats=s["stats"], pro_gamma=gamma,
+                                      pro_beta=beta, groups=G, out=s["out"], gn=ops.GnPart())
+
+        def conv2(s):
+            return lambda: ops.conv1d(s["x"], w, bias, pad=1, prologue=1, pro_stats=s["stats"], pro_gamma=gamma,
+                                      pro_beta=beta, groups=G, out=s["out"], res=s["res"])
+
+        def dgrad(s):
+            return lambda: ops.conv1d(s["x"], w, None, pad=1, transposed=True, out=s["out"])
+
+        def add(s):
+            return lambda: ops.add(s["x"], s["res"], out=s["out"])
+        for cfg in os.environ.get("TILE_CFGS", "120").split(","):
+            os.environ["ADP_TILE_CFG"] = cfg
             row = []
             for temp, nset in (("warm", 1), ("cold", 4)):
-                def conv1(s):
-                    return lambda: ops.conv1d(s["x"], w, bias, pad=1, prologue=1, pro_stats=s["stats"], pro_gamma=gamma,
-                                              pro_beta=beta, groups=G, out=s["out"], gn=ops.GnPart())
-
-                def conv2(s):
-                    return lambda: ops.conv1d(s["x"], w, bias, pad=1, prologue=1, pro_stats=s["stats"], pro_gamma=gamma,
-                                              pro_beta=beta, groups=G, out=s["out"], res=s["res"])
-
-                def dgrad(s):
-                    return lambda: ops.conv1d(s["x"], w, None, pad=1, transposed=True, out=s["out"])
-
-                def add(s):
-                    return lambda: ops.add(s["x"], s["res"], out=s["out"])
-                for name, mk, nb in (("conv1", conv1, 2), ("conv2", conv2, 3), ("dgrad", dgrad, 2)) + \
-                        ((("add", add, 3),) if mode == "0" else ()):
+                for name, mk, nb in (("conv1", conv1, 2), ("conv2", conv2, 3), ("dgrad", dgrad, 2), ("add", add, 3)):
                     t = graph_time([mk(sets[i % nset]) for i in range(20)])
                     row.append(f"{name} {t:5.1f} us {nb * A / t / 1e6:5.2f} TB/s")
                 row.append("|")
-            print(f"B{B} {'tile lead ' + lead.ljust(3) if mode == '1' else 'stream       '} warm: " + "  ".join(row), flush=True)
-    os.environ.pop("ADP_CONV_TILE", None)
-
-
-def step():
-    import audio_diffusion_pytorch_amd as adp
-    dev = torch.device("cuda:0")
-    torch.manual_seed(0)
-    for B in (4, 1):
-        model = adp.DiffusionModel(net_t=adp.UNetV0, in_channels=2, channels=bench.CHANNELS, factors=bench.FACTORS,
-                                   items=bench.ITEMS).to(dev)
-        x = torch.randn(B, 2, bench.LENGTH, device=dev)
-
-        def zero():
-            for p in model.parameters():
-                p.grad = None
-
-        def one():
-            zero()
-            model(x).backward()
-        for r in range(2):
-            for mode in ("0", "1"):
-                os.environ["ADP_CONV_TILE"] = mode
-                dt = bench._time(bench._graphed(one, zero), 20)
-                print(f"batch {B} round {r} ADP_CONV_TILE={mode}: {dt * 1e3:.3f} ms", flush=True)
-        del model
-        torch.cuda.empty_cache()
-    os.environ.pop("ADP_CONV_TILE", None)
+            print(f"B{B} cfg {cfg:>4} warm: " + "  ".join(row), flush=True)
+    os.environ.pop("ADP_TILE_CFG", None)
 
 
 if __name__ == "__main__":
-    what = sys.argv[1] if len(sys.argv) > 1 else "all"
-    if what in ("micro", "all"):
-        micro()
-    if what in ("step", "all"):
-        step()
+    main()
