@@ -127,8 +127,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, const flo
 // element b.  Chan's combination over the (C/G)/4 quads x E slices of a group (contiguous in memory), one wave.
 __device__ __forceinline__ void gn_combine_wave(const float* p, int64_t cnt, int lane, float eps, float& mean,
                                                 float& rstd) {
+  // the first four entries of a lane stay in registers for the second pass (the deep layers have 64-256 entries per group:
+  // one trip to memory instead of two)
+  float pm[4], pq[4], pn[4];
   float s = 0.0f, n = 0.0f;
-  for (int64_t i = lane; i < cnt; i += 64) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = lane + 64 * k;
+    pm[k] = pq[k] = pn[k] = 0.0f;
+    if (i < cnt) {
+      pm[k] = p[i * 3];
+      pq[k] = p[i * 3 + 1];
+      pn[k] = p[i * 3 + 2];
+    }
+    s = fmaf(pm[k], pn[k], s);
+    n += pn[k];
+  }
+  for (int64_t i = lane + 256; i < cnt; i += 64) {
     s = fmaf(p[i * 3], p[i * 3 + 2], s);
     n += p[i * 3 + 2];
   }
@@ -136,7 +151,12 @@ __device__ __forceinline__ void gn_combine_wave(const float* p, int64_t cnt, int
   n = adp_wave_sum(n);
   mean = s / n;
   float q = 0.0f;
-  for (int64_t i = lane; i < cnt; i += 64) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float dm = pm[k] - mean;
+    q += pq[k] + pn[k] * dm * dm;
+  }
+  for (int64_t i = lane + 256; i < cnt; i += 64) {
     const float dm = p[i * 3] - mean;
     q += p[i * 3 + 1] + p[i * 3 + 2] * dm * dm;
   }
@@ -217,11 +237,30 @@ __global__ __launch_bounds__(256) void gn_act_kernel(const float* x, const float
 // group's statistics (10.9 us for a 4 MB tensor).  SRC: 0 = finished statistics, 1 = the producer's (mean, M2, count)
 // partials (gn_finalize_act), 2 = gn_partial_kernel's chunk partials (gn_stats_act).
 template <int SRC, int NV>
-__global__ __launch_bounds__(256) void gn_act_slab_kernel(const float* x, const float* src, const float* gamma,
-                                                          const float* beta, int64_t C, int64_t L, int64_t G, int64_t E,
-                                                          float eps, float* stats, float* a) {
+__global__ __launch_bounds__(256) void gn_act_slab_kernel(const float* __restrict__ x, const float* __restrict__ src,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          int64_t C, int64_t L, int64_t G, int64_t E, float eps,
+                                                          float* __restrict__ stats, float* __restrict__ a) {
   __shared__ float st[2];
   const int64_t bg = blockIdx.y, b = bg / G, g = bg % G, Cg = C / G, NG = Cg * L;
+  // Every load of the kernel is requested BEFORE the statistics are combined: the deep layers' launches of this kernel move
+  // 2-8 MB and are bound by memory round trips, not by bandwidth -- with the tile requested behind the combination (its
+  // loads, a wave reduction, a barrier) a launch was two round trips long.
+  const float* xs = x + bg * NG;
+  float* as = a + bg * NG;
+  f32x4 v[NV];
+  int64_t e[NV];
+  float gm[NV], bt[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    e[j] = (((int64_t)blockIdx.x * NV + j) * 256 + threadIdx.x) * 4;
+    if (e[j] < NG) {
+      v[j] = *reinterpret_cast<const f32x4*>(xs + e[j]);
+      const int64_t c = g * Cg + e[j] / L;  // L % 4 == 0: a quad never straddles two rows
+      gm[j] = gamma[c];
+      bt[j] = beta[c];
+    }
+  }
   if (SRC == 0) {
     if (threadIdx.x == 0) {
       st[0] = src[bg * 2];
@@ -260,20 +299,10 @@ __global__ __launch_bounds__(256) void gn_act_slab_kernel(const float* x, const 
   }
   __syncthreads();
   const float mean = st[0], rstd = st[1];
-  const float* xs = x + bg * NG;
-  float* as = a + bg * NG;
-  f32x4 v[NV];
-  int64_t e[NV];
-#pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    e[j] = (((int64_t)blockIdx.x * NV + j) * 256 + threadIdx.x) * 4;
-    if (e[j] < NG) v[j] = *reinterpret_cast<const f32x4*>(xs + e[j]);
-  }
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     if (e[j] >= NG) continue;
-    const int64_t c = g * Cg + e[j] / L;  // L % 4 == 0: a quad never straddles two rows
-    const float pa = gamma[c] * rstd, pb = beta[c] - mean * pa;
+    const float pa = gm[j] * rstd, pb = bt[j] - mean * pa;
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[j][k] = adp_silu_fast(fmaf(v[j][k], pa, pb));
     *reinterpret_cast<f32x4*>(as + e[j]) = v[j];
@@ -422,11 +451,13 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_vec_kernel(const float* x, 
 }
 
 template <int TPR>
-__global__ __launch_bounds__(256) void gn_bwd_apply_vec_kernel(const float* x, const float* dact, const float* stats,
-                                                               const float* gamma, const float* beta, const float* ab,
-                                                               const float* dres, int64_t C, int64_t L, int64_t G,
-                                                               int64_t NS, int64_t CL, int64_t nseg, float* dx, int64_t B,
-                                                               float* dgamma, float* dbeta, int accumulate) {
+__global__ __launch_bounds__(256) void gn_bwd_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ dact,
+                                                               const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ ab,
+                                                               const float* __restrict__ dres, int64_t C, int64_t L, int64_t G,
+                                                               int64_t NS, int64_t CL, int64_t nseg, float* __restrict__ dx,
+                                                               int64_t B, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int accumulate) {
   __shared__ float sh[4];
   const int sl = threadIdx.x / TPR, li = threadIdx.x % TPR;
   const int64_t seg = (int64_t)blockIdx.x * (256 / TPR) + sl;
@@ -434,6 +465,28 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_vec_kernel(const float* x, c
   const int64_t sg = live ? seg : nseg - 1;
   const int64_t row = sg / NS, split = sg % NS;
   const int64_t b = row / C, c = row % C, Cg = C / G, g = c / Cg;
+  // The segment's first quads are requested before anything else: the deep layers' launches (one quad per lane) are bound
+  // by memory round trips, and the sums below (two dependent trips to `ab`) used to come first.
+  const int64_t lo = split * CL, hi = (lo + CL < L) ? lo + CL : L;
+  const float* xr = x + row * L;
+  const float* dr = dact + row * L;
+  const int64_t l0 = lo + 4 * li;
+  f32x4 xv0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, dv0 = xv0, rv0 = xv0;
+  if (live && l0 < hi) {
+    xv0 = *reinterpret_cast<const f32x4*>(xr + l0);
+    dv0 = *reinterpret_cast<const f32x4*>(dr + l0);
+    if (dres) rv0 = *reinterpret_cast<const f32x4*>(dres + row * L + l0);
+  }
+  const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+  const float gam = gamma[c], bet = beta[c];
+  float sa = 0.0f, sb = 0.0f;
+  for (int64_t e = li; e < Cg * NS; e += TPR) {
+    const int64_t cc = g * Cg + e / NS, spx = e % NS;
+    const float gm = gamma[cc];
+    const f32x2 p = *reinterpret_cast<const f32x2*>(ab + ((b * C + cc) * NS + spx) * 2);
+    sa = fmaf(gm, p[0], sa);
+    sb = fmaf(gm, p[1], sb);
+  }
   if (dgamma) {  // parameter gradients of this channel: dgamma = sum_{b,s} A, dbeta = sum_{b,s} B (batch 0's segments)
     const bool mine = (b == 0 && split == 0);
     float pa = 0.0f, pb = 0.0f;
@@ -452,27 +505,18 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_vec_kernel(const float* x, c
       }
     }
   }
-  const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
-  float sa = 0.0f, sb = 0.0f;
-  for (int64_t e = li; e < Cg * NS; e += TPR) {
-    const int64_t cc = g * Cg + e / NS, spx = e % NS;
-    const float gm = gamma[cc];
-    const f32x2 p = *reinterpret_cast<const f32x2*>(ab + ((b * C + cc) * NS + spx) * 2);
-    sa = fmaf(gm, p[0], sa);
-    sb = fmaf(gm, p[1], sb);
-  }
   const float inv = 1.0f / ((float)Cg * (float)L);
   const float m2 = gn_seg_sum<TPR>(sa, sh) * inv;
   const float m1 = gn_seg_sum<TPR>(sb, sh) * inv;
-  const float gam = gamma[c];
-  const float ga = gam * rstd, be = beta[c] - mean * ga;
-  const int64_t lo = split * CL, hi = (lo + CL < L) ? lo + CL : L;
-  const float* xr = x + row * L;
-  const float* dr = dact + row * L;
+  const float ga = gam * rstd, be = bet - mean * ga;
   if (!live) return;
-  for (int64_t l = lo + 4 * li; l < hi; l += 4 * TPR) {
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + l);
-    const f32x4 dv = *reinterpret_cast<const f32x4*>(dr + l);
+  for (int64_t l = l0; l < hi; l += 4 * TPR) {
+    f32x4 xv = xv0, dv = dv0, rv = rv0;
+    if (l != l0) {
+      xv = *reinterpret_cast<const f32x4*>(xr + l);
+      dv = *reinterpret_cast<const f32x4*>(dr + l);
+      if (dres) rv = *reinterpret_cast<const f32x4*>(dres + row * L + l);
+    }
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -481,9 +525,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_vec_kernel(const float* x, c
       o[k] = rstd * (gam * ds - m1 - xh * m2);
     }
     if (dres) {
-      const f32x4 r = *reinterpret_cast<const f32x4*>(dres + row * L + l);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] += r[k];
+      for (int k = 0; k < 4; ++k) o[k] += rv[k];
     }
     *reinterpret_cast<f32x4*>(dx + row * L + l) = o;
   }
@@ -683,11 +726,18 @@ __global__ __launch_bounds__(NT) void chan_lnv_fwd_kernel(const float* x, const 
   const int l0 = blockIdx.x * TL + 4 * lr, b = blockIdx.y;
   const bool valid = l0 < L;  // L % 4 == 0: a quad is inside or outside
   const float* xb = x + (int64_t)b * C * L + l0;
+  const float* sb = ss ? ss + b * bstride : nullptr;
   f32x4 v[VPT];
+  float mulv[VPT], addv[VPT];  // per-channel scale / shift, requested WITH the tile (not behind the two reductions)
   float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int c = rg + i * RPP;
+    mulv[i] = addv[i] = 0.0f;
+    if (y != nullptr && c < C) {
+      mulv[i] = gam ? gam[c] : 1.0f + sb[c];
+      addv[i] = gam ? bet[c] : sb[C + c];
+    }
     if (valid && c < C) {
       v[i] = *reinterpret_cast<const f32x4*>(xb + (int64_t)c * L);
     } else {
@@ -742,12 +792,11 @@ __global__ __launch_bounds__(NT) void chan_lnv_fwd_kernel(const float* x, const 
   if (y == nullptr || !valid) return;
   float* yb = y + (int64_t)b * C * L + l0;
   float* yb2 = y2 ? y2 + (int64_t)b * C * L + l0 : nullptr;
-  const float* sb = ss ? ss + b * bstride : nullptr;
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int c = rg + i * RPP;
     if (c >= C) continue;
-    const float mul = gam ? gam[c] : 1.0f + sb[c], add = gam ? bet[c] : sb[C + c];
+    const float mul = mulv[i], add = addv[i];
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = fmaf((v[i][k] - mean[k]) * rstd[k], mul, add);

@@ -41,10 +41,11 @@ def _split_prefixed(kwargs: Dict[str, Any], *prefixes: str):
 
 
 def _start_noise(shape: Sequence[int], like: Tensor, generator: Optional[Generator]) -> Tensor:
-    """N(0, 1) starting point of a sampling run.  Drawn exactly where the reference draws it (utils.py:123-125,
-    models.py:127-129, :164): on the HOST -- from `generator`, or from torch's global CPU generator when none is given
-    -- then moved to `like`'s device in one copy, so that `torch.manual_seed(s); model.sample(...)` scripts produce the
-    reference's starting noise on any backend.  (A generator that lives on the device is honoured in place.)"""
+    """N(0, 1) starting point of DiffusionUpsampler.sample.  Drawn exactly where the reference draws it (utils.randn_like,
+    utils.py:123-125 <- models.py:163): on the HOST -- from `generator`, or from torch's global CPU generator when none is
+    given -- then moved to `like`'s device in one copy, so that `torch.manual_seed(s); model.sample(...)` scripts produce the
+    reference's starting noise on any backend.  (A generator that lives on the device is honoured in place.)
+    DiffusionAE.decode does NOT come through here: the reference draws that noise on the latent's device (models.py:120-125)."""
     if generator is not None and generator.device.type != "cpu":
         return torch.randn(tuple(shape), generator=generator, dtype=like.dtype, device=generator.device).to(like.device)
     return torch.randn(tuple(shape), generator=generator, dtype=like.dtype).to(like.device)
@@ -124,7 +125,10 @@ class DiffusionAE(DiffusionModel):
     @torch.no_grad()
     def decode(self, latent: Tensor, generator: Optional[Generator] = None, **kwargs) -> Tensor:
         length = closest_power_2(latent.shape[2] * self.latent_factor)
-        noise = _start_noise((latent.shape[0], self.in_channels, length), latent, generator)
+        # drawn like the reference's decode (models.py:117-125): on the latent's device, from `generator` or that device's
+        # global generator -- a seeded decode() script sees the reference's starting noise
+        noise = torch.randn((latent.shape[0], self.in_channels, length), device=latent.device, dtype=latent.dtype,
+                            generator=generator)
         out = super().sample(noise, channels=self._context(latent), **kwargs)
         return out if self.adapter is None else self.adapter.decode(out)
 

@@ -50,11 +50,16 @@ class DataParallel(nn.Module):
     before autograd's AccumulateGrad touches the flat buffer's views; the trailing bucket is issued and waited for
     in an autograd final callback, after the last node of the backward pass."""
 
-    def __init__(self, module: nn.Module, min_bucket_bytes: int = 32 << 20, process_group=None):
+    def __init__(self, module: nn.Module, min_bucket_bytes: int = 32 << 20, process_group=None,
+                 force_collectives: bool = False):
+        """`force_collectives`: issue the bucketed all-reduces even in a ONE-rank group (they return their input): the
+        whole RCCL path -- AVG op, RCCL stream against the compute stream on the flat buffer, the trailing bucket -- can
+        then be exercised on a single GPU (tests/test_parallel.py, -m gpu)."""
         super().__init__()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._collect = self.world > 1 or (force_collectives and dist.is_initialized())
         self.min_bucket = min_bucket_bytes // 4
         self._works: List = []
         self._pending: List = []  # contiguous (start, end) regions not yet sent
@@ -66,7 +71,7 @@ class DataParallel(nn.Module):
         if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
             raise RuntimeError(f"DataParallel: the module lives on {dev} but the current device is "
                                f"cuda:{torch.cuda.current_device()}; call torch.cuda.set_device first")
-        if self.world > 1:
+        if self._collect:
             with torch.no_grad():
                 for p in module.parameters():
                     dist.broadcast(p, src=0, group=process_group)
@@ -98,37 +103,55 @@ class DataParallel(nn.Module):
     def _on_extra_grad(self, p):
         self._queue_final()
 
-    def _finalize(self):
-        self._final_queued = False
-        if self._extra:  # trailing bucket: [grad of every non-U-Net parameter | has-grad flags]
+    def _tail_bucket(self):
+        """The trailing bucket, allocated ONCE: [gradient of every non-U-Net parameter | one has-grad flag each], with a
+        view per parameter and a pinned host row for the flags (one asynchronous copy per step instead of a scalar write per
+        parameter)."""
+        if getattr(self, "_tail", None) is None:
             sizes = [p.numel() for p in self._extra]
             ref = self._extra[0]
-            buf = torch.zeros(sum(sizes) + len(sizes), dtype=torch.float32, device=ref.device)
-            off = 0
-            for i, (p, n) in enumerate(zip(self._extra, sizes)):
-                if p.grad is not None:
-                    buf[off:off + n].copy_(p.grad.reshape(-1))
-                    buf[sum(sizes) + i] = 1.0
+            total = sum(sizes)
+            self._tail = torch.zeros(total + len(sizes), dtype=torch.float32, device=ref.device)
+            self._tail_views, off = [], 0
+            for p, n in zip(self._extra, sizes):
+                self._tail_views.append(self._tail[off:off + n].view(p.shape))
                 off += n
+            self._tail_flags = self._tail[total:]
+            self._tail_host = torch.zeros(len(sizes), dtype=torch.float32)
+            if ref.is_cuda:
+                self._tail_host = self._tail_host.pin_memory()
+        return self._tail
+
+    def _finalize(self):
+        self._final_queued = False
+        if self._extra:
+            buf = self._tail_bucket()
+            have = [p.grad is not None for p in self._extra]
+            if not all(have):
+                buf.zero_()  # (slices of absent gradients must not carry last step's values into the sum)
+            dst = [v for v, h in zip(self._tail_views, have) if h]
+            if dst:
+                torch._foreach_copy_(dst, [p.grad for p, h in zip(self._extra, have) if h])
+            self._tail_host.copy_(torch.tensor(have, dtype=torch.float32))
+            self._tail_flags.copy_(self._tail_host, non_blocking=True)
             self._works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
         self._wait_all()
         if self._extra:
             # Which parameters got a gradient on SOME rank?  A parameter this rank produced a gradient for certainly
             # did, so the summed flags only have to be read back (one tiny device-to-host copy = a host sync) when a
             # local gradient is missing -- a step in which every rank used every parameter stays sync-free.
-            if all(p.grad is not None for p in self._extra):
-                flags = [1.0] * len(sizes)
-            else:
-                flags = buf[sum(sizes):].tolist()
-            off = 0
-            for p, n, used in zip(self._extra, sizes, flags):
+            flags = [1.0] * len(have) if all(have) else self._tail_flags.tolist()
+            buf.mul_(1.0 / self.world)
+            tgt, src = [], []
+            for p, v, used in zip(self._extra, self._tail_views, flags):
                 if used > 0:
-                    avg = (buf[off:off + n] / self.world).view(p.shape)
                     if p.grad is None:
-                        p.grad = avg.clone()
+                        p.grad = v.clone()
                     else:
-                        p.grad.copy_(avg)
-                off += n
+                        tgt.append(p.grad)
+                        src.append(v)
+            if tgt:
+                torch._foreach_copy_(tgt, src)
 
     def measure_overlap(self, step, timer, reps: int = 3) -> dict:
         """How much of the gradient all-reduce hides under the backward pass.  Three timings of `step()` (a full
@@ -137,12 +160,19 @@ class DataParallel(nn.Module):
           step_without_allreduce_ms    the same step with the collectives skipped (hook detached: what backward costs)
           allreduce_alone_ms           the step's bucket sequence all-reduced back to back with no compute beside it
         hidden_frac = 1 - (step - step_without) / allreduce_alone: 1.0 = fully overlapped, 0.0 = fully exposed."""
+        if not self._collect:
+            raise RuntimeError("measure_overlap needs a process group of more than one rank (no collectives at world size 1)")
         t_step = timer(step, reps)
         sent: List = []
         hook, orig_send = self.unet._grad_ready_hook, self._send
-        self._send = lambda flat, a, b: (sent.append((a, b)), orig_send(flat, a, b))[1]
-        step()
-        self._send = orig_send
+        try:
+            self._send = lambda flat, a, b: (sent.append((a, b)), orig_send(flat, a, b))[1]
+            step()
+        finally:
+            self._send = orig_send
+        if not sent:
+            raise RuntimeError("measure_overlap: step() sent no gradient bucket -- it has to run a backward pass through the "
+                               "wrapped U-Net")
         self.unet._grad_ready_hook = None
         try:
             t_plain = timer(step, reps)

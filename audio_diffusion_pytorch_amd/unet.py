@@ -370,6 +370,7 @@ class _Run:
         n = self.net
         if n.bank_total == 0:
             return None
+        assert not self.mod_sums.items, "dss_all is read while second stages of Modulation backwards are still parked"
         dfa = ops.linear_bwd_data(self.dss_all, n.bank_weight)  # the bank's own gradient: bank_grad_for_depth
         dfeat = ops.act_bwd(self.feats, dfa, ACT_SILU)
         if not n.use_time:
@@ -392,6 +393,7 @@ class _Run:
         n = self.net
         a, b = n.bank_depth_rows[d] if n.bank_total > 0 else (0, 0)
         self.mod_sums.flush(a, b)
+        assert not any(a <= it[0] < b for it in self.mod_sums.items), "parked Modulation sums inside the rows being read"
         if b > a:
             K = n.mf
             ops.linear_bwd_weight(self.dss_all.view(-1)[a:], self.feats, act=ACT_SILU,

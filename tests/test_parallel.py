@@ -147,3 +147,32 @@ def test_dp2_gloo_equals_single_process(emul, tmp_path):
     for n, p in model.net.named_parameters():
         err = (r0["grads"][n] - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-3 * gmax)
         assert err < 1e-4, (n, err)
+
+
+def _run_rccl_workers(world):
+    import subprocess
+    port = str(30700 + (os.getpid() % 500))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_rccl_worker.py"), str(r), str(world), port],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+        assert "DataParallel over RCCL ok" in o
+
+
+@pytest.mark.gpu
+def test_dp_rccl_one_rank_group():
+    """parallel.DataParallel on the REAL RCCL backend with a one-rank group (all a 1-GPU box offers) and
+    force_collectives=True: bucketed ReduceOp.AVG all-reduces from inside the U-Net backward on RCCL's stream, the wait at the
+    end of the backward node, the pre-allocated trailing bucket of the parameter outside the U-Net -- gradients must equal
+    the unwrapped model's."""
+    _run_rccl_workers(1)
+
+
+@pytest.mark.gpu
+def test_dp_rccl_two_ranks():
+    """The same over two GPUs (when the box has them): each rank takes half of the batch, gradients = single-process
+    gradients of the whole batch."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run_rccl_workers(2)

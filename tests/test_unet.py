@@ -304,6 +304,13 @@ def test_diffusion_autoencoder(dev):
     z = enc_ref(x).detach()
     out = ae.decode(z.to(dev), num_steps=2, generator=None)
     assert out.shape == (2, 2, 64)  # closest_power_2(16 * 4)
+    # the starting noise comes from the latent's device and the caller's generator, like the reference's decode
+    # (models.py:117-125): same seed -> same sample, and it equals sampling from that draw explicitly
+    g1, g2 = torch.Generator(device=dev).manual_seed(5), torch.Generator(device=dev).manual_seed(5)
+    o1 = ae.decode(z.to(dev), num_steps=2, generator=g1)
+    start = torch.randn((2, 2, 64), device=dev, dtype=z.dtype, generator=g2)
+    o2 = ae.sample(start, channels=[None, z.to(dev)], num_steps=2)
+    assert torch.equal(o1, o2)
 
 
 @pytest.mark.parametrize("L", [100, 36])

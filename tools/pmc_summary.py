@@ -79,7 +79,8 @@ def merge(fetch, write, dst, mfma=None, grbm=None):
             if k in gui and gui[k][2] > 0:
                 out[k]["grbm_gui_active_per_xcd"] = round(gui[k][1] / NUM_XCD, 1)
     with open(dst, "w") as f:
-        json.dump({"note": "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE doubled per the "
+        json.dump({"csrc_sha16": csrc_sha16(),
+                   "note": "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE doubled per the "
                            "gfx950 correction for 16-byte coalesced reads (MI355X_MICROARCH.md, HBM); reads served by "
                            "the 256 MiB Infinity Cache are included by these counters, not excluded.  mfma_busy = "
                            "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (kernel duration x 2.4 GHz): the share of the matrix "
@@ -91,6 +92,20 @@ def merge(fetch, write, dst, mfma=None, grbm=None):
 
 
 NUM_XCD, NUM_SIMD, PEAK_CLOCK_GHZ = 8, 1024, 2.4
+
+
+def csrc_sha16():
+    """Hash of the kernel sources the counters were collected from (bench.py compares it with the tree it runs in and marks
+    stored counters of other code as stale)."""
+    import hashlib
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "audio_diffusion_pytorch_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(root)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(root, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 if __name__ == "__main__":
     if sys.argv[1] == "--reduce":
