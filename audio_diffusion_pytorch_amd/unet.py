@@ -231,6 +231,83 @@ class UNetV0Net(nn.Module):
                 else:
                     own[k].copy_(v)
 
+    # ------------------------------------------------------------------ checkpoints of the reference (a_unet naming)
+    def a_unet_key_order(self) -> List[str]:
+        """Parameter names (in oracle/a_unet_restatement.py naming) in the order a_unet's module tree REGISTERS them, as
+        recalled (/root/reference/audio_diffusion_pytorch/components.py:157, :178 show the
+        `Module([...], fn)` -> ModuleList `blocks` convention): TimeConditioningPlugin = Module([embedder, mlp, net]) and
+        every Block = Module([skip_adapter, Sequential(downsample, *items, inner_block, *items_up, upsample), skip]) -- i.e.
+        depth d + 1 sits NESTED between depth d's down items and up items, where this package (and the restatement) keep one
+        flat list per depth.  UNVERIFIED offline like the rest of the a_unet half (DESIGN.md section 2);
+        tools/pin_a_unet.py checks it against the real package where that exists."""
+        names: List[str] = []
+        if self.use_time:
+            names += ["time_weights", "time_linear.weight", "time_linear.bias"]
+            for i in range(TIME_NUM_LAYERS):
+                names += [f"time_mlp.{i}.weight", f"time_mlp.{i}.bias"]
+        item_keys = {
+            ITEM_RESNET: ["gn1.weight", "gn1.bias", "conv1.weight", "conv1.bias", "gn2.weight", "gn2.bias", "conv2.weight",
+                          "conv2.bias"],
+            ITEM_MODULATION: ["to_scale_shift.weight", "to_scale_shift.bias"],
+            ITEM_INJECT: ["conv.weight", "conv.bias"],
+            ITEM_ATTENTION: ["norm.weight", "norm.bias", "norm_context.weight", "norm_context.bias", "to_q.weight",
+                             "to_kv.weight", "to_out.weight"],
+        }
+        item_keys[ITEM_CROSS_ATTENTION] = item_keys[ITEM_ATTENTION]
+
+        def block(d: int):
+            if d == len(self.blocks):
+                return
+            blk = self.blocks[d]
+            if hasattr(blk, "skip_adapter"):
+                names.extend([f"blocks.{d}.skip_adapter.weight", f"blocks.{d}.skip_adapter.bias"])
+            names.extend([f"blocks.{d}.down.weight", f"blocks.{d}.down.bias"])
+            for i, t in enumerate(self.item_types[d]):
+                names.extend(f"blocks.{d}.items_down.{i}.{k}" for k in item_keys[t])
+            block(d + 1)
+            for i, t in enumerate(self.item_types[d]):
+                names.extend(f"blocks.{d}.items_up.{i}.{k}" for k in item_keys[t])
+            names.extend([f"blocks.{d}.up.weight", f"blocks.{d}.up.bias"])
+            if self.use_modulation:
+                names.extend([f"blocks.{d}.skip.to_scale.weight", f"blocks.{d}.skip.to_scale.bias"])
+            else:
+                names.extend([f"blocks.{d}.skip.conv.weight", f"blocks.{d}.skip.conv.bias"])
+        block(0)
+        return names
+
+    def load_a_unet_state_dict(self, sd: Dict[str, Tensor]) -> Dict[str, str]:
+        """Loads a checkpoint of the REFERENCE's UNetV0 (a_unet's own key names, e.g. `blocks.2.blocks.1.blocks.3...`): the
+        floating-point tensors of `sd`, in its (registration) order, are assigned to `a_unet_key_order()` position by
+        position, every shape checked -- the names themselves are never interpreted, so the exact spelling of a_unet's
+        nesting does not matter, only its construction order.  Returns {checkpoint key: name it was loaded as}.  Raises
+        with the first mismatching entry when the checkpoint does not have this net's structure."""
+        theirs = [(k, v) for k, v in sd.items() if torch.is_tensor(v) and v.dtype.is_floating_point]
+        order = self.a_unet_key_order()
+        if len(theirs) != len(order):
+            raise ValueError(f"checkpoint holds {len(theirs)} floating-point tensors, this UNetV0 has {len(order)} parameters "
+                             f"(Modulation / SkipModulate layers counted per item)")
+        shapes = self._oracle_shapes()
+        for (k, v), name in zip(theirs, order):
+            # (exact shape, or the same shape up to unit axes: a Linear [M, R] stored where this net keeps a 1x1 conv [M, R, 1])
+            if tuple(d for d in v.shape if d != 1) != tuple(d for d in shapes[name] if d != 1):
+                raise ValueError(f"checkpoint entry {k!r} has shape {tuple(v.shape)}, expected {shapes[name]} for {name!r}: the "
+                                 f"checkpoint was not produced by UNetV0 with this configuration (or a_unet registers its "
+                                 f"parameters in another order than recalled: see a_unet_key_order)")
+        self.load_oracle_state_dict({name: v.reshape(shapes[name]) for (k, v), name in zip(theirs, order)})
+        return {k: name for (k, _), name in zip(theirs, order)}
+
+    def _oracle_shapes(self) -> Dict[str, tuple]:
+        """Shape of every parameter under its oracle-naming key (the conditioning bank split per item)."""
+        out = {}
+        for k, p in self.named_parameters():
+            if k not in ("bank_weight", "bank_bias"):
+                out[k.replace(".skip_cat.", ".skip.conv.")] = tuple(p.shape)
+        for key, (off, nout) in self.bank_slices.items():
+            base = f"blocks.{key[0]}.skip.to_scale" if key[1] == "skip" else f"blocks.{key[0]}.items_{key[1]}.{key[2]}.to_scale_shift"
+            out[base + ".weight"] = (nout, self.mf)
+            out[base + ".bias"] = (nout,)
+        return out
+
     def oracle_named_grads(self, grads: Dict[str, Tensor]) -> Dict[str, Tensor]:
         """Maps {own parameter name: tensor} to oracle naming (splitting the bank)."""
         out = {}

@@ -189,3 +189,33 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.adp_version() >= 100
+
+
+def test_a_unet_checkpoint_order_loader(emul):
+    """UNetV0Net.load_a_unet_state_dict: a checkpoint whose tensors come in a_unet's (recalled) NESTED registration order under
+    foreign key names -- depth d + 1 between depth d's down and up items, a_unet's `blocks.N...` style names -- loads
+    position by position and reproduces the restatement's output; a checkpoint of another structure is refused with the
+    entry that does not fit.  (The order itself is unverifiable offline: tools/pin_a_unet.py checks it where a_unet exists.)"""
+    import audio_diffusion_pytorch_amd as adp
+    from oracle.a_unet_restatement import UNetV0Oracle
+    cfg = dict(in_channels=2, channels=[8, 16, 16], factors=[2, 2, 2], items=[1, 2, 1], modulation_features=24,
+               attentions=[0, 0, 1], attention_heads=2, attention_features=8)  # depths 1 and 2 share their shapes
+    torch.manual_seed(3)
+    oracle = UNetV0Oracle(**cfg)
+    net = adp.UNetV0(dim=1, **cfg)
+    order = net.a_unet_key_order()
+    osd = oracle.state_dict()
+    assert sorted(order) == sorted(osd.keys())
+    assert order.index("blocks.1.items_down.0.gn1.weight") < order.index("blocks.2.down.weight") < \
+        order.index("blocks.1.items_up.0.gn1.weight"), "depth 2 nests between depth 1's down and up items"
+    foreign = {f"blocks.2.blocks.{i}.w{i}": osd[k].clone() for i, k in enumerate(order)}
+    keymap = net.load_a_unet_state_dict(foreign)
+    assert list(keymap.values()) == order
+    x, t = torch.randn(2, 2, 64), torch.tensor([0.3, 0.8])
+    with torch.no_grad():
+        assert rel_err(net(x, t), oracle(x, t)) < 1e-4
+    wrong = dict(foreign)
+    k5 = list(wrong)[10]
+    wrong[k5] = torch.zeros(3, 3)
+    with pytest.raises(ValueError, match="expected"):
+        net.load_a_unet_state_dict(wrong)

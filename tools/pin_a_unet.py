@@ -115,7 +115,7 @@ def rel(a, b):
     return (a - b).abs().max().item() / (d if d > 0 else 1.0)
 
 
-def pin(real_factory, tol=1e-5, verbose=True):
+def pin(real_factory, tol=1e-5, verbose=True, check_order=True):
     """Compares the restatement with `real_factory(**cfg)` on every configuration; returns the golden payload."""
     from oracle.a_unet_restatement import UNetV0Oracle
     payload = {"configs": {}, "tolerance": tol}
@@ -137,7 +137,16 @@ def pin(real_factory, tol=1e-5, verbose=True):
         if not (e_y < tol and e_g < 100 * tol):
             raise AssertionError(f"configuration {name!r}: the restatement does not reproduce the real a_unet "
                                  f"(output {e_y:.2e}, gradients {e_g:.2e}); check the [switch] constants")
-        payload["configs"][name] = {"cfg": cfg, "keymap": keymap, "state_dict": real_sd, "x": x, "t": t, "kw": kw,
+        # the product's positional checkpoint loader (UNetV0Net.a_unet_key_order): does the real registration order match the
+        # recalled one?  (compared through the shape-and-order key map above, which does not depend on it)
+        import audio_diffusion_pytorch_amd as adp
+        recalled = adp.UNetV0(dim=1, **cfg).a_unet_key_order()
+        real_order = [keymap[k] for k in real_sd]
+        if verbose and check_order and recalled != real_order:
+            first = next(i for i, (a, b) in enumerate(zip(recalled, real_order)) if a != b)
+            print(f"[pin_a_unet] {name:16s} NOTE: a_unet registers entry {first} as {real_order[first]!r}, "
+                  f"UNetV0Net.a_unet_key_order() has {recalled[first]!r} there -- fix the order in unet.py")
+        payload["configs"][name] = {"cfg": cfg, "keymap": keymap, "key_order_matches": recalled == real_order, "state_dict": real_sd, "x": x, "t": t, "kw": kw,
                                     "gy": gy, "y": y_r, "grads": {k: v for k, v in list(g_r.items())[:8]}}
     return payload
 
@@ -158,7 +167,7 @@ def _self_test_factory(**cfg):
 
 def main():
     self_test = "--self-test" in sys.argv
-    payload = pin(_self_test_factory if self_test else load_reference_unetv0())
+    payload = pin(_self_test_factory if self_test else load_reference_unetv0(), check_order=not self_test)
     if self_test:
         print("[pin_a_unet] self-test ok (nothing written: the restatement compared with itself pins nothing)")
         return
