@@ -156,6 +156,9 @@ def check(code: int, what: str):
 # events on the stream it launches on and labelled with the kernel instantiation(s) it dispatched.
 PROFILE = None
 _TAG = None
+# bench.py's convblock leg: when REPLAY is a list, ops.conv1d appends (shape label, algorithmic bytes, relaunch callable) for
+# every conv it issues, so that single launches can be re-timed from a hipGraph without the per-launch event pair
+REPLAY = None
 
 
 def tag(**meta):

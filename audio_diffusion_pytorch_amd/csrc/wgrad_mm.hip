@@ -518,7 +518,7 @@ int pick_wg(const adp_wgrad_desc& d, void* stream) {
 bool wg_winograd(const adp_wgrad_desc& d) {
   if (!adp_winograd_enabled()) return false;
   const char* mr = getenv("ADP_WINO_WGRAD_MIN_R");
-  const int64_t min_r = mr ? atoll(mr) : 64;
+  const int64_t min_r = mr ? atoll(mr) : 32;
   return d.KT == 3 && d.stride == 1 && d.pad == 1 && d.R >= min_r;
 }
 

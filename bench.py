@@ -219,12 +219,62 @@ def roofline_leg(model, x, top: int = 14):
         hbm["traffic"] = per or None
         hbm["traffic_source"] = "stored rocprofv3 PMC pass (profiles/pmc_traffic.json), per kernel instantiation" if per else None
         hbm["what"] = "forward ConvBlock convs (GroupNorm+SiLU prologue, k=3) of depths 0-1: A_in + A_out (+A_res) bytes"
+        hbm["timing"] = ("HIP event pair around every launch of three instrumented eager steps (the pair itself adds 2-3 us to a "
+                         "20 us kernel); replay_* = the same launches re-timed one by one from a hipGraph of 20 replays each")
+        try:  # the same launches without the per-launch event pair
+            rp = _replay_convblock(model, x)
+            if rp:
+                hbm.update(rp)
+        except Exception as e:
+            hbm["replay_error"] = f"{type(e).__name__}: {e}"
     table = {}
     for k, a in order[:top]:
         e = entry(k, a)
         table[k] = {"launches": e["launches"], "avg_us": e["avg_us"], "total_ms": round(a["ms"], 3),
                     "bound": e["bound"], "achieved": e["achieved"], "unit": e["unit"], "frac": e["frac"]}
     return rf, hbm, table, round(total_ms, 3)
+
+
+def _replay_convblock(model, x):
+    """Re-times the depth-0/1 forward ConvBlock conv launches of one step: each launch (same tensors, inputs as warm in the
+    Infinity Cache as behind their producer in the step) replayed 20 times back to back from its own hipGraph, HIP events
+    around the replays.  Returns replay_avg_us / replay_achieved (GB/s) / replay_frac for the group."""
+    from audio_diffusion_pytorch_amd import _C
+    _C.REPLAY = []
+    try:
+        with torch.no_grad():
+            model.net(x, torch.full((x.shape[0],), 0.5, device=x.device))
+        torch.cuda.synchronize()
+        recs = [r for r in _C.REPLAY if " pro1" in r[0] and " tr0" in r[0] and (" R8 " in r[0] or " R32 " in r[0])]
+    finally:
+        _C.REPLAY = None
+    if not recs:
+        return None
+    tot_us, tot_bytes = 0.0, 0
+    for label, nbytes, fn in recs:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(20):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(3):
+            g.replay()
+        b.record()
+        torch.cuda.synchronize()
+        tot_us += a.elapsed_time(b) * 1e3 / 60
+        tot_bytes += nbytes
+    gbps = tot_bytes / (tot_us * 1e-6) / 1e9
+    return {"replay_launches": len(recs), "replay_avg_us": round(tot_us / len(recs), 2), "replay_achieved": round(gbps, 1),
+            "replay_frac": round(gbps / PEAK_HBM_GBPS, 4)}
 
 
 def _graphed(step, zero):
