@@ -894,7 +894,6 @@ extern "C" int64_t adp_conv1d_tile(const adp_conv_desc* dp) {
 extern "C" int64_t adp_conv1d_wgrad_ws_bytes(const adp_wgrad_desc* dp) {
   if (!dp || !ks_supported(dp->KT, dp->stride) || dp->B <= 0 || dp->N <= 0) return ADP_ERR_UNSUPPORTED;
   int64_t nsplit;
-  if (adp_wgrad_tile_eligible(*dp)) return adp_wgrad_tile_ws_floats(*dp) * (int64_t)sizeof(float);
   if (adp_wgrad_mm_eligible(*dp)) return adp_wgrad_mm_ws_floats(*dp) * (int64_t)sizeof(float);
   if (adp_wgrad_direct_eligible(*dp)) return adp_wgrad_direct_ws_floats(*dp) * (int64_t)sizeof(float);
   if (wgrad_s1_eligible(*dp)) {
@@ -920,7 +919,6 @@ extern "C" int adp_conv1d_wgrad(const adp_wgrad_desc* dp, void* stream) {
   if (d.prologue < 0 || d.prologue > 2 || (d.prologue != 0 && !d.pro_stats)) return ADP_ERR_NULL;
   if (d.prologue == 1 && (d.groups < 1 || d.R % d.groups != 0)) return ADP_ERR_SHAPE;
   if (adp_cdiv(d.M, 32) > 65535 || adp_cdiv(d.R, 32) > 65535) return ADP_ERR_SHAPE;
-  if (adp_wgrad_tile_eligible(d)) return adp_wgrad_tile(d, stream);
   if (adp_wgrad_mm_eligible(d)) return adp_wgrad_mm(d, stream);
   if (adp_wgrad_direct_eligible(d)) return adp_wgrad_direct(d, stream);
   if (d.KT == 1) return launch_wgrad<1, 1>(d, stream);

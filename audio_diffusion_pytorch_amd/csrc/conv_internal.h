@@ -32,11 +32,6 @@ int64_t adp_conv_tile_gn_entries(const adp_conv_desc& d);  // GroupNorm partial 
 bool adp_conv_direct_eligible(const adp_conv_desc& d);
 int adp_conv_direct(const adp_conv_desc& d, void* stream);
 
-// wgrad_tile.hip: register-operand weight gradient of the 32 -> 32 channel kernel-3 ConvBlock convs (depth 1)
-bool adp_wgrad_tile_eligible(const adp_wgrad_desc& d);
-int64_t adp_wgrad_tile_ws_floats(const adp_wgrad_desc& d);
-int adp_wgrad_tile(const adp_wgrad_desc& d, void* stream);
-
 // wgrad_direct.hip: VALU streaming weight gradient for the narrow layers (M * R <= 256)
 bool adp_wgrad_direct_eligible(const adp_wgrad_desc& d);
 int64_t adp_wgrad_direct_ws_floats(const adp_wgrad_desc& d);

@@ -363,33 +363,6 @@ def test_conv_tile32(dev, nw, B, L, pro, res, shift, monkeypatch):
     assert rel_err(dx, F.conv_transpose1d(x, w, None, padding=1)) < TOL
 
 
-@pytest.mark.parametrize("waves", [16, 32, 4096])
-@pytest.mark.parametrize("B,L,pro", [(1, 256, 0), (2, 1024, 1), (3, 96, 1), (4, 65536, 1)])
-def test_wgrad_tile32(dev, waves, B, L, pro, monkeypatch):
-    """wgrad_tile.hip: weight / bias gradient of the 32 -> 32 channel kernel-3 ConvBlock convs with both MFMA operands straight
-    from registers (lane = row, K = positions; the taps are register-index shifts of the activated window), several tiles per
-    wave, the workgroup's waves summed in a fixed tree: against autograd, with and without the GroupNorm+SiLU prologue."""
-    if dev.type != "cuda" and L > 4096:
-        pytest.skip("emulator: large case runs on the GPU only")
-    monkeypatch.setenv("ADP_WGRAD_TILE", "1")
-    monkeypatch.setenv("ADP_WGRAD_TILE_WAVES", str(waves))
-    C, G = 32, 8
-    x = rnd(B, C, L, seed=1) * 1.3 + 0.2
-    w, bias = rnd(C, C, 3, seed=2, scale=0.2).requires_grad_(), rnd(C, seed=3).requires_grad_()
-    gamma, beta = rnd(C, seed=4) * 0.5 + 1, rnd(C, seed=5) * 0.1
-    a = ref_gn_silu(x, G, gamma, beta) if pro else x
-    y = F.conv1d(a, w, bias, padding=1)
-    dy = rnd(*y.shape, seed=9)
-    dw_ref, db_ref = torch.autograd.grad(y, (w, bias), dy)
-    xd = x.to(dev)
-    if pro:
-        dw, db = ops.conv1d_wgrad(xd, dy.to(dev), 3, pad=1, prologue=1, pro_stats=ops.gn_stats(xd, G),
-                                  pro_gamma=gamma.to(dev), pro_beta=beta.to(dev), groups=G)
-    else:
-        dw, db = ops.conv1d_wgrad(xd, dy.to(dev), 3, pad=1)
-    assert rel_err(dw, dw_ref) < TOL and rel_err(db, db_ref) < TOL
-
-
 MM_RESAMPLE_CASES = [
     # B, R, M, Lin, KT, stride, pad, up -- DownsampleItem (kernel = stride) and UpsampleItem (nearest + k3) on conv_mm
     (2, 32, 64, 256, 2, 2, 0, 1),

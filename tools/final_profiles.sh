@@ -3,7 +3,7 @@
 #   pytest -m gpu | bench line + per-shape table | rocprofv3 kernel stats of the bench step, the batch-1 step and the sampler |
 #   PMC passes (HBM traffic, matrix-core busy)
 set -u
-TAG=${1:-r03z}
+TAG=${1:-r04z}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$ROOT/gpurun_out
 mkdir -p "$O"
