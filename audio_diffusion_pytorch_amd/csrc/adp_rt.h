@@ -81,6 +81,17 @@ __device__ __forceinline__ int adp_uniform(int v) { return __builtin_amdgcn_read
 __device__ __forceinline__ float adp_read_lane(float v, int src) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
 }
+// sum over each 16-lane row of the wave with four DPP adds; valid in EVERY lane of the row
+__device__ __forceinline__ float adp_row16_sum(float v) {
+#define ADP_DPP_ADD16(ctrl) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+  ADP_DPP_ADD16(0xB1);   // quad_perm [1,0,3,2]
+  ADP_DPP_ADD16(0x4E);   // quad_perm [2,3,0,1]
+  ADP_DPP_ADD16(0x141);  // row_half_mirror
+  ADP_DPP_ADD16(0x140);  // row_mirror
+#undef ADP_DPP_ADD16
+  return v;
+}
 // sum over the 32 lanes of each half-wave with five DPP adds (no LDS, no bpermute); VALID IN LANES 16-31 AND 48-63 only
 __device__ __forceinline__ float adp_half_sum(float v) {
 #define ADP_DPP_ADD(ctrl, rmask) \

@@ -57,18 +57,20 @@ __device__ __forceinline__ f32x2 wt_silu2(f32x2 h) {
   return h * f32x2{adp_rcp(den[0]), adp_rcp(den[1])};
 }
 
+constexpr int WT_US = WT_C * 2 * 16 * 6;  // floats of the transformed weights U[c][rb][m16][6]
+
 template <bool TR, int PRO, int NW, bool RES, bool GN>
 __global__ __launch_bounds__(64 * NW) void conv_tile32_kernel(adp_conv_desc d, int tiles_per_b, int cfg) {
   // One LDS block, U first: its fragment reads (and the tile's) then take their K-step offsets as 16-bit immediates.
-  //   U[r][m][4] | (pa, pb) per input channel | statistics scratch [NW][8][2] | NW wave tiles [32][66]
-  __shared__ __attribute__((aligned(16))) float lds[WT_C * WT_C * 4 + 2 * WT_C + NW * 16 + NW * WT_XT];
+  //   U[c][rb][m][6] | (pa, pb) per input channel | statistics scratch [NW][8][2] | NW wave tiles [32][66]
+  __shared__ __attribute__((aligned(16))) float lds[WT_US + 2 * WT_C + NW * 16 + NW * WT_XT];
   float* const us = lds;
-  float* const pab = lds + WT_C * WT_C * 4;
+  float* const pab = lds + WT_US;
   float* const gsh = pab + 2 * WT_C;
   float* const xs = gsh + NW * 16;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = adp_uniform(tid >> 6);  // scalar: everything addressed per tile sits on SGPR bases + 32-bit lane offsets
-  const int hi = lane >> 5, l31 = lane & 31;
+  const int j = lane & 15, kq = lane >> 4;  // MFMA 16x16x4: lane = (output row / quad column j, K index kq)
   const int L = (int)d.Lin;
   // the workgroup's NW tiles are consecutive and lie in one batch element (tiles_per_b % NW == 0)
   const int t = (int)blockIdx.x * NW + wave;
@@ -79,16 +81,17 @@ __global__ __launch_bounds__(64 * NW) void conv_tile32_kernel(adp_conv_desc d, i
 
   // ---- tile loads: lane -> quads q = lane + 64 i of the 32 x 16 body (row = q >> 4), one halo scalar.
   // Waves w, w + 4, w + 8, w + 12 of a workgroup share a SIMD (cyclic placement; tools/probe/tile_probe prints it).  On this
-  // chip the exact-f32 MFMA and the f32 VALU ops of a SIMD ADD (tile_probe: a stage that runs its SiLU while two others
-  // multiply needs 5-7 us for 0.5 us of work), so the kernel is bound by the instructions a SIMD issues: everything around
-  // the 65 MFMAs of a tile is written for instruction count (scalar bases, packed f32 ops, DPP reductions).  Stage
-  // s = w >> 2 asks for its tile s * `gap` after the launch, so that the tiles of a SIMD land one after the other.
+  // chip an exact-f32 MFMA stream leaves the other waves of its SIMD about five issue slots per 64-cycle MFMA
+  // (tools/probe/alu_probe: a VALU op beside it takes 13 cycles instead of 5), so the kernel is bound by the instructions a
+  // SIMD issues: everything around the MFMAs of a tile is written for instruction count (scalar bases, packed f32 ops, DPP
+  // reductions).  Stage s = w >> 2 asks for its tile s * `gap` after the launch.
   const char* xt = reinterpret_cast<const char*>(d.x + tbase);
   const int stage = wave >> 2;
   const long long t_start = adp_clock();
   WT_STAMP(0);
   WT_STAMP(7);
   f32x4 rx[8];
+  const int hi = lane >> 5, l31 = lane & 31;
   const int hrel = hi ? WT_TN : -1;  // right / left halo of row l31
   const bool hok = n0 + hrel >= 0 && n0 + hrel < L;
   float hx = 0.0f;
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(64 * NW) void conv_tile32_kernel(adp_conv_desc d, i
     for (int k = 0; k < NIT; ++k) {
       const int p = sid + k * NST;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) wv[k][j] = p < WT_C * WT_C ? d.w[3 * p + j] : 0.0f;
+      for (int q = 0; q < 3; ++q) wv[k][q] = p < WT_C * WT_C ? d.w[3 * p + q] : 0.0f;
     }
     float pg = 1.0f, pbt = 0.0f, pmean = 0.0f, prstd = 1.0f;
     if (PRO == 1 && sid < WT_C) {
@@ -136,16 +139,16 @@ __global__ __launch_bounds__(64 * NW) void conv_tile32_kernel(adp_conv_desc d, i
     for (int k = 0; k < NIT; ++k) {
       const int p = sid + k * NST;
       if (p < WT_C * WT_C) {
-        // p = m * 32 + r reads w[m][r][0..2]; the data gradient (w[r][m][.], taps flipped) takes p = r * 32 + m
-        const float a = wv[k][0], c = wv[k][1], e = wv[k][2];
+        // p = m * 32 + c reads w[m][c][0..2]; the data gradient (w[c][m][.], taps flipped) takes p = c * 32 + m.
+        // Winograd F(4,3) weight transform G g, G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+        const float a = wv[k][0], g1 = wv[k][1], e = wv[k][2];
         const float g0 = TR ? e : a, g2 = TR ? a : e;
-        const int m = TR ? (p & 31) : (p >> 5), r = TR ? (p >> 5) : (p & 31);
-        f32x4 u;
-        u[0] = g0;
-        u[1] = 0.5f * (g0 + c + g2);
-        u[2] = 0.5f * (g0 - c + g2);
-        u[3] = g2;
-        *reinterpret_cast<f32x4*>(us + (r * WT_C + m) * 4) = u;
+        const int m = TR ? (p & 31) : (p >> 5), c = TR ? (p >> 5) : (p & 31);
+        const float s02 = g0 + g2, q = 0.041666666666666664f * g0 + 0.16666666666666666f * g2;
+        float* u = us + ((c * 2 + (m >> 4)) * 16 + (m & 15)) * 6;
+        *reinterpret_cast<f32x2*>(u) = f32x2{0.25f * g0, -0.16666666666666666f * (s02 + g1)};
+        *reinterpret_cast<f32x2*>(u + 2) = f32x2{-0.16666666666666666f * (s02 - g1), q + 0.08333333333333333f * g1};
+        *reinterpret_cast<f32x2*>(u + 4) = f32x2{q - 0.08333333333333333f * g1, g2};
       }
     }
     if (PRO == 1 && sid < WT_C) {
@@ -162,6 +165,10 @@ __global__ __launch_bounds__(64 * NW) void conv_tile32_kernel(adp_conv_desc d, i
   WT_STAMP(2);
 
   // ---- activate and park the tile in this wave's LDS region: index i of a row <-> position n0 - 1 + i
+  // (Issue priority was tried both ways -- the multiplying stage first, and the activation above the MFMA loops: the latter
+  // does bring "tile in LDS" forward from 7.7 / 10.3 / 12.8 us to 6.7 / 7.7 / 9.0 us for stages 1-3, but the four tiles of a
+  // SIMD still end at the same time (its VALU + MFMA instruction total is what bounds it) and conv2 got 2 us slower in the
+  // hipGraph microbench; no s_setprio is left in the kernel.)
   float* X = xs + wave * WT_XT;
   {
     float* o = X + (lane >> 4) * WT_RS + 4 * (lane & 15) + 1;  // + 4 i rows: immediates
@@ -187,97 +194,113 @@ __global__ __launch_bounds__(64 * NW) void conv_tile32_kernel(adp_conv_desc d, i
   adp_wave_sync();
   WT_STAMP(3);
 
-  // ---- 16 K steps of two channels: four MFMAs each on the four Winograd planes
-  f32x16 P0, P1, P2, P3;
+  // ---- Winograd F(4,3) on v_mfma_f32_16x16x4_f32: column j of the MFMA tile is an output QUAD (positions n0 + 4j .. + 3),
+  // the two 16-row blocks rb cover the 32 output channels, a K step is four input channels (lane kq holds channel 4 ks + kq).
+  // Per K step a lane reads the six inputs around its quad (three 8-byte LDS reads), forms V = B^T d with 13 VALU ops and
+  // issues 2 x 6 MFMAs on the six Winograd planes: 96 MFMAs of 32 cycles per tile against 65 of 64 cycles for F(2,3)
+  // (144 of 64 cycles in the direct form).  fp32 error against fp64 1.2e-6 of the output's max norm (direct form 3.7e-7).
+  f32x4 M[2][6];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) P0[r] = P1[r] = P2[r] = P3[r] = 0.0f;
-  {
-    const float bias_a = (d.bias && hi == 0) ? d.bias[l31] : 0.0f;
-    P1 = adp_mfma32(bias_a, 1.0f, P1);  // bias[m] in both y0 = P0+P1+P2 and y1 = P1-P2-P3
-  }
-  const float* Xr = X + hi * WT_RS + 2 * l31;
-  const float* Ur = us + (hi * WT_C + l31) * 4;
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int p = 0; p < 6; ++p) M[rb][p] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  const float* Xr = X + kq * WT_RS + 4 * j;    // + 4 ks rows
+  const float* Ur = us + (kq * 32 + j) * 6;    // + 4 ks channels (192 floats each), + rb * 96
   if (!(elim & 1)) {
-    // fragments of step k + 1 are requested before the MFMAs of step k are issued: a wave that has the SIMD's matrix pipe to
-    // itself keeps it busy (tile_probe: 3.5 us per tile with just-in-time reads against 1.7 us of MFMA issue)
-    f32x4 u = *reinterpret_cast<const f32x4*>(Ur);
-    f32x2 da = *reinterpret_cast<const f32x2*>(Xr), db = *reinterpret_cast<const f32x2*>(Xr + 2);
+    f32x2 dn[3], un[2][3];
+    auto frags = [&](int ks) {
 #pragma unroll
-    for (int k = 0; k < WT_C / 2; ++k) {
-      f32x4 un = u;
-      f32x2 dan = da, dbn = db;
-      if (k + 1 < WT_C / 2) {
-        un = *reinterpret_cast<const f32x4*>(Ur + (k + 1) * 2 * WT_C * 4);
-        dan = *reinterpret_cast<const f32x2*>(Xr + (k + 1) * 2 * WT_RS);
-        dbn = *reinterpret_cast<const f32x2*>(Xr + (k + 1) * 2 * WT_RS + 2);
+      for (int q = 0; q < 3; ++q) {
+        dn[q] = *reinterpret_cast<const f32x2*>(Xr + 4 * ks * WT_RS + 2 * q);
+        un[0][q] = *reinterpret_cast<const f32x2*>(Ur + 4 * ks * 192 + 2 * q);
+        un[1][q] = *reinterpret_cast<const f32x2*>(Ur + 4 * ks * 192 + 96 + 2 * q);
       }
-      adp_sched_fence();  // (the reads stay AHEAD of the four MFMAs: the scheduler otherwise sinks them behind the third)
-      // V = (d0 - d2, d1 + d2, d2 - d1, d1 - d3).  (A hand-written packed form -- v_pk_add_f32 with op_sel / neg_hi through
-      // inline asm -- fed the MFMA a stale register: the compiler's hazard recogniser does not see into the asm.)
-      P0 = adp_mfma32(u[0], da[0] - db[0], P0);
-      P1 = adp_mfma32(u[1], da[1] + db[0], P1);
-      P2 = adp_mfma32(u[2], db[0] - da[1], P2);
-      P3 = adp_mfma32(u[3], da[1] - db[1], P3);
+    };
+    frags(0);
+#pragma unroll
+    for (int ks = 0; ks < WT_C / 4; ++ks) {
+      f32x2 dc[3], uc[2][3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        dc[q] = dn[q];
+        uc[0][q] = un[0][q];
+        uc[1][q] = un[1][q];
+      }
+      if (ks + 1 < WT_C / 4) frags(ks + 1);  // requested before this step's MFMAs are issued
       adp_sched_fence();
-      u = un;
-      da = dan;
-      db = dbn;
+      // B^T d: (4 d0 - 5 d2 + d4, -4 d1 - 4 d2 + d3 + d4, 4 d1 - 4 d2 - d3 + d4, -2 d1 - d2 + 2 d3 + d4,
+      //         2 d1 - d2 - 2 d3 + d4, 4 d1 - 5 d3 + d5)
+      const float d0 = dc[0][0], d1 = dc[0][1], d2 = dc[1][0], d3 = dc[1][1], d4 = dc[2][0], d5 = dc[2][1];
+      const float a = fmaf(-4.0f, d2, d4), bb = fmaf(-4.0f, d1, d3), c = d4 - d2, e = 2.0f * (d3 - d1);
+      float v[6];
+      v[0] = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));
+      v[1] = a + bb;
+      v[2] = a - bb;
+      v[3] = c + e;
+      v[4] = c - e;
+      v[5] = fmaf(4.0f, d1, fmaf(-5.0f, d3, d5));
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        M[0][p] = adp_mfma16(uc[0][p >> 1][p & 1], v[p], M[0][p]);
+        M[1][p] = adp_mfma16(uc[1][p >> 1][p & 1], v[p], M[1][p]);
+      }
+      adp_sched_fence();
     }
   }
 
   WT_STAMP(4);
-  // ---- epilogue: accumulator register i <-> row (i & 3) + 8 (i >> 2) + 4 hi, column l31 = output pair
+  // ---- epilogue: accumulator register r of block rb <-> output channel 16 rb + 4 kq + r, column j = output quad;
+  // y = A^T m, A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]; 16-byte stores, 256 contiguous bytes per row
   char* ot = reinterpret_cast<char*>(d.out + tbase);
   const char* rt = reinterpret_cast<const char*>(RES ? d.res + tbase : d.out + tbase);
-  const unsigned ob = 4u * (unsigned)hi * Lb + 8u * (unsigned)l31;  // lane part; rows add scalar multiples of the pitch
+  const unsigned ob = 4u * (unsigned)kq * Lb + 16u * (unsigned)j;  // lane part; rows add scalar multiples of the pitch
   const bool has_res = RES && !(elim & 2);
   constexpr bool want_gn = GN;
-  float gk[4];
-  f32x2 gs[4], gq[4];  // per row quad: shift, shifted sums / sums of squares of this lane's (even, odd) positions
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {  // two halves of eight rows: 16 residual registers live at a time
-    f32x2 rv[8];
+  for (int rb = 0; rb < 2; ++rb) {
+    f32x4 rv[4], bv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if (has_res) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = 8 * h + i;
-        rv[i] = *reinterpret_cast<const f32x2*>(rt + (ob + (unsigned)((r & 3) + 8 * (r >> 2)) * Lb));
+      for (int r = 0; r < 4; ++r) rv[r] = *reinterpret_cast<const f32x4*>(rt + (ob + (unsigned)(16 * rb + r) * Lb));
+    }
+    if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + 16 * rb + 4 * kq);
+    float gk = 0.0f;
+    f32x2 gs = f32x2{0.0f, 0.0f}, gq = f32x2{0.0f, 0.0f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float m0 = M[rb][0][r], m1 = M[rb][1][r], m2 = M[rb][2][r], m3 = M[rb][3][r], m4 = M[rb][4][r], m5 = M[rb][5][r];
+      const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+      f32x2 ya = f32x2{m0 + s12 + s34, fmaf(2.0f, d34, d12)} + bv[r];
+      f32x2 yb = f32x2{fmaf(4.0f, s34, s12), fmaf(8.0f, d34, d12) + m5} + bv[r];
+      if (has_res) {
+        ya = ya + f32x2{rv[r][0], rv[r][1]};
+        yb = yb + f32x2{rv[r][2], rv[r][3]};
+      }
+      if (!(elim & 2))
+        *reinterpret_cast<f32x4*>(ot + (ob + (unsigned)(16 * rb + r) * Lb)) = f32x4{ya[0], ya[1], yb[0], yb[1]};
+      if (want_gn) {
+        if (r == 0) gk = __shfl(ya[0], lane & 48, 64);  // shift of this row quad: its first value, lane j = 0 of the kq row
+        const f32x2 ea = ya - gk, eb = yb - gk;
+        gs = gs + ea + eb;
+        gq = ea * ea + (eb * eb + gq);
       }
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = 8 * h + i;
-      const float s12 = P1[r] + P2[r], d12 = P1[r] - P2[r];
-      f32x2 y = f32x2{P0[r] + s12, d12 - P3[r]};
-      if (has_res) y = y + rv[i];
-      if (!(elim & 2))
-        *reinterpret_cast<f32x2*>(ot + (ob + (unsigned)((r & 3) + 8 * (r >> 2)) * Lb)) = y;
-      if (want_gn) {
-        const int q = r >> 2;
-        if ((r & 3) == 0) {  // shift of this row quad: its first value in lane 0 / 32 of the half-wave
-          const float k0 = adp_read_lane(y[0], 0), k1 = adp_read_lane(y[0], 32);
-          gk[q] = hi ? k1 : k0;
-          gs[q] = gq[q] = f32x2{0.0f, 0.0f};
-        }
-        const f32x2 e = y - gk[q];
-        gs[q] = gs[q] + e;
-        gq[q] = e * e + gq[q];
+    if (want_gn) {
+      // one (mean, M2) per (wave, row quad 4 rb + kq): the quad's 4 channels are this lane's registers, its 64 positions the
+      // 16 lanes of the kq row
+      constexpr float cnt = 4.0f * WT_TN;
+      const float sv = adp_row16_sum(gs[0] + gs[1]), qv = adp_row16_sum(gq[0] + gq[1]);
+      if (j == 0) {
+        float* e = gsh + (wave * 8 + 4 * rb + kq) * 2;
+        e[0] = gk + sv / cnt;
+        e[1] = fmaxf(qv - sv * (sv / cnt), 0.0f);
       }
     }
   }
   WT_STAMP(5);
   if (want_gn) {
-    // one (mean, M2) per (wave, row quad) -> Chan-combined over the workgroup's NW waves -> one gn_part entry per quad
+    // Chan-combined over the workgroup's NW waves -> one gn_part entry per row quad
     constexpr float cnt = 4.0f * WT_TN;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float sv = adp_half_sum(gs[q][0] + gs[q][1]), qv = adp_half_sum(gq[q][0] + gq[q][1]);
-      if (l31 == 31) {  // (the DPP sums are complete in the upper lanes of each half-wave)
-        float* e = gsh + (wave * 8 + 2 * q + hi) * 2;  // row quad index (8 q + 4 hi) / 4
-        e[0] = gk[q] + sv / cnt;
-        e[1] = fmaxf(qv - sv * (sv / cnt), 0.0f);
-      }
-    }
     __syncthreads();
     if (tid < 8) {
       float mean = gsh[tid * 2], m2 = gsh[tid * 2 + 1], n = cnt;
@@ -338,7 +361,8 @@ bool adp_conv_tile_eligible(const adp_conv_desc& d) {
   if (d.prologue == 1 && (d.groups < 1 || WT_C % d.groups != 0)) return false;
   if (d.N != d.Lin || d.N % WT_TN != 0) return false;
   if (reinterpret_cast<uintptr_t>(d.x) & 15) return false;
-  if ((reinterpret_cast<uintptr_t>(d.out) | reinterpret_cast<uintptr_t>(d.res)) & 7) return false;
+  if ((reinterpret_cast<uintptr_t>(d.out) | reinterpret_cast<uintptr_t>(d.res) | reinterpret_cast<uintptr_t>(d.bias)) & 15)
+    return false;  // 16-byte epilogue accesses
   if (d.B * (d.N / WT_TN) >= (int64_t)1 << 30 || d.B * WT_C * d.Lin >= (int64_t)1 << 40) return false;
   if ((WT_C + 1) * d.Lin * 4 >= (int64_t)1 << 32) return false;  // a tile's rows are addressed by 32-bit byte offsets
   return true;

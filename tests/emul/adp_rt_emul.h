@@ -360,6 +360,10 @@ static inline void adp_setprio(int) {}
 static inline float adp_exp2(float x) { return exp2f(x); }
 static inline int adp_uniform(int v) { return v; }
 static inline float adp_read_lane(float v, int src) { return adp_emul::shfl_idx(v, src); }
+static inline float adp_row16_sum(float v) {
+  for (int o = 1; o < 16; o <<= 1) v += adp_emul::shfl_idx(v, adp_emul::lane_id() ^ o);
+  return v;
+}
 static inline float adp_half_sum(float v) {  // (valid in every lane here; the hardware form only in lanes 16-31 / 48-63)
   for (int o = 1; o < 32; o <<= 1) v += adp_emul::shfl_idx(v, adp_emul::lane_id() ^ o);
   return v;
