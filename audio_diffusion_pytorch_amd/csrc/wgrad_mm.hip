@@ -514,7 +514,7 @@ int pick_wg(const adp_wgrad_desc& d, void* stream) {
 }
 
 // Winograd F(2,3) form of the kernel-3 weight gradients (WN): same switch as the forward / data-gradient convs
-// (ADP_CONV_WINO, conv_mm.hip), for layers with at least ADP_WINO_WGRAD_MIN_R (default 64) channels
+// (ADP_CONV_WINO, conv_mm.hip), for layers with at least ADP_WINO_WGRAD_MIN_R (default 32) channels
 bool wg_winograd(const adp_wgrad_desc& d) {
   if (!adp_winograd_enabled()) return false;
   const char* mr = getenv("ADP_WINO_WGRAD_MIN_R");
