@@ -92,6 +92,8 @@ SIGNATURES = {
     "adp_cfg_mix": (c_int, [P, I, F, P, P]),
     "adp_select_rows": (c_int, [P, P, P, I, I, P, P]),
     "adp_resample": (c_int, [P, P, I, I, I, I, I, I, I, P, P]),
+    "adp_ctx_fold_fwd": (c_int, [P, P, P, I, I, I, P, P, P]),
+    "adp_ctx_fold_bwd": (c_int, [P, P, P, P, P, I, I, I, P, P, P, P]),
     "adp_attn_fwd": (c_int, [P, P, P, I, I, I, I, I, I, I, P, P, P, P]),
     "adp_attn_fwd_ws_bytes": (I, [I, I, I, I, I]),
     "adp_attn_bwd_ws_bytes": (I, [I, I, I, I, I]),

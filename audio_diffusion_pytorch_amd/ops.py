@@ -520,12 +520,39 @@ def attn_fwd(q: Tensor, kv: Tensor, heads: int, head_features: int):
     return o, lse
 
 
-def attn_bwd(q: Tensor, kv: Tensor, o: Tensor, dout: Tensor, lse: Tensor, heads: int, head_features: int):
+def ctx_fold_fwd(tab: Tensor, I: int, M2: int, E: int):
+    """Folded context bank of I CrossAttentionItems (adp_ctx_fold_fwd): tab = device int64 [3, I] pointers of (to_kv weight
+    [M2, E], norm_context weight [E], norm_context bias [E]) -> (w_all [I*M2, E] = W_i diag(gamma_i), bias_all [I*M2] = W_i beta_i)."""
+    w_all = torch.empty((I * M2, E), dtype=torch.float32, device=tab.device)
+    bias_all = torch.empty((I * M2,), dtype=torch.float32, device=tab.device)
+    _C.tag(bytes=8 * w_all.numel(), shape=f"I{I} M{M2} E{E}")
+    _C.call("adp_ctx_fold_fwd", ptr(tab[0], torch.int64), ptr(tab[1], torch.int64), ptr(tab[2], torch.int64), I, M2, E,
+            ptr(w_all), ptr(bias_all), _C.stream())
+    return w_all, bias_all
+
+
+def ctx_fold_bwd(tab: Tensor, dw_all: Tensor, dbias_all: Tensor, I: int, M2: int, E: int, flat: Tensor, dw_off: Tensor,
+                 dgb_off: Tensor) -> None:
+    """Gradients of the folded bank back to the items' parameters, written into the flat gradient buffer (adp_ctx_fold_bwd)."""
+    _C.tag(bytes=12 * dw_all.numel(), shape=f"I{I} M{M2} E{E}")
+    _C.call("adp_ctx_fold_bwd", ptr(tab[0], torch.int64), ptr(tab[1], torch.int64), ptr(tab[2], torch.int64), ptr(dw_all),
+            ptr(dbias_all), I, M2, E, ptr(flat), ptr(dw_off, torch.int64), ptr(dgb_off, torch.int64), _C.stream())
+
+
+def copy_rows(src: Tensor, src_stride: int, dst: Tensor, dst_stride: int, rows: int, cols: int) -> None:
+    """dst[r * dst_stride + c] = src[r * src_stride + c] over flat fp32 views (adp_copy2d)."""
+    _C.call("adp_copy2d", ptr(src), src_stride, ptr(dst), dst_stride, rows, cols, _C.stream())
+
+
+def attn_bwd(q: Tensor, kv: Tensor, o: Tensor, dout: Tensor, lse: Tensor, heads: int, head_features: int,
+             dkv: Optional[Tensor] = None):
     """Returns (dq [B, H*D, n], dkv [B, 2*H*D, m])."""
     B, mid, n = q.shape
     m = kv.shape[2]
     H, D = heads, head_features
-    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    dq = torch.empty_like(q)
+    if dkv is None:
+        dkv = torch.empty_like(kv)
     ws = _ws(_C.query("adp_attn_bwd_ws_bytes", B, H, D, n, m), q)
     kvf, dkvf = kv.view(-1), dkv.view(-1)
     # QK^T is recomputed in both passes: dV, dP, dK in the key/value pass and dP, dQ in the query pass (7 contractions)

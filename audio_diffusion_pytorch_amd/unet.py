@@ -728,6 +728,10 @@ class _UNetFn(torch.autograd.Function):
         run.conditioning(time, features)
         run.emb_grad = None
         run.want_emb_grad = bool(embedding is not None and ctx.needs_input_grad[4])
+        run.ctx_bank = None
+        if embedding is not None and os.environ.get("ADP_CTX_BANK", "1") != "0":
+            from .attention import CtxBank
+            run.ctx_bank = CtxBank.prepare(run, embedding.contiguous())
         y = run.block(0, x, x2, embedding.contiguous() if embedding is not None else None, channels,
                       need_dx=bool(ctx.needs_input_grad[1]))
         ctx.run = run
@@ -770,6 +774,8 @@ class _UNetFn(torch.autograd.Function):
                         w0 = offs["bank_weight"][0]
                         hook(flat, w0 + ra * net.mf, w0 + rb * net.mf)
         run.mod_sums.flush()  # (nothing is left when every Modulation belongs to a tagged block)
+        if run.ctx_bank is not None:
+            run.ctx_bank.backward(run)
         dfeat = run.conditioning_backward()
         if hook is not None:
             for a, b in net.nonblock_param_ranges():

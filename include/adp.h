@@ -270,6 +270,19 @@ int adp_attn_bwd(const float* q, const float* k, const float* v, const float* o,
                  int64_t kv_bstride, float* dq, float* dk, float* dv, float* ws, void* stream);
 int64_t adp_attn_bwd_ws_bytes(int64_t B, int64_t H, int64_t D, int64_t n, int64_t m);
 
+/* The context side of all CrossAttentionItems of a U-Net as one weight bank (components.py:93: every item projects the SAME
+ * embedding through its own LayerNorm + to_kv).  With xhat = LayerNorm-without-affine(context) computed once,
+ * kv_i = (W_i diag(gamma_i)) xhat + W_i beta_i: adp_ctx_fold_fwd writes the folded bank w_all [I*M2, E] and bias_all [I*M2]
+ * from I per-item tensors (w, gamma, beta: DEVICE arrays of I pointers; W_i is [M2, E] row-major), so that ONE adp_conv1d
+ * yields every item's k | v.  adp_ctx_fold_bwd turns the bank's gradients (dw_all, dbias_all from ONE adp_conv1d_wgrad) into
+ * dW_i = dW'_i diag(gamma_i) + db'_i beta_i^T at flat[dw_off[i]] and [dgamma_i | dbeta_i] (2E floats) at flat[dgb_off[i]]
+ * (dw_off / dgb_off: device arrays of element offsets into the caller's flat gradient buffer). */
+int adp_ctx_fold_fwd(const float* const* w, const float* const* gamma, const float* const* beta, int64_t I, int64_t M2,
+                     int64_t E, float* w_all, float* bias_all, void* stream);
+int adp_ctx_fold_bwd(const float* const* w, const float* const* gamma, const float* const* beta, const float* dw_all,
+                     const float* dbias_all, int64_t I, int64_t M2, int64_t E, float* flat, const int64_t* dw_off,
+                     const int64_t* dgb_off, void* stream);
+
 /* one VInpainter resample step (diffusion.py:339-350): x_new = mask ? a1*source + b1*noise
  *                                                                  : a1*(a0 x - b0 v) + b1*(b0 x + a0 v);
  * ab4 = device [a_i, b_i, a_j, b_j] (j = i + 1 on the last resample of a step, else i); mask is 1 byte / element */

@@ -857,6 +857,35 @@ def test_attention_fwd_bwd(dev, B, H, D, n, m):
     assert rel_err(dkv, dkv_ref) < TOL
 
 
+@pytest.mark.parametrize("I,M2,E", [(3, 16, 12), (2, 40, 70), (5, 64, 33)])
+def test_ctx_fold_fwd_bwd(dev, I, M2, E):
+    """adp_ctx_fold_fwd / _bwd (ctx_bank.hip): w_all = W_i diag(gamma_i), bias_all = W_i beta_i per item of the bank and the
+    transpose of that map, written at given offsets of a flat gradient buffer (ragged E: not a multiple of the wave / of 32)."""
+    W = [rnd(M2, E, seed=10 + i).to(dev) for i in range(I)]
+    ga = [rnd(E, seed=20 + i).to(dev) for i in range(I)]
+    be = [rnd(E, seed=30 + i).to(dev) for i in range(I)]
+    tab = torch.tensor([[t.data_ptr() for t in W], [t.data_ptr() for t in ga], [t.data_ptr() for t in be]],
+                       dtype=torch.int64).to(dev)
+    w_all, b_all = ops.ctx_fold_fwd(tab, I, M2, E)
+    for i in range(I):
+        assert rel_err(w_all[i * M2:(i + 1) * M2], W[i] * ga[i][None, :]) < TOL
+        assert rel_err(b_all[i * M2:(i + 1) * M2], W[i] @ be[i]) < TOL
+    dw_all, db_all = rnd(I * M2, E, seed=40).to(dev), rnd(I * M2, seed=41).to(dev)
+    per = M2 * E + 2 * E + 5  # (a gap between the items' regions)
+    flat = torch.full((I * per + 3,), 7.0, device=dev)
+    dw_off = torch.tensor([3 + i * per + 2 * E + 5 for i in range(I)], dtype=torch.int64).to(dev)
+    dgb_off = torch.tensor([3 + i * per for i in range(I)], dtype=torch.int64).to(dev)
+    ops.ctx_fold_bwd(tab, dw_all, db_all, I, M2, E, flat, dw_off, dgb_off)
+    for i in range(I):
+        dW, db = dw_all[i * M2:(i + 1) * M2], db_all[i * M2:(i + 1) * M2]
+        a = 3 + i * per
+        assert rel_err(flat[a + 2 * E + 5:a + per].view(M2, E), dW * ga[i][None, :] + db[:, None] * be[i][None, :]) < TOL
+        assert rel_err(flat[a:a + E], (dW * W[i]).sum(0)) < TOL
+        assert rel_err(flat[a + E:a + 2 * E], db @ W[i]) < TOL
+        assert bool((flat[a + 2 * E:a + 2 * E + 5] == 7.0).all())
+    assert bool((flat[:3] == 7.0).all())
+
+
 @pytest.mark.parametrize("B,R,M,L,KT,stride,up", [
     (2, 32, 64, 200, 3, 1, 1),     # conv_mm, ragged last tile
     (1, 64, 32, 128, 1, 1, 1),     # conv_mm 1x1

@@ -202,14 +202,17 @@ ATTN = dict(in_channels=2, channels=[8, 16, 32], factors=[1, 2, 2], items=[1, 1,
             embedding_features=12)
 
 
-def test_unet_attention_self_and_cross(dev):
+@pytest.mark.parametrize("batch,bank", [(2, "1"), (1, "1"), (2, "0")])
+def test_unet_attention_self_and_cross(dev, batch, bank, monkeypatch):
     """README attention layout at tiny size (self attention + cross attention over an injected embedding:
-    BASELINE config 4 feeds `embedding=` directly)."""
+    BASELINE config 4 feeds `embedding=` directly).  bank = the context side of the four cross-attention
+    items as one folded weight bank (attention.CtxBank: slice views at batch 1, row copies otherwise) or item by item."""
+    monkeypatch.setenv("ADP_CTX_BANK", bank)
     oracle, net = build_pair(ATTN, dev)
     g = torch.Generator().manual_seed(4)
-    x = torch.randn(2, 2, 96, generator=g)
-    t = torch.tensor([0.15, 0.65])
-    emb = torch.randn(2, 5, 12, generator=g).requires_grad_()
+    x = torch.randn(batch, 2, 96, generator=g)
+    t = torch.tensor([0.15, 0.65][:batch])
+    emb = torch.randn(batch, 5, 12, generator=g).requires_grad_()
     y_ref = oracle(x, t, embedding=emb)
     emb_d = emb.detach().to(dev).requires_grad_()
     y = net(x.to(dev), t.to(dev), embedding=emb_d)
@@ -219,6 +222,7 @@ def test_unet_attention_self_and_cross(dev):
     y.backward(gy.to(dev))
     compare_grads(net, oracle)
     assert rel_err(emb_d.grad, emb.grad) < TOL
+    assert (getattr(net.net if hasattr(net, "net") else net, "_ctx_tables", None) is not None) == (bank == "1")
 
 
 def test_classifier_free_guidance(dev):
