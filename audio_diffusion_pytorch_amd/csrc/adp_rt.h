@@ -67,6 +67,9 @@ __device__ __forceinline__ void adp_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Keeps two registers occupied up to this point without an instruction (register-allocation hint: see conv_mm's chunk-ahead reads)
+__device__ __forceinline__ void adp_keep(float a, float b) { asm volatile("" ::"v"(a), "v"(b)); }
+
 // Issue priority of this wave among the waves of its SIMD (0-3; s_setprio takes an immediate)
 __device__ __forceinline__ void adp_setprio(int p) {
   if (p >= 3) __builtin_amdgcn_s_setprio(3);

@@ -98,7 +98,7 @@ struct cmax {
 // NSP > 1 (2 / 4; short K, long N: the mid-depth layers): the block covers NSP adjacent 64-position tiles and the MMA
 // waves trade K groups for positions (NKG = 4 / NSP), so a block stages the same weight chunk once for NSP times the
 // outputs, half / none of the K-group exchange remains, and a wave issues NSP times the MFMAs per barrier.
-template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD, bool WN = false, int NSP = 1>
+template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD, bool WN = false, int NSP = 1, bool PF = false>
 __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD, NSP)) * 64) void conv_mm_kernel(
     adp_conv_desc d, int KS) {
   static_assert(!WN || (KT == 3 && S == 1), "Winograd F(2,3): kernel 3, stride 1 (any upsample factor: the LDS tile "
@@ -275,6 +275,72 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD, NSP)
   const int afrag = TR ? 4 * hi * AS + (wm0 + l31) * KT                // + (ci + c) * AS + (KT - 1 - t)
                        : (wm0 + l31) * AS + 4 * hi * KT;               // + ci * KT + (c * KT + t)
   if (PRO == 1) __syncthreads();
+  if constexpr (PF) {
+    // ---- fragment reads one CHUNK ahead (8-wave blocks: the register file has room for a second fragment set): after barrier
+    // B_c the wave REQUESTS chunk c's fragments and multiplies chunk c-1 from the other register set, so the LDS latency of a
+    // chunk lies under the previous chunk's MFMAs instead of between a barrier and the first MFMA (one MMA wave per SIMD here:
+    // nothing else hides it; tools/probe wn_probe: 93 -> 62-66 cycles per MFMA).  Same barriers, same loader code: chunk c's
+    // reads are complete when the wave arrives at B_{c+1} (the barrier's own lgkmcnt(0)), which is what the loaders' store of
+    // chunk c+2 into the same buffer waits for.
+    static_assert(WN && CPK == 8 && NSP == 1, "chunk-ahead fragments: one K-group step per chunk");
+    auto rd = [&](int c, float (&av)[4 * KT], f32x2 (&px)[4][3]) {
+      const float* Ab = smem + (c & 1) * (A_ELEMS + X_ELEMS);
+      const float* Xb = Ab + A_ELEMS;
+      const int ci = kg * CPK;
+      if (!TR) {
+        const float* ap = Ab + afrag + ci * KT;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(ap + 4 * j);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) av[4 * j + k] = q[k];
+        }
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+          for (int t = 0; t < KT; ++t) av[cc * KT + t] = Ab[afrag + (ci + cc) * AS + (KT - 1 - t)];
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const float* xp = Xb + xfrag + (ci + cc) * XSP;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) px[cc][q] = *reinterpret_cast<const f32x2*>(xp + 2 * q);
+      }
+    };
+    auto mm = [&](const float (&av)[4 * KT], const f32x2 (&px)[4][3]) {
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const float d0 = px[cc][0][1], d1 = px[cc][1][0], d2 = px[cc][1][1], d3 = px[cc][2][0];
+        const float g0 = av[cc * KT], g1 = av[cc * KT + 1], g2 = av[cc * KT + 2];
+        const float gs = g0 + g2;
+        acc[0] = adp_mfma32(g0, d0 - d2, acc[0]);
+        acc[1] = adp_mfma32(gs + g1, d1 + d2, acc[1]);
+        acc[2] = adp_mfma32(gs - g1, d2 - d1, acc[2]);
+        acc[3] = adp_mfma32(g2, d1 - d3, acc[3]);
+      }
+      // the outer floats of the 24-byte windows are never used: keep their registers occupied until here, or the register
+      // allocator hands them out as temporaries while the read that fills them is still in flight (a wait in mid-chunk)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) adp_keep(px[cc][0][0], px[cc][2][1]);
+    };
+    float avA[4 * KT], avB[4 * KT];
+    f32x2 pxA[4][3], pxB[4][3];
+    for (int c = 0; c < nrounds; c += 2) {  // (ghost chunks re-read the last staged chunk: never multiplied)
+      __syncthreads();  // B_c
+      rd(c, avA, pxA);
+      if (c >= 1 && c - 1 < nchunks) mm(avB, pxB);
+      if (c + 1 < nrounds) {
+        __syncthreads();  // B_{c+1}
+        rd(c + 1, avB, pxB);
+        if (c < nchunks) mm(avA, pxA);
+      }
+    }
+    if (nrounds - 1 < nchunks) {
+      if ((nrounds - 1) & 1) mm(avB, pxB);
+      else mm(avA, pxA);
+    }
+  } else
   for (int c = 0; c < nrounds; ++c) {
     __syncthreads();  // B_c: chunk c is in LDS[c & 1]
     if (c < nchunks) {
@@ -530,6 +596,17 @@ template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD, bool
 int launch_mm(const adp_conv_desc& d, void* stream) {
   const int64_t blocks = (d.M / BM) * adp_cdiv(d.N, MM_BN * NSP) * d.B;
   const int KS = d.ws ? (int)adp_conv_mm_ksplit(d) : 1;
+  // chunk-ahead fragment reads (PF) for the 8-wave blocks -- one MMA wave per SIMD: step 13.32 -> 13.25 ms, batch 1 7.09 -> 6.99,
+  // sampler 2.407 -> 2.383 (ADP_MM_PF=0/1 interleaved on one box).  The 12-wave 64-row blocks (two MMA waves per SIMD hide each
+  // other's reads) lose with it: 13.16 -> 13.27 ms.
+  if constexpr (WN && BM == 32 && NSP == 1 && BKT == 32 && UP == 1 && mm_nld(PRO, BM, PD, NSP) == 4) {
+    const char* e = getenv("ADP_MM_PF");
+    if (!e || e[0] != '0') {
+      ADP_LAUNCH((conv_mm_kernel<BM, KT, S, UP, TR, PRO, BKT, PD, WN, NSP, true>), dim3((unsigned)blocks, (unsigned)KS),
+                 dim3(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD, NSP)) * 64), stream, d, KS);
+      return ADP_LAUNCH_OK();
+    }
+  }
   ADP_LAUNCH((conv_mm_kernel<BM, KT, S, UP, TR, PRO, BKT, PD, WN, NSP>), dim3((unsigned)blocks, (unsigned)KS),
              dim3(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD, NSP)) * 64), stream, d, KS);
   return ADP_LAUNCH_OK();
@@ -548,6 +625,7 @@ int launch_pd(const adp_conv_desc& d, void* stream) {
   }
   // (a 64-channel chunk already is two 32-channel register stages; a second one does not fit the register file)
   // (a third register stage for the short Winograd chunks was measured: 14.37 -> 15.17 ms per step, rejected)
+  // (four register stages for the batch-1 deep layers, 16 chunks per block: batch-1 step 7.97 -> 8.10 ms, sampler 2.75 -> 2.80)
   if (BKT < 64 && d.R / BKT / KS >= 4) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 2, WN>(d, stream);
   return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1, WN>(d, stream);
 }

@@ -356,6 +356,7 @@ static inline void adp_barrier_consume() { adp_emul::sync_block(); }
 static inline void adp_barrier_lds() { adp_emul::sync_block(); }
 static inline void adp_sched_fence() {}
 static inline void adp_wave_sync() { adp_emul::sync_wave(); }
+static inline void adp_keep(float, float) {}
 static inline void adp_setprio(int) {}
 static inline float adp_exp2(float x) { return exp2f(x); }
 static inline int adp_uniform(int v) { return v; }
