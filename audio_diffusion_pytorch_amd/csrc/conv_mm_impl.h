@@ -375,6 +375,9 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD, NSP)
 #pragma unroll
             for (int q = 0; q < 3; ++q) px[cc][q] = *reinterpret_cast<const f32x2*>(xp + 2 * q);
           }
+          // (measured in round 4: a scheduler fence here + adp_keep on the unused window floats gives "barrier, 9 reads, 16 MFMAs"
+          //  in the ISA instead of the compiler's interleaving of reads and MFMAs -- and 13.16 -> 13.31 ms per step: with two MMA
+          //  waves per SIMD the spread-out reads share the LDS better than eight waves reading everything right after the barrier)
 #pragma unroll
           for (int cc = 0; cc < 4; ++cc) {
             const float d0 = px[cc][0][1], d1 = px[cc][1][0], d2 = px[cc][1][1], d3 = px[cc][2][0];
