@@ -67,6 +67,9 @@ __device__ __forceinline__ void adp_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The value is materialised in registers HERE (optimisation barrier for code motion across this point, no instruction)
+__device__ __forceinline__ void adp_pin(f32x2& v) { asm volatile("" : "+v"(v)); }
+
 // Keeps two registers occupied up to this point without an instruction (register-allocation hint: see conv_mm's chunk-ahead reads)
 __device__ __forceinline__ void adp_keep(float a, float b) { asm volatile("" ::"v"(a), "v"(b)); }
 
@@ -108,6 +111,13 @@ __device__ __forceinline__ float adp_half_sum(float v) {
   return v;
 }
 __device__ __forceinline__ float adp_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+// value of the previous / next lane of the wave (DPP wave_shr:1 / wave_shl:1, no LDS); lane 0 / lane 63 keep `edge`
+__device__ __forceinline__ float adp_lane_prev(float edge, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float adp_lane_next(float edge, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
 
 // 100 MHz wall clock (s_memrealtime) and a parked wait on it: staggers the waves that share a SIMD without a barrier.
 __device__ __forceinline__ long long adp_clock() { return (long long)wall_clock64(); }
@@ -141,6 +151,12 @@ __device__ __forceinline__ float adp_sigmoid(float h) { return 1.0f / (1.0f + __
 __device__ __forceinline__ float adp_silu(float h) { return h * adp_sigmoid(h); }
 // hot-loop form: v_exp_f32 + v_rcp_f32, ~2 ulp (the 1e-3 parity contract has 4 orders of magnitude of slack)
 __device__ __forceinline__ float adp_silu_fast(float h) { return h * adp_rcp(1.0f + __expf(-h)); }
+// SiLU of two values: packed multiplies / adds around the two transcendental pairs (v_exp_f32, v_rcp_f32)
+__device__ __forceinline__ f32x2 adp_silu2(f32x2 h) {
+  const f32x2 t = h * -1.4426950408889634f;
+  const f32x2 den = f32x2{adp_exp2(t[0]), adp_exp2(t[1])} + 1.0f;
+  return h * f32x2{adp_rcp(den[0]), adp_rcp(den[1])};
+}
 // d silu(h) / dh
 __device__ __forceinline__ float adp_dsilu(float h) {
   float s = adp_sigmoid(h);

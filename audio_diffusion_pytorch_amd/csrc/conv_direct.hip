@@ -217,6 +217,127 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(adp_conv_desc d) {
   }
 }
 
+// ---- kernel 3, stride 1, at most 8 input channels (the depth-0 ConvBlocks and their data gradients: 8 x 8 x 3 weights against
+// 2**18 positions).  Same thread <-> data mapping as conv_direct_kernel (four consecutive positions, 8 output channels), on a
+// diet (alu_probe: the generic kernel spent ~1500 VALU issue slots per thread on a 67 MB launch):
+//   * the two halo elements of a thread's window come from the neighbouring LANES (DPP wave shifts of the ACTIVATED values), so a
+//     row costs one 16-byte load + one masked 4-byte load for the wave's two outer lanes, and five activations instead of six;
+//   * the contraction runs on packed FMAs over position pairs: the window is kept as the five overlapping pairs
+//     (L,a0) (a0,a1) (a1,a2) (a2,a3) (a3,R); SiLU in packed form around its two transcendentals;
+//   * every global load of the thread is issued before the first activation; input rows are streamed against acc[8][2 pairs].
+template <bool PRO, int RR>
+__global__ __launch_bounds__(256) void conv_direct8_kernel(adp_conv_desc d) {
+  __shared__ __attribute__((aligned(16))) float Ws[RR * 24];  // [r][t][m], zero beyond R / M
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int M = (int)d.M, R = (int)d.R, R1 = (int)d.R1, N = (int)d.N;
+  const int b = blockIdx.z, m0 = blockIdx.y * 8;
+  const int n0 = (blockIdx.x * 256 + tid) * 4;
+  if (tid < RR * 24) {
+    const int r = tid / 24, k = tid - r * 24, t = k >> 3, m = k & 7;
+    float v = 0.0f;
+    if (r < R && m0 + m < M)
+      v = d.transposed ? d.w[((int64_t)r * M + m0 + m) * 3 + (2 - t)] : d.w[((int64_t)(m0 + m) * R + r) * 3 + t];
+    Ws[tid] = v;
+  }
+  const bool valid = n0 < N;
+  // the wave's outer lanes fetch the element beyond the wave's 256 positions (lane 0: n0 - 1, lane 63: n0 + 4)
+  const int hoff = lane == 0 ? n0 - 1 : n0 + 4;
+  const bool hok = valid && ((lane == 0 && n0 > 0) || (lane == 63 && n0 + 4 < N));
+  // every load is unconditional (clamped addresses: rows beyond R re-read row R - 1 against zero weights, threads beyond N
+  // re-read the last quad and store nothing) -- conditional loads cost a register copy of the whole window set per branch
+  const int n0c = valid ? n0 : N - 4, hoffc = hok ? hoff : n0c;
+  f32x4 xq[RR];
+  float hv[RR];
+#pragma unroll
+  for (int r = 0; r < RR; ++r) {
+    const int rc = r < R ? r : R - 1;
+    const float* row = (rc < R1) ? d.x + ((int64_t)b * R1 + rc) * N : d.x2 + ((int64_t)b * (R - R1) + (rc - R1)) * N;
+    xq[r] = *reinterpret_cast<const f32x4*>(row + n0c);
+    hv[r] = row[hoffc];
+  }
+  float pa[RR], pb[RR];
+  if (PRO) {
+    const int cpg = R / (int)d.groups;
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+      const int rc = r < R ? r : R - 1, g = rc / cpg;
+      const float mean = d.pro_stats[((int64_t)b * d.groups + g) * 2];
+      pa[r] = (d.pro_gamma ? d.pro_gamma[rc] : 1.0f) * d.pro_stats[((int64_t)b * d.groups + g) * 2 + 1];
+      pb[r] = (d.pro_beta ? d.pro_beta[rc] : 0.0f) - mean * pa[r];
+    }
+  }
+  __syncthreads();
+  f32x2 acc[8][2];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m][0] = acc[m][1] = f32x2{0.0f, 0.0f};
+#pragma unroll
+  for (int r = 0; r < RR; ++r) {  // (rows beyond R carry zero weights)
+    f32x2 a01 = f32x2{xq[r][0], xq[r][1]}, a23 = f32x2{xq[r][2], xq[r][3]};
+    float ah = hv[r];
+    if (PRO) {
+      a01 = adp_silu2(a01 * pa[r] + pb[r]);
+      a23 = adp_silu2(a23 * pa[r] + pb[r]);
+      ah = adp_silu_fast(fmaf(ah, pa[r], pb[r]));
+    }
+    ah = hok ? ah : 0.0f;  // zero padding (applied after the activation); the row's first / last quad has no neighbour
+    float lft = adp_lane_prev(ah, a23[1]), rgt = adp_lane_next(ah, a01[0]);
+    lft = n0 > 0 ? lft : 0.0f;
+    rgt = n0 + 4 < N ? rgt : 0.0f;
+    // the window (lft, a0, a1, a2, a3, rgt) as its five overlapping pairs: e01 a01 a12 a23 e45
+    const f32x2 e01 = f32x2{lft, a01[0]}, a12 = f32x2{a01[1], a23[0]}, e45 = f32x2{a23[1], rgt};
+    const float* wp = Ws + r * 24;
+    float wv[24];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(wp + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wv[4 * q + j] = t4[j];
+    }
+    // outputs (0,1) see the pairs e01 / a01 / a12 under taps 0 / 1 / 2, outputs (2,3) a12 / a23 / e45; eight independent
+    // accumulators per line, so no packed FMA waits for its predecessor
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m][0] = e01 * wv[m] + acc[m][0];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m][1] = a12 * wv[m] + acc[m][1];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m][0] = a01 * wv[8 + m] + acc[m][0];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m][1] = a23 * wv[8 + m] + acc[m][1];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m][0] = a12 * wv[16 + m] + acc[m][0];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m][1] = e45 * wv[16 + m] + acc[m][1];
+  }
+  // (without this the optimiser sinks the whole contraction into the per-channel blocks of the epilogue below -- all 192
+  //  weights live at once, 256 registers + spills)
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    adp_pin(acc[m][0]);
+    adp_pin(acc[m][1]);
+  }
+  if (!valid) return;
+  const int64_t ebs = d.e_bstride ? d.e_bstride : M;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int mm = m0 + m;
+    if (mm >= M) break;
+    const float bias = d.bias ? d.bias[mm] : 0.0f;
+    f32x4 v = f32x4{acc[m][0][0] + bias, acc[m][0][1] + bias, acc[m][1][0] + bias, acc[m][1][1] + bias};
+    const int64_t o = ((int64_t)b * M + mm) * N + n0;
+    if (d.out_pre) *reinterpret_cast<f32x4*>(d.out_pre + o) = v;
+    if (d.e_scale) v = v * d.e_scale[b * ebs + mm];
+    if (d.res) v = v + *reinterpret_cast<const f32x4*>(d.res + o);
+    *reinterpret_cast<f32x4*>(d.out + o) = v;
+  }
+}
+
+template <bool PRO, int RR>
+int launch_dc8(const adp_conv_desc& d, void* stream) {
+  dim3 grid((unsigned)adp_cdiv(d.N, 1024), (unsigned)adp_cdiv(d.M, DC_MB), (unsigned)d.B);
+  ADP_LAUNCH((conv_direct8_kernel<PRO, RR>), grid, dim3(256), stream, d);
+  return ADP_LAUNCH_OK();
+}
+
 template <int KT, int S, int UP>
 int launch_dc(const adp_conv_desc& d, void* stream) {
   dim3 grid((unsigned)adp_cdiv(d.N, 1024), (unsigned)adp_cdiv(d.M, DC_MB), (unsigned)d.B);
@@ -249,6 +370,10 @@ int adp_conv_direct(const adp_conv_desc& d, void* stream) {
   if (d.stride == 2) return launch_dc<2, 2, 1>(d, stream);
   if (d.stride == 4) return launch_dc<4, 4, 1>(d, stream);
   if (d.KT == 3) {
+    if (d.up == 1 && d.R <= 8 && d.store == 0 && d.N == d.Lin) {
+      if (d.R <= 2) return d.prologue == 1 ? launch_dc8<true, 2>(d, stream) : launch_dc8<false, 2>(d, stream);
+      return d.prologue == 1 ? launch_dc8<true, 8>(d, stream) : launch_dc8<false, 8>(d, stream);
+    }
     if (d.up == 2) return launch_dc<3, 1, 2>(d, stream);
     if (d.up == 4) return launch_dc<3, 1, 4>(d, stream);
     return launch_dc<3, 1, 1>(d, stream);

@@ -58,6 +58,8 @@ struct f32x4 {
   float& operator[](int i) { return v[i]; }
   const float& operator[](int i) const { return v[i]; }
 };
+static inline f32x4 operator+(f32x4 a, f32x4 b) { return f32x4{{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]}}; }
+static inline f32x4 operator*(f32x4 a, float b) { return f32x4{{a[0] * b, a[1] * b, a[2] * b, a[3] * b}}; }
 
 #define __global__
 #define __device__
@@ -357,8 +359,19 @@ static inline void adp_barrier_lds() { adp_emul::sync_block(); }
 static inline void adp_sched_fence() {}
 static inline void adp_wave_sync() { adp_emul::sync_wave(); }
 static inline void adp_keep(float, float) {}
+static inline void adp_pin(f32x2&) {}
 static inline void adp_setprio(int) {}
 static inline float adp_exp2(float x) { return exp2f(x); }
+static inline float adp_lane_prev(float edge, float v) {
+  const int l = adp_emul::lane_id();
+  const float o = adp_emul::shfl_idx(v, l > 0 ? l - 1 : 0);
+  return l > 0 ? o : edge;
+}
+static inline float adp_lane_next(float edge, float v) {
+  const int l = adp_emul::lane_id();
+  const float o = adp_emul::shfl_idx(v, l < 63 ? l + 1 : 63);
+  return l < 63 ? o : edge;
+}
 static inline int adp_uniform(int v) { return v; }
 static inline float adp_read_lane(float v, int src) { return adp_emul::shfl_idx(v, src); }
 static inline float adp_row16_sum(float v) {

@@ -270,6 +270,24 @@ def test_conv1d_concat_and_skipmod(dev):
     assert rel_err(out, ref) < TOL
 
 
+@pytest.mark.parametrize("R1,R2,M,L", [(8, 0, 8, 2304), (5, 3, 8, 1100), (2, 0, 6, 516)])
+def test_conv_direct8_prologue_concat(dev, R1, R2, M, L):
+    """conv_direct8 (kernel 3, <= 8 input channels) with the GroupNorm+SiLU prologue: the window's halo travels between lanes
+    AFTER the activation, zero padding stays zero; x2 concat; lengths with several waves, a ragged last workgroup."""
+    B, R, G = 2, R1 + R2, (R1 + R2) if (R1 + R2) < 8 else 8
+    xa = rnd(B, R, L, seed=1) * 1.5 + 0.3
+    w, b = rnd(M, R, 3, seed=3, scale=0.3), rnd(M, seed=4)
+    gamma, beta = rnd(R, seed=5) * 0.3 + 1.0, rnd(R, seed=6) * 0.2
+    ref = F.conv1d(ref_gn_silu(xa, G, gamma, beta), w, b, padding=1)
+    xd = xa.to(dev)
+    stats = ops.gn_stats(xd, G)
+    x1 = xd[:, :R1].contiguous()
+    x2 = xd[:, R1:].contiguous() if R2 else None
+    out = ops.conv1d(x1, w.to(dev), b.to(dev), pad=1, x2=x2, prologue=1, pro_stats=stats, pro_gamma=gamma.to(dev),
+                     pro_beta=beta.to(dev), groups=G)
+    assert rel_err(out, ref) < TOL
+
+
 # ------------------------------------------------------------------ deep-layer GEMM conv (conv_mm.hip)
 MM_CASES = [
     # B, R, M, L, KT, pad, dil -- every (tile, K-group) variant of the split-K-in-block kernel, multi-chunk K,
@@ -480,6 +498,9 @@ DIRECT_CASES = [
     (1, 32, 8, 60, 3, 1, 1, 4),
     (2, 16, 8, 34, 3, 1, 1, 2),
     (1, 8, 40, 64, 3, 1, 1, 1),       # 5 output-channel groups
+    (2, 5, 12, 772, 3, 1, 1, 1),      # 8-row kernel with 5 rows (clamped row loads), ragged channel group, threads beyond N
+    (1, 2, 8, 260, 3, 1, 1, 1),       # 2-row instantiation
+    (1, 8, 8, 4, 3, 1, 1, 1),         # one quad: both neighbours are padding
 ]
 
 

@@ -2,7 +2,8 @@
 time in the numbers): conv1 (GroupNorm+SiLU prologue, statistics epilogue), conv2 (+ residual), data gradient at
 [B, 32, 65536], next to a plain 2-read-1-write streaming kernel (adp_add) of the same tensors.  `warm` re-runs on one buffer
 set (input in the Infinity Cache, as behind its producer in the step), `cold` rotates four sets (400 MB: past the cache).
-TILE_CFGS = comma list of ADP_TILE_CFG values (stage gap in 10 ns ticks), TILE_BATCHES = comma list of batch sizes.
+TILE_CFGS = comma list of ADP_TILE_CFG values (stage gap in 10 ns ticks), TILE_BATCHES = comma list of batch sizes, TILE_C /
+TILE_L = channels / length (8 / 262144 = the depth-0 convs on conv_direct8).
 usage: python tools/tile_bench.py"""
 import os
 import sys
@@ -41,7 +42,7 @@ def graph_time(fns, reps=5):
 
 def main():
     dev = torch.device("cuda:0")
-    C, L, G = 32, 65536, 8
+    C, L, G = int(os.environ.get("TILE_C", "32")), int(os.environ.get("TILE_L", "65536")), 8  # (TILE_C=8 TILE_L=262144: depth 0, conv_direct8)
     for B in [int(v) for v in os.environ.get("TILE_BATCHES", "4").split(",")]:
         sets = []
         for _ in range(4):
@@ -54,7 +55,7 @@ def main():
 
         def conv1(s):
             return lambda: ops.conv1d(s["x"], w, bias, pad=1, prologue=1, pro_stats=s["stats"], pro_gamma=gamma,
-                                      pro_beta=beta, groups=G, out=s["out"], gn=ops.GnPart())
+                                      pro_beta=beta, groups=G, out=s["out"], gn=ops.GnPart() if C % 32 == 0 else None)
 
         def conv2(s):
             return lambda: ops.conv1d(s["x"], w, bias, pad=1, prologue=1, pro_stats=s["stats"], pro_gamma=gamma,
