@@ -118,6 +118,23 @@ __device__ __forceinline__ float adp_lane_prev(float edge, float v) {
 __device__ __forceinline__ float adp_lane_next(float edge, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
+// value of the previous / next lane within the 16-lane DPP row (row_shr:1 / row_shl:1); 0 at the row's first / last lane
+__device__ __forceinline__ float adp_row_prev(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float adp_row_next(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
+}
+// sum over each aligned group of 8 lanes with three DPP adds; valid in every lane of the group
+__device__ __forceinline__ float adp_oct_sum(float v) {
+#define ADP_DPP_ADD8(ctrl) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+  ADP_DPP_ADD8(0xB1);   // quad_perm [1,0,3,2]
+  ADP_DPP_ADD8(0x4E);   // quad_perm [2,3,0,1]
+  ADP_DPP_ADD8(0x141);  // row_half_mirror
+#undef ADP_DPP_ADD8
+  return v;
+}
 
 // 100 MHz wall clock (s_memrealtime) and a parked wait on it: staggers the waves that share a SIMD without a barrier.
 __device__ __forceinline__ long long adp_clock() { return (long long)wall_clock64(); }

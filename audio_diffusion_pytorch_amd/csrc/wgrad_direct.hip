@@ -13,6 +13,7 @@
 //     bank-conflict free; lanes sharing a row broadcast) and keeps its KT sums in registers for the whole kernel;
 //   * at the end the NSEG position shares are summed through LDS and each workgroup writes one partial; the
 //     partials are combined by adp_wgrad_reduce (fixed order: deterministic, no atomics).
+#include <type_traits>
 #include "adp_rt.h"
 #include "adp.h"
 #include "conv_internal.h"
@@ -157,6 +158,161 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(adp_wgrad_desc d, int
   }
 }
 
+// ---- kernel 3, stride 1, at most 8 x 8 channels (the depth-0 ConvBlocks): the weight gradient as a register streaming
+// reduction -- no LDS staging (the generic kernel above is bound by its LDS fragment reads at these shapes: four 16-byte reads per
+// 12 FMAs).  Lane = (input row r, quad q): the 8 lanes of a row group cover 32 consecutive positions, the 8 groups of the wave
+// the 8 input rows; a lane loads ITS row's quad (+ the halo from its neighbour lanes: DPP row shifts of the activated values) and
+// the dy quads of ALL output rows (the eight row groups read the same addresses: one fetch per wave instruction), and keeps the
+// sums dw[m][r][0..2], m = 0..7 in registers over its share of the positions (packed FMAs: the pair (t0, t1) against the window
+// pairs, t2 as two half sums).  One 8-lane butterfly + one LDS round per workgroup at the end; partials in the layout of
+// adp_wgrad_reduce like the generic kernel.
+constexpr int WD8_MAXBLOCKS = 1024;
+
+template <bool PRO>
+__global__ __launch_bounds__(256) void wgrad_direct8_kernel(adp_wgrad_desc d, int bpb, int spans_b) {
+  __shared__ float red[4][8][32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = adp_uniform(tid >> 6);  // scalar: the span loop and its full / tail branch are wave-uniform
+  const int r = lane >> 3, q = lane & 7;
+  const int M = (int)d.M, R = (int)d.R, R1 = (int)d.R1, N = (int)d.N, G = (int)d.groups;
+  const int b = blockIdx.y;
+  const int rc = r < R ? r : R - 1;  // (row groups beyond R re-read row R - 1; their sums are never stored)
+  const float* xrow = (rc < R1) ? d.x + ((int64_t)b * R1 + rc) * N : d.x2 + ((int64_t)b * (R - R1) + (rc - R1)) * N;
+  const float* dyb = d.dy + (int64_t)b * M * N;
+  float pa = 1.0f, pb = 0.0f;
+  if (PRO) {
+    const int g = rc / (R / G);
+    const float mean = d.pro_stats[((int64_t)b * G + g) * 2];
+    pa = (d.pro_gamma ? d.pro_gamma[rc] : 1.0f) * d.pro_stats[((int64_t)b * G + g) * 2 + 1];
+    pb = (d.pro_beta ? d.pro_beta[rc] : 0.0f) - mean * pa;
+  }
+  f32x2 acc01[8], acc2[8], bs[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc01[m] = acc2[m] = bs[m] = f32x2{0.0f, 0.0f};
+
+  struct Span {  // one lane's share of a 32-position span, as loaded: its input row's quad and the dy quad of output row m = r
+    f32x4 xq, dyq;
+    float ah;
+    bool hok, last;
+  };
+  // the dy quads travel between the wave's eight row groups through a wave-private LDS slot (no barrier: a wave's LDS
+  // instructions execute in order).  Every lane fetching all eight rows itself kept the texture path busy with 8x redundant
+  // requests: 21 us per launch against 67 MB)
+  __shared__ __attribute__((aligned(16))) float dysh[4][2][8][8][4];
+  auto load = [&](int s, Span& sp, auto tailc) {
+    constexpr bool TAIL = decltype(tailc)::value;  // spans that may be partly filled (N % 32 != 0) take the masked form
+    const int n0 = s * 32 + 4 * q;
+    const bool valid = !TAIL || n0 < N;
+    const int n0c = valid ? n0 : N - 4;
+    sp.hok = valid && ((q == 0 && n0 > 0) || (q == 7 && n0 + 4 < N));
+    sp.last = TAIL && n0 + 4 >= N;
+    const int hoffc = sp.hok ? (q == 0 ? n0 - 1 : n0 + 4) : n0c;
+    sp.xq = *reinterpret_cast<const f32x4*>(xrow + n0c);
+    sp.ah = xrow[hoffc];
+    const int mc = r < M ? r : M - 1;  // (rows beyond M: duplicates, never stored)
+    sp.dyq = *reinterpret_cast<const f32x4*>(dyb + (int64_t)mc * N + n0c);
+    if (TAIL && !valid) sp.dyq = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  };
+  auto compute = [&](const Span& sp, int slot) {
+    *reinterpret_cast<f32x4*>(&dysh[wave][slot][r][q][0]) = sp.dyq;
+    adp_wave_sync();
+    f32x4 dq[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) dq[m] = *reinterpret_cast<const f32x4*>(&dysh[wave][slot][m][q][0]);
+    f32x2 a01 = f32x2{sp.xq[0], sp.xq[1]}, a23 = f32x2{sp.xq[2], sp.xq[3]};
+    float ah = sp.ah;
+    if (PRO) {
+      a01 = adp_silu2(a01 * pa + pb);
+      a23 = adp_silu2(a23 * pa + pb);
+      ah = adp_silu_fast(fmaf(ah, pa, pb));
+    }
+    ah = sp.hok ? ah : 0.0f;  // zero padding is applied after the activation
+    float lft = adp_row_prev(a23[1]), rgt = adp_row_next(a01[0]);
+    lft = q == 0 ? ah : lft;
+    rgt = (q == 7 || sp.last) ? (q == 7 ? ah : 0.0f) : rgt;
+    const f32x2 e01 = f32x2{lft, a01[0]}, a12 = f32x2{a01[1], a23[0]}, e45 = f32x2{a23[1], rgt};
+    // dw[t] += dy[p] * win[p + t] over the window win = (lft, a0, a1, a2, a3, rgt): (t0, t1) against the pair (win[p], win[p+1])
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc01[m] = e01 * dq[m][0] + acc01[m];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc2[m] = f32x2{dq[m][0], dq[m][1]} * a12 + acc2[m];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc01[m] = a01 * dq[m][1] + acc01[m];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc2[m] = f32x2{dq[m][2], dq[m][3]} * e45 + acc2[m];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc01[m] = a12 * dq[m][2] + acc01[m];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) bs[m] = bs[m] + (f32x2{dq[m][0], dq[m][1]} + f32x2{dq[m][2], dq[m][3]});
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc01[m] = a23 * dq[m][3] + acc01[m];
+  };
+  // TWO spans per trip, both requested before the first is multiplied: the kernel is a latency-bound stream (one span per trip:
+  // 24 KB in flight per CU against the ~60 KB that 8 TB/s x 2 us asks for -- 21 us)
+  const int full = N / 32, stride = bpb * 4;
+  int s = blockIdx.x * 4 + wave;
+  for (; s + stride < full; s += 2 * stride) {
+    Span A, B;
+    load(s, A, std::false_type{});
+    load(s + stride, B, std::false_type{});
+    compute(A, 0);
+    compute(B, 1);
+  }
+  for (; s < spans_b; s += stride) {
+    Span A;
+    load(s, A, std::true_type{});
+    compute(A, 0);
+    adp_wave_sync();  // (the slot is rewritten by the next trip)
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    adp_pin(acc01[m]);
+    adp_pin(acc2[m]);
+    adp_pin(bs[m]);
+  }
+  // ---- the row group's 8 lanes, then the workgroup's 4 waves (fixed order), one partial per workgroup
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const float t0 = adp_oct_sum(acc01[m][0]), t1 = adp_oct_sum(acc01[m][1]), t2 = adp_oct_sum(acc2[m][0] + acc2[m][1]);
+    const float bb = adp_oct_sum(bs[m][0] + bs[m][1]);
+    if (q == 0) {
+      red[wave][r][3 * m] = t0;
+      red[wave][r][3 * m + 1] = t1;
+      red[wave][r][3 * m + 2] = t2;
+      red[wave][r][24 + m] = bb;
+    }
+  }
+  __syncthreads();
+  const int rr = tid >> 5, k = tid & 31;
+  const float sum = (red[0][rr][k] + red[1][rr][k]) + (red[2][rr][k] + red[3][rr][k]);
+  const int64_t cnt = (int64_t)M * R * 3, P = (int64_t)gridDim.x * gridDim.y, pidx = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (k < 24) {
+    const int m = k / 3, t = k - 3 * m;
+    if (rr < R && m < M) d.ws[pidx * cnt + ((int64_t)m * R + rr) * 3 + t] = sum;
+  } else if (rr == 0 && k - 24 < M && d.dbias) {
+    d.ws[P * cnt + pidx * M + (k - 24)] = sum;
+  }
+}
+
+static bool wd8_ok(const adp_wgrad_desc& d) {
+  return d.KT == 3 && d.stride == 1 && d.up == 1 && d.R <= 8 && d.M <= 8 && d.N == d.Lin && d.N >= 4;
+}
+// workgroups per batch element: four waves x >= 4 spans of 32 positions each, at most WD8_MAXBLOCKS partials in all
+static int wd8_bpb(const adp_wgrad_desc& d) {
+  const int64_t spans = adp_cdiv(d.N, 32);
+  int64_t bpb = adp_cdiv(spans, 16);
+  const int64_t cap = WD8_MAXBLOCKS / d.B > 0 ? WD8_MAXBLOCKS / d.B : 1;
+  return (int)(bpb < cap ? bpb : cap);
+}
+static int launch_wd8(const adp_wgrad_desc& d, void* stream) {
+  const int bpb = wd8_bpb(d), spans = (int)adp_cdiv(d.N, 32);
+  dim3 grid((unsigned)bpb, (unsigned)d.B);
+  if (d.prologue == 1) ADP_LAUNCH((wgrad_direct8_kernel<true>), grid, dim3(256), stream, d, bpb, spans);
+  else ADP_LAUNCH((wgrad_direct8_kernel<false>), grid, dim3(256), stream, d, bpb, spans);
+  if (ADP_LAUNCH_OK() != ADP_OK) return ADP_ERR_LAUNCH;
+  return adp_wgrad_reduce(d.ws, (int64_t)bpb * d.B, d.M * d.R * d.KT, d.M, d.dw, d.dbias, (int)d.accumulate, stream);
+}
+
 struct WdPlan {
   int np2, tpb, ntiles, blocks;
   size_t lds;
@@ -209,10 +365,12 @@ bool adp_wgrad_direct_eligible(const adp_wgrad_desc& d) {
 }
 
 int64_t adp_wgrad_direct_ws_floats(const adp_wgrad_desc& d) {
+  if (wd8_ok(d) && d.B <= 65535) return (int64_t)wd8_bpb(d) * d.B * (d.M * d.R * d.KT + d.M);
   return (int64_t)wd_plan(d).blocks * (d.M * d.R * d.KT + d.M);
 }
 
 int adp_wgrad_direct(const adp_wgrad_desc& d, void* stream) {
+  if (wd8_ok(d) && d.B <= 65535) return launch_wd8(d, stream);
   if (d.stride == 2) return launch_wd<2, 2, 1>(d, stream);
   if (d.stride == 4) return launch_wd<4, 4, 1>(d, stream);
   if (d.KT == 3) {

@@ -372,6 +372,20 @@ static inline float adp_lane_next(float edge, float v) {
   const float o = adp_emul::shfl_idx(v, l < 63 ? l + 1 : 63);
   return l < 63 ? o : edge;
 }
+static inline float adp_row_prev(float v) {
+  const int l = adp_emul::lane_id();
+  const float o = adp_emul::shfl_idx(v, (l & 15) ? l - 1 : l);
+  return (l & 15) ? o : 0.0f;
+}
+static inline float adp_row_next(float v) {
+  const int l = adp_emul::lane_id();
+  const float o = adp_emul::shfl_idx(v, (l & 15) != 15 ? l + 1 : l);
+  return (l & 15) != 15 ? o : 0.0f;
+}
+static inline float adp_oct_sum(float v) {
+  for (int o = 1; o < 8; o <<= 1) v += adp_emul::shfl_idx(v, adp_emul::lane_id() ^ o);
+  return v;
+}
 static inline int adp_uniform(int v) { return v; }
 static inline float adp_read_lane(float v, int src) { return adp_emul::shfl_idx(v, src); }
 static inline float adp_row16_sum(float v) {

@@ -674,7 +674,33 @@ def test_wgrad_mm_resample(dev, B, R, M, L, KT, stride, pad, up, wino, monkeypat
     assert rel_err(db, db_ref) < TOL
 
 
-@pytest.mark.parametrize("B,R,M,L,KT,stride,pad,up", DIRECT_CASES[:7] + [(3, 8, 8, 1300, 3, 1, 1, 1)])
+@pytest.mark.parametrize("R1,R2,M,L", [(8, 0, 8, 2304), (5, 3, 8, 1100), (2, 0, 6, 516), (8, 0, 8, 36)])
+def test_wgrad_direct8_prologue_concat(dev, R1, R2, M, L):
+    """wgrad_direct8 (kernel 3, <= 8 x 8 channels: lane = (input row, quad), halo through DPP row shifts of the ACTIVATED values)
+    with the GroupNorm+SiLU prologue, x2 concat, several spans per wave, a partly filled last span, accumulate."""
+    B, R, G = 3, R1 + R2, (R1 + R2) if (R1 + R2) < 8 else 8
+    xa = rnd(B, R, L, seed=1) * 1.5 + 0.3
+    w = rnd(M, R, 3, seed=3, scale=0.3).requires_grad_()
+    b = rnd(M, seed=4).requires_grad_()
+    gamma, beta = rnd(R, seed=5) * 0.3 + 1.0, rnd(R, seed=6) * 0.2
+    y = F.conv1d(ref_gn_silu(xa, G, gamma, beta), w, b, padding=1)
+    dy = rnd(*y.shape, seed=9)
+    dw_ref, db_ref = torch.autograd.grad(y, (w, b), dy)
+    xd = xa.to(dev)
+    stats = ops.gn_stats(xd, G)
+    x1 = xd[:, :R1].contiguous()
+    x2 = xd[:, R1:].contiguous() if R2 else None
+    kw = dict(pad=1, x2=x2, prologue=1, pro_stats=stats, pro_gamma=gamma.to(dev), pro_beta=beta.to(dev), groups=G)
+    dw, db = ops.conv1d_wgrad(x1, dy.to(dev), 3, **kw)
+    assert rel_err(dw, dw_ref) < TOL
+    assert rel_err(db, db_ref) < TOL
+    base = rnd(M, R, 3, seed=11).to(dev)
+    dw2, _ = ops.conv1d_wgrad(x1, dy.to(dev), 3, dw=base.clone(), want_bias=False, accumulate=True, **kw)
+    assert rel_err(dw2, base.cpu() + dw_ref) < TOL
+
+
+@pytest.mark.parametrize("B,R,M,L,KT,stride,pad,up", DIRECT_CASES[:7] + [(3, 8, 8, 1300, 3, 1, 1, 1), (2, 5, 7, 772, 3, 1, 1, 1),
+                                                                       (1, 2, 8, 260, 3, 1, 1, 1), (1, 8, 8, 4, 3, 1, 1, 1)])
 def test_wgrad_direct_family(dev, B, R, M, L, KT, stride, pad, up):
     """Weight gradients of the narrow layers on the VALU streaming kernel (wgrad_direct.hip), incl. x2 concat."""
     x = rnd(B, R, L, seed=1)

@@ -64,14 +64,21 @@ def main():
         def dgrad(s):
             return lambda: ops.conv1d(s["x"], w, None, pad=1, transposed=True, out=s["out"])
 
+        def wgrad(s):
+            dw, db = torch.empty(C, C, 3, device=dev), torch.empty(C, device=dev)
+            return lambda: ops.conv1d_wgrad(s["x"], s["res"], 3, pad=1, prologue=1, pro_stats=s["stats"], pro_gamma=gamma,
+                                            pro_beta=beta, groups=G, dw=dw, dbias=db)
+
         def add(s):
             return lambda: ops.add(s["x"], s["res"], out=s["out"])
         for cfg in os.environ.get("TILE_CFGS", "120").split(","):
             os.environ["ADP_TILE_CFG"] = cfg
             row = []
             for temp, nset in (("warm", 1), ("cold", 4)):
-                for name, mk, nb in (("conv1", conv1, 2), ("conv2", conv2, 3), ("dgrad", dgrad, 2), ("add", add, 3)):
+                for name, mk, nb in (("conv1", conv1, 2), ("conv2", conv2, 3), ("dgrad", dgrad, 2), ("wgrad(+reduce)", wgrad, 4), ("add", add, 3)):
                     t = graph_time([mk(sets[i % nset]) for i in range(20)])
+                    if nb == 4:  # per CALL = two launches (partials + second stage); bytes: x + dy
+                        nb = 2
                     row.append(f"{name} {t:5.1f} us {nb * A / t / 1e6:5.2f} TB/s")
                 row.append("|")
             print(f"B{B} cfg {cfg:>4} warm: " + "  ".join(row), flush=True)
