@@ -338,6 +338,111 @@ int launch_dc8(const adp_conv_desc& d, void* stream) {
   return ADP_LAUNCH_OK();
 }
 
+// ---- nearest x4 upsample + kernel 3 (the UpsampleItem that ends the U-Net: 32 -> 8 channels at 2**18 positions) as FOUR PHASE
+// convolutions on the low-resolution input.  Output 4j + s reads the upsampled positions 4j + s - 1 .. 4j + s + 1, i.e. the inputs
+//     s = 0: x[j-1], x[j], x[j]      s = 1, 2: x[j], x[j], x[j]      s = 3: x[j], x[j], x[j+1]
+// so with the taps summed once per workgroup (A = w0, B = w1 + w2, S = w0 + w1 + w2, C = w0 + w1, D = w2)
+//     y[4j] = A x[j-1] + B x[j]      y[4j+1] = y[4j+2] = S x[j]      y[4j+3] = C x[j] + D x[j+1]
+// five multiplies per input channel for four outputs where the gather form (conv_direct_kernel<3,1,4>) spends twelve.
+// A thread owns two input positions (eight outputs, 8 output channels): packed FMAs over the position pair, halo through DPP lane
+// shifts, every load up front, branch-free -- the structure of conv_direct8_kernel.
+constexpr int UP4_RMAX = 32;
+
+template <int RR>
+__global__ __launch_bounds__(256) void conv_up4_kernel(adp_conv_desc d) {
+  __shared__ __attribute__((aligned(16))) float Ws[RR * 40];  // [r][A B S C D][m], zero beyond R / M
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int M = (int)d.M, R = (int)d.R, L = (int)d.Lin, N = (int)d.N;
+  const int b = blockIdx.z, m0 = blockIdx.y * 8;
+  const int j0 = (blockIdx.x * 256 + tid) * 2;
+  for (int e = tid; e < RR * 40; e += 256) {
+    const int r = e / 40, k = e - r * 40, tap = k >> 3, m = k & 7;
+    float v = 0.0f;
+    if (r < R && m0 + m < M) {
+      const float* wp = d.w + ((int64_t)(m0 + m) * R + r) * 3;
+      const float w0 = wp[0], w1 = wp[1], w2 = wp[2];
+      v = tap == 0 ? w0 : tap == 1 ? w1 + w2 : tap == 2 ? (w0 + w1) + w2 : tap == 3 ? w0 + w1 : w2;
+    }
+    Ws[e] = v;
+  }
+  const bool valid = j0 < L;
+  const int j0c = valid ? j0 : L - 2;
+  const bool hok = valid && ((lane == 0 && j0 > 0) || (lane == 63 && j0 + 2 < L));
+  const int hoffc = hok ? (lane == 0 ? j0 - 1 : j0 + 2) : j0c;
+  f32x2 xv[RR];
+  float hv[RR];
+#pragma unroll
+  for (int r = 0; r < RR; ++r) {
+    const int rc = r < R ? r : R - 1;  // (rows beyond R: re-read against zero weights)
+    const float* row = d.x + ((int64_t)b * R + rc) * L;
+    xv[r] = *reinterpret_cast<const f32x2*>(row + j0c);
+    hv[r] = row[hoffc];
+  }
+  __syncthreads();
+  f32x2 y0[8], y1[8], y3[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) y0[m] = y1[m] = y3[m] = f32x2{0.0f, 0.0f};
+#pragma unroll
+  for (int r = 0; r < RR; ++r) {
+    const float ah = hok ? hv[r] : 0.0f;
+    float lft = adp_lane_prev(ah, xv[r][1]), rgt = adp_lane_next(ah, xv[r][0]);
+    lft = j0 > 0 ? lft : 0.0f;
+    rgt = j0 + 2 < L ? rgt : 0.0f;
+    const f32x2 pa = f32x2{lft, xv[r][0]}, pb = xv[r], pc = f32x2{xv[r][1], rgt};
+    const float* wp = Ws + r * 40;
+    float wv[40];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(wp + 4 * q);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wv[4 * q + i] = t4[i];
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) y0[m] = pa * wv[m] + y0[m];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) y1[m] = pb * wv[16 + m] + y1[m];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) y3[m] = pb * wv[24 + m] + y3[m];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) y0[m] = pb * wv[8 + m] + y0[m];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) y3[m] = pc * wv[32 + m] + y3[m];
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    adp_pin(y0[m]);
+    adp_pin(y1[m]);
+    adp_pin(y3[m]);
+  }
+  if (!valid) return;
+  const int64_t ebs = d.e_bstride ? d.e_bstride : M;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int mm = m0 + m;
+    if (mm >= M) break;
+    const float bias = d.bias ? d.bias[mm] : 0.0f;
+    f32x4 v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) v[h] = f32x4{y0[m][h] + bias, y1[m][h] + bias, y1[m][h] + bias, y3[m][h] + bias};
+    const int64_t o = ((int64_t)b * M + mm) * N + 4 * (int64_t)j0;
+    const float es = d.e_scale ? d.e_scale[b * ebs + mm] : 1.0f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (d.out_pre) *reinterpret_cast<f32x4*>(d.out_pre + o + 4 * h) = v[h];
+      f32x4 u = v[h] * es;
+      if (d.res) u = u + *reinterpret_cast<const f32x4*>(d.res + o + 4 * h);
+      *reinterpret_cast<f32x4*>(d.out + o + 4 * h) = u;
+    }
+  }
+}
+
+template <int RR>
+int launch_up4(const adp_conv_desc& d, void* stream) {
+  dim3 grid((unsigned)adp_cdiv(d.Lin, 512), (unsigned)adp_cdiv(d.M, DC_MB), (unsigned)d.B);
+  ADP_LAUNCH((conv_up4_kernel<RR>), grid, dim3(256), stream, d);
+  return ADP_LAUNCH_OK();
+}
+
 template <int KT, int S, int UP>
 int launch_dc(const adp_conv_desc& d, void* stream) {
   dim3 grid((unsigned)adp_cdiv(d.N, 1024), (unsigned)adp_cdiv(d.M, DC_MB), (unsigned)d.B);
@@ -375,7 +480,15 @@ int adp_conv_direct(const adp_conv_desc& d, void* stream) {
       return d.prologue == 1 ? launch_dc8<true, 8>(d, stream) : launch_dc8<false, 8>(d, stream);
     }
     if (d.up == 2) return launch_dc<3, 1, 2>(d, stream);
-    if (d.up == 4) return launch_dc<3, 1, 4>(d, stream);
+    if (d.up == 4) {
+      if (d.R <= UP4_RMAX && d.store == 0 && d.prologue == 0 && d.transposed == 0 && d.R1 == d.R && d.Lin % 2 == 0 &&
+          d.N == 4 * d.Lin) {
+        if (d.R <= 8) return launch_up4<8>(d, stream);
+        if (d.R <= 16) return launch_up4<16>(d, stream);
+        return launch_up4<32>(d, stream);
+      }
+      return launch_dc<3, 1, 4>(d, stream);
+    }
     return launch_dc<3, 1, 1>(d, stream);
   }
   if (d.up == 2) return launch_dc<1, 1, 2>(d, stream);

@@ -501,6 +501,9 @@ DIRECT_CASES = [
     (2, 5, 12, 772, 3, 1, 1, 1),      # 8-row kernel with 5 rows (clamped row loads), ragged channel group, threads beyond N
     (1, 2, 8, 260, 3, 1, 1, 1),       # 2-row instantiation
     (1, 8, 8, 4, 3, 1, 1, 1),         # one quad: both neighbours are padding
+    (2, 32, 8, 1100, 3, 1, 1, 4),     # x4 upsample conv as four phase convs (conv_up4): several waves, ragged last workgroup
+    (1, 12, 5, 66, 3, 1, 1, 4),       # 16-row instantiation with 12 rows, 5 output channels
+    (1, 8, 8, 2, 3, 1, 1, 4),         # one input pair
 ]
 
 
