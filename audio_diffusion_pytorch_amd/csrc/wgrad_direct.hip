@@ -313,6 +313,156 @@ static int launch_wd8(const adp_wgrad_desc& d, void* stream) {
   return adp_wgrad_reduce(d.ws, (int64_t)bpb * d.B, d.M * d.R * d.KT, d.M, d.dw, d.dbias, (int)d.accumulate, stream);
 }
 
+// ---- weight gradient of the x4 UpsampleItem conv of the narrow end (<= 32 -> <= 8 channels; conv_direct.hip: conv_up4_kernel)
+// in its phase form.  With D0..D3 = dy[m][4j .. 4j+3] of one input position j:
+//     dw[m][r][0] += D0 x[j-1] + (D1+D2+D3) x[j]     dw[m][r][1] += (D0+D1+D2+D3) x[j]     dw[m][r][2] += (D0+D1+D2) x[j] + D3 x[j+1]
+// -- the four dy values are summed once per (m, j) and shared by all input rows: three packed / scalar FMAs per (m, r, j) where the
+// gather form (wgrad_direct_kernel<3,1,4>) spends twelve behind LDS reads.  Register streaming reduction like wgrad_direct8:
+// lane = (group g, position q): the 8 lanes of a group cover 8 consecutive input positions, group g owns the input rows g, g+8,
+// ... and fetches the dy quad of output row m = g, which the groups exchange through a wave-private LDS slot.
+template <int RPL>
+__global__ __launch_bounds__(256) void wgrad_up4_kernel(adp_wgrad_desc d, int bpb, int spans_b) {
+  constexpr int NE = 8 * RPL * 24 + 8;  // sums of one workgroup: [row][m][tap] + bias[m]
+  __shared__ __attribute__((aligned(16))) float dysh[4][2][8][8][4];
+  __shared__ float red[4][NE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = adp_uniform(tid >> 6);
+  const int g = lane >> 3, q = lane & 7;
+  const int M = (int)d.M, R = (int)d.R, L = (int)d.Lin, N = (int)d.N;
+  const int b = blockIdx.y;
+  const float* xrow[RPL];
+#pragma unroll
+  for (int k = 0; k < RPL; ++k) {
+    const int r = g + 8 * k;
+    xrow[k] = d.x + ((int64_t)b * R + (r < R ? r : R - 1)) * L;  // (rows beyond R: duplicates, never stored)
+  }
+  const float* dyrow = d.dy + ((int64_t)b * M + (g < M ? g : M - 1)) * N;
+  f32x2 a02[RPL][8];  // (dw[..][0], dw[..][2])
+  float a1[RPL][8], bsum = 0.0f;
+#pragma unroll
+  for (int k = 0; k < RPL; ++k)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      a02[k][m] = f32x2{0.0f, 0.0f};
+      a1[k][m] = 0.0f;
+    }
+  struct Span {
+    float x[RPL], h[RPL];
+    f32x4 dyq;
+    bool hok, last;
+  };
+  auto load = [&](int s, Span& sp, auto tailc) {
+    constexpr bool TAIL = decltype(tailc)::value;  // the last, partly filled span of a row (L % 8 != 0)
+    const int j = s * 8 + q;
+    const bool valid = !TAIL || j < L;
+    const int jc = valid ? j : L - 1;
+    sp.hok = valid && ((q == 0 && j > 0) || (q == 7 && j + 1 < L));
+    sp.last = TAIL && j + 1 >= L;
+    const int hc = sp.hok ? (q == 0 ? j - 1 : j + 1) : jc;
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+      sp.x[k] = xrow[k][jc];
+      sp.h[k] = xrow[k][hc];
+    }
+    sp.dyq = *reinterpret_cast<const f32x4*>(dyrow + 4 * (int64_t)jc);
+    if (TAIL && !valid) sp.dyq = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  };
+  auto compute = [&](const Span& sp, int slot) {
+    *reinterpret_cast<f32x4*>(&dysh[wave][slot][g][q][0]) = sp.dyq;
+    bsum += (sp.dyq[0] + sp.dyq[1]) + (sp.dyq[2] + sp.dyq[3]);
+    adp_wave_sync();
+    f32x2 p13[8], p03[8];  // (D1+D2+D3, D0+D1+D2) and (D0, D3)
+    float ssum[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const f32x4 D = *reinterpret_cast<const f32x4*>(&dysh[wave][slot][m][q][0]);
+      const float t = D[1] + D[2];
+      p13[m] = f32x2{t + D[3], t + D[0]};
+      p03[m] = f32x2{D[0], D[3]};
+      ssum[m] = (t + D[3]) + D[0];
+    }
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+      const float x = sp.x[k], hv = sp.hok ? sp.h[k] : 0.0f;
+      float xl = adp_row_prev(x), xr = adp_row_next(x);
+      xl = q == 0 ? hv : xl;
+      xr = (q == 7 || sp.last) ? (q == 7 ? hv : 0.0f) : xr;
+      const f32x2 lr = f32x2{xl, xr};
+#pragma unroll
+      for (int m = 0; m < 8; ++m) a02[k][m] = p13[m] * x + a02[k][m];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) a1[k][m] = fmaf(ssum[m], x, a1[k][m]);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) a02[k][m] = p03[m] * lr + a02[k][m];
+    }
+  };
+  const int full = L / 8, stride = bpb * 4;
+  int s = blockIdx.x * 4 + wave;
+  for (; s + stride < full; s += 2 * stride) {  // two spans requested per trip (see wgrad_direct8_kernel)
+    Span A, B;
+    load(s, A, std::false_type{});
+    load(s + stride, B, std::false_type{});
+    compute(A, 0);
+    compute(B, 1);
+  }
+  for (; s < spans_b; s += stride) {
+    Span A;
+    load(s, A, std::true_type{});
+    compute(A, 0);
+    adp_wave_sync();
+  }
+#pragma unroll
+  for (int k = 0; k < RPL; ++k)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) adp_pin(a02[k][m]);
+  // ---- the group's 8 lanes, then the workgroup's 4 waves (fixed order), one partial per workgroup
+#pragma unroll
+  for (int k = 0; k < RPL; ++k)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const float t0 = adp_oct_sum(a02[k][m][0]), t1 = adp_oct_sum(a1[k][m]), t2 = adp_oct_sum(a02[k][m][1]);
+      if (q == 0) {
+        float* e = &red[wave][((g + 8 * k) * 8 + m) * 3];
+        e[0] = t0;
+        e[1] = t1;
+        e[2] = t2;
+      }
+    }
+  const float bb = adp_oct_sum(bsum);
+  if (q == 0) red[wave][8 * RPL * 24 + g] = bb;
+  __syncthreads();
+  const int64_t cnt = (int64_t)M * R * 3, P = (int64_t)gridDim.x * gridDim.y, pidx = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  for (int e = tid; e < NE; e += 256) {
+    const float sum = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (e < 8 * RPL * 24) {
+      const int r = e / 24, k = e - r * 24, m = k / 3, t = k - 3 * m;
+      if (r < R && m < M) d.ws[pidx * cnt + ((int64_t)m * R + r) * 3 + t] = sum;
+    } else if (e - 8 * RPL * 24 < M && d.dbias) {
+      d.ws[P * cnt + pidx * M + (e - 8 * RPL * 24)] = sum;
+    }
+  }
+}
+
+static bool wdu4_ok(const adp_wgrad_desc& d) {
+  return d.KT == 3 && d.stride == 1 && d.up == 4 && d.prologue == 0 && d.R <= 32 && d.M <= 8 && d.R1 == d.R &&
+         d.N == 4 * d.Lin && d.B <= 65535;
+}
+static int wdu4_bpb(const adp_wgrad_desc& d) {
+  const int64_t spans = adp_cdiv(d.Lin, 8);
+  int64_t bpb = adp_cdiv(spans, 16);
+  const int64_t cap = WD8_MAXBLOCKS / d.B > 0 ? WD8_MAXBLOCKS / d.B : 1;
+  return (int)(bpb < cap ? bpb : cap);
+}
+static int launch_wdu4(const adp_wgrad_desc& d, void* stream) {
+  const int bpb = wdu4_bpb(d), spans = (int)adp_cdiv(d.Lin, 8);
+  dim3 grid((unsigned)bpb, (unsigned)d.B);
+  if (d.R <= 8) ADP_LAUNCH((wgrad_up4_kernel<1>), grid, dim3(256), stream, d, bpb, spans);
+  else if (d.R <= 16) ADP_LAUNCH((wgrad_up4_kernel<2>), grid, dim3(256), stream, d, bpb, spans);
+  else ADP_LAUNCH((wgrad_up4_kernel<4>), grid, dim3(256), stream, d, bpb, spans);
+  if (ADP_LAUNCH_OK() != ADP_OK) return ADP_ERR_LAUNCH;
+  return adp_wgrad_reduce(d.ws, (int64_t)bpb * d.B, d.M * d.R * d.KT, d.M, d.dw, d.dbias, (int)d.accumulate, stream);
+}
+
 struct WdPlan {
   int np2, tpb, ntiles, blocks;
   size_t lds;
@@ -366,11 +516,13 @@ bool adp_wgrad_direct_eligible(const adp_wgrad_desc& d) {
 
 int64_t adp_wgrad_direct_ws_floats(const adp_wgrad_desc& d) {
   if (wd8_ok(d) && d.B <= 65535) return (int64_t)wd8_bpb(d) * d.B * (d.M * d.R * d.KT + d.M);
+  if (wdu4_ok(d)) return (int64_t)wdu4_bpb(d) * d.B * (d.M * d.R * d.KT + d.M);
   return (int64_t)wd_plan(d).blocks * (d.M * d.R * d.KT + d.M);
 }
 
 int adp_wgrad_direct(const adp_wgrad_desc& d, void* stream) {
   if (wd8_ok(d) && d.B <= 65535) return launch_wd8(d, stream);
+  if (wdu4_ok(d)) return launch_wdu4(d, stream);
   if (d.stride == 2) return launch_wd<2, 2, 1>(d, stream);
   if (d.stride == 4) return launch_wd<4, 4, 1>(d, stream);
   if (d.KT == 3) {

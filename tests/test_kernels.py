@@ -703,7 +703,9 @@ def test_wgrad_direct8_prologue_concat(dev, R1, R2, M, L):
 
 
 @pytest.mark.parametrize("B,R,M,L,KT,stride,pad,up", DIRECT_CASES[:7] + [(3, 8, 8, 1300, 3, 1, 1, 1), (2, 5, 7, 772, 3, 1, 1, 1),
-                                                                       (1, 2, 8, 260, 3, 1, 1, 1), (1, 8, 8, 4, 3, 1, 1, 1)])
+                                                                       (1, 2, 8, 260, 3, 1, 1, 1), (1, 8, 8, 4, 3, 1, 1, 1),
+                                                                       (2, 32, 8, 1100, 3, 1, 1, 4), (1, 12, 5, 66, 3, 1, 1, 4),
+                                                                       (1, 8, 8, 2, 3, 1, 1, 4), (3, 32, 8, 4096, 3, 1, 1, 4)])
 def test_wgrad_direct_family(dev, B, R, M, L, KT, stride, pad, up):
     """Weight gradients of the narrow layers on the VALU streaming kernel (wgrad_direct.hip), incl. x2 concat."""
     x = rnd(B, R, L, seed=1)
