@@ -443,6 +443,92 @@ int launch_up4(const adp_conv_desc& d, void* stream) {
   return ADP_LAUNCH_OK();
 }
 
+// ---- data gradient of the same layer (transposed conv + pooled store over the 4 replicas = gradient of the nearest upsample) in
+// the phase form: with dys[j] = dy[m][4j + s] and the summed taps A B S C D of conv_up4_kernel (weights w[m][r][t] of the forward),
+//     dx[r][j] = sum_m  A dy0[j+1] + B dy0[j] + S (dy1[j] + dy2[j]) + C dy3[j] + D dy3[j-1]
+// five multiplies per (m, r, j) on the LOW-resolution grid, no pooling pass.  A thread owns two positions j (two dy quads per
+// input row, halo = the neighbour lanes' first / last element) and RR output rows.
+template <int RR>
+__global__ __launch_bounds__(256) void conv_up4_dgrad_kernel(adp_conv_desc d) {
+  __shared__ __attribute__((aligned(16))) float Ws[8 * 5 * RR];  // [m][A B S C D][r], zero beyond the channel counts
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int Mi = (int)d.R, Ro = (int)d.M, N = (int)d.N, L = N / 4;  // Mi dy rows in, Ro dx rows out
+  const int b = blockIdx.z;
+  const int j0 = (blockIdx.x * 256 + tid) * 2;
+  for (int e = tid; e < 8 * 5 * RR; e += 256) {
+    const int m = e / (5 * RR), k = e - m * 5 * RR, tap = k / RR, r = k - tap * RR;
+    float v = 0.0f;
+    if (m < Mi && r < Ro) {
+      const float* wp = d.w + ((int64_t)m * Ro + r) * 3;  // the forward's w[m][r][0..2]
+      const float w0 = wp[0], w1 = wp[1], w2 = wp[2];
+      v = tap == 0 ? w0 : tap == 1 ? w1 + w2 : tap == 2 ? (w0 + w1) + w2 : tap == 3 ? w0 + w1 : w2;
+    }
+    Ws[e] = v;
+  }
+  const bool valid = j0 < L;
+  const int j0c = valid ? j0 : L - 2;
+  const bool hok = valid && ((lane == 0 && j0 > 0) || (lane == 63 && j0 + 2 < L));
+  const int hoffc = hok ? (lane == 0 ? 4 * j0 - 1 : 4 * (j0 + 2)) : 4 * j0c;
+  f32x4 q0[8], q1[8];
+  float hv[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const float* row = d.x + ((int64_t)b * Mi + (m < Mi ? m : Mi - 1)) * N;  // (rows beyond Mi: re-read against zero weights)
+    q0[m] = *reinterpret_cast<const f32x4*>(row + 4 * (int64_t)j0c);
+    q1[m] = *reinterpret_cast<const f32x4*>(row + 4 * (int64_t)j0c + 4);
+    hv[m] = row[hoffc];
+  }
+  __syncthreads();
+  f32x2 acc[RR];
+#pragma unroll
+  for (int r = 0; r < RR; ++r) acc[r] = f32x2{0.0f, 0.0f};
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const float ah = hok ? hv[m] : 0.0f;
+    float prv = adp_lane_prev(ah, q1[m][3]), nxt = adp_lane_next(ah, q0[m][0]);  // dy3[j0-1], dy0[j0+2]
+    prv = j0 > 0 ? prv : 0.0f;
+    nxt = j0 + 2 < L ? nxt : 0.0f;
+    const f32x2 d0 = f32x2{q0[m][0], q1[m][0]}, d0n = f32x2{q1[m][0], nxt};
+    const f32x2 d12 = f32x2{q0[m][1] + q0[m][2], q1[m][1] + q1[m][2]};
+    const f32x2 d3 = f32x2{q0[m][3], q1[m][3]}, d3p = f32x2{prv, q0[m][3]};
+    const float* wp = Ws + m * 5 * RR;
+#pragma unroll
+    for (int c = 0; c < RR / 4; ++c) {  // four output rows at a time (the weights of a tap are contiguous over r)
+      f32x4 wa = *reinterpret_cast<const f32x4*>(wp + 4 * c), wb = *reinterpret_cast<const f32x4*>(wp + RR + 4 * c);
+      f32x4 wS = *reinterpret_cast<const f32x4*>(wp + 2 * RR + 4 * c), wc = *reinterpret_cast<const f32x4*>(wp + 3 * RR + 4 * c);
+      f32x4 wd = *reinterpret_cast<const f32x4*>(wp + 4 * RR + 4 * c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[4 * c + i] = d0n * wa[i] + acc[4 * c + i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[4 * c + i] = d0 * wb[i] + acc[4 * c + i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[4 * c + i] = d12 * wS[i] + acc[4 * c + i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[4 * c + i] = d3 * wc[i] + acc[4 * c + i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[4 * c + i] = d3p * wd[i] + acc[4 * c + i];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RR; ++r) adp_pin(acc[r]);
+  if (!valid) return;
+#pragma unroll
+  for (int r = 0; r < RR; ++r) {
+    if (r >= Ro) break;
+    const int64_t o = ((int64_t)b * Ro + r) * L + j0;
+    f32x2 v = acc[r];
+    if (d.res) v = v + *reinterpret_cast<const f32x2*>(d.res + o);
+    *reinterpret_cast<f32x2*>(d.out + o) = v;
+  }
+}
+
+template <int RR>
+int launch_up4_dgrad(const adp_conv_desc& d, void* stream) {
+  dim3 grid((unsigned)adp_cdiv(d.N / 4, 512), 1, (unsigned)d.B);
+  ADP_LAUNCH((conv_up4_dgrad_kernel<RR>), grid, dim3(256), stream, d);
+  return ADP_LAUNCH_OK();
+}
+
 template <int KT, int S, int UP>
 int launch_dc(const adp_conv_desc& d, void* stream) {
   dim3 grid((unsigned)adp_cdiv(d.N, 1024), (unsigned)adp_cdiv(d.M, DC_MB), (unsigned)d.B);
@@ -475,6 +561,13 @@ int adp_conv_direct(const adp_conv_desc& d, void* stream) {
   if (d.stride == 2) return launch_dc<2, 2, 1>(d, stream);
   if (d.stride == 4) return launch_dc<4, 4, 1>(d, stream);
   if (d.KT == 3) {
+    if (d.up == 1 && d.transposed && d.store == 2 && d.sp == 4 && d.R <= 8 && d.M <= UP4_RMAX && d.prologue == 0 && !d.bias &&
+        !d.e_scale && d.R1 == d.R && d.N == d.Lin && d.N % 8 == 0 &&
+        ((reinterpret_cast<uintptr_t>(d.out) | reinterpret_cast<uintptr_t>(d.res)) & 7) == 0) {
+      if (d.M <= 8) return launch_up4_dgrad<8>(d, stream);
+      if (d.M <= 16) return launch_up4_dgrad<16>(d, stream);
+      return launch_up4_dgrad<32>(d, stream);
+    }
     if (d.up == 1 && d.R <= 8 && d.store == 0 && d.N == d.Lin) {
       if (d.R <= 2) return d.prologue == 1 ? launch_dc8<true, 2>(d, stream) : launch_dc8<false, 2>(d, stream);
       return d.prologue == 1 ? launch_dc8<true, 8>(d, stream) : launch_dc8<false, 8>(d, stream);
