@@ -15,15 +15,15 @@
 //   * 16 waves per CU (four per SIMD, <= 128 registers) cover the whole [4, 32, 65536] problem in ONE resident generation of
 //     4096 waves: the chip's own wave scheduler overlaps one wave's HBM latency with another's MFMAs and a third's stores;
 //     nothing is synchronised, so nothing waits for the slowest participant.
-//   * Winograd F(2,3) in the wave's registers (as conv_mm's WN variant): column l31 of the MFMA tile is an output PAIR;
-//     per input channel the lane reads the four inputs around its pair (two 8-byte LDS reads), forms
-//     V = (d0-d2, d1+d2, d2-d1, d1-d3) with four VALU ops and issues FOUR exact-f32 MFMAs where the direct form issues six:
-//     64 MFMAs per tile = 4096 matrix-pipe cycles per wave, ~52 % of a SIMD's time at the HBM-bound tile rate.  The
-//     transformed weights U = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) are built once per workgroup into 16 KB of LDS (the one
-//     workgroup barrier, reached while the tile loads are already in flight) and read as 16-byte A fragments.
-//   * y0 = P0+P1+P2, y1 = P1-P2-P3 per pair: 8-byte stores, 256 contiguous bytes per half-wave row; the bias enters through
-//     one MFMA step on P1 (it is in both sums).  GroupNorm partial statistics of the output: shifted sums per 4-channel row
-//     quad (shift = a sample of the quad, so |mean| >> sigma costs no digits), Chan-combined over the workgroup's waves.
+//   * Winograd F(4,3) on v_mfma_f32_16x16x4_f32 in the wave's registers: column j of the MFMA tile is an output QUAD; per K step
+//     (four input channels) the lane reads the six inputs around its quad (three 8-byte LDS reads), forms V = B^T d with 13 VALU
+//     ops and issues 2 x 6 MFMAs on the six Winograd planes -- 96 MFMAs of 32 cycles per tile where F(2,3) needs 65 of 64 cycles
+//     and the direct form 144.  The transformed weights U = G g are built once per workgroup into 24 KB of LDS (the one
+//     workgroup barrier, reached while the first stage's tile loads are already in flight).
+//   * y = A^T m per quad: 16-byte stores, 256 contiguous bytes per row; bias and residual as 16-byte operands.  GroupNorm partial
+//     statistics of the output: shifted sums per 4-channel row quad (shift = a sample of the quad, so |mean| >> sigma costs no
+//     digits), Chan-combined over the workgroup's waves.
+//   * the four waves that share a SIMD start their tiles `gap` apart (wall-clock stagger, no barrier): tools/probe/tile_probe.
 // Algorithmic bytes per launch: 4 * B * 32 * L * (2 + has_res) + 12 KB of weights.
 #include <stdlib.h>
 #include "adp_rt.h"

@@ -169,6 +169,11 @@ __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float* dy,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t nbase = ((int64_t)blockIdx.x * 4 + wave) * rpw;
   const bool vec = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(dw) & 15) == 0);
+  // the first row's dy values are requested before the activation rows are staged: the small layers (one row per wave) are a
+  // chain of memory round trips (x -> LDS -> dy -> store), and this one need not wait for the barrier
+  float dfirst[BT];
+#pragma unroll
+  for (int b = 0; b < BT; ++b) dfirst[b] = (b < B && nbase < N) ? dy[b * dybstride + nbase] : 0.0f;
   for (int64_t k0 = 0; k0 < K; k0 += LIN_KC) {
     const int kc = (int)((K - k0) < LIN_KC ? (K - k0) : LIN_KC);
     __syncthreads();
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float* dy,
       if (n >= N) break;
       float d[BT];
 #pragma unroll
-      for (int b = 0; b < BT; ++b) d[b] = (b < B) ? dy[b * dybstride + n] : 0.0f;
+      for (int b = 0; b < BT; ++b) d[b] = r == 0 ? dfirst[b] : ((b < B) ? dy[b * dybstride + n] : 0.0f);
       if (k0 == 0 && dbias && lane == 0) {
         float s = 0.0f;
 #pragma unroll
