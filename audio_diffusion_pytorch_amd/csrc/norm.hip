@@ -720,7 +720,7 @@ __global__ __launch_bounds__(NT) void chan_lnv_fwd_kernel(const float* x, const 
                                                           const float* bet, const float* gam2, const float* bet2,
                                                           float* y2) {
   constexpr int TL = 4 * LPR, RPP = NT / LPR, NW = NT / 64;
-  __shared__ float red[NW][TL];
+  __shared__ float red2[2][NW][TL];  // one array per reduction round: no barrier before a round's writes
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = tid % LPR, rg = tid / LPR;
   const int l0 = blockIdx.x * TL + 4 * lr, b = blockIdx.y;
@@ -747,13 +747,13 @@ __global__ __launch_bounds__(NT) void chan_lnv_fwd_kernel(const float* x, const 
 #pragma unroll
     for (int k = 0; k < 4; ++k) s[k] += v[i][k];
   }
-  auto over_channels = [&](float (&t)[4]) {  // sum over every row group of the workgroup; result in all threads
+  auto over_channels = [&](float (&t)[4], int round) {  // sum over every row group of the workgroup; result in all threads
 #pragma unroll
     for (int o = LPR; o < 64; o <<= 1)
 #pragma unroll
       for (int k = 0; k < 4; ++k) t[k] += __shfl_xor(t[k], o, 64);
     if (NW > 1) {
-      __syncthreads();
+      float (*red)[TL] = red2[round];
       if (lane < LPR)
 #pragma unroll
         for (int k = 0; k < 4; ++k) red[wave][4 * lr + k] = t[k];
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(NT) void chan_lnv_fwd_kernel(const float* x, const 
       }
     }
   };
-  over_channels(s);
+  over_channels(s, 0);
   float mean[4], q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int k = 0; k < 4; ++k) mean[k] = s[k] / (float)C;
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(NT) void chan_lnv_fwd_kernel(const float* x, const 
       q[k] = fmaf(dlt, dlt, q[k]);
     }
   }
-  over_channels(q);
+  over_channels(q, 1);
   float rstd[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) rstd[k] = 1.0f / sqrtf(q[k] / (float)C + eps);
@@ -919,16 +919,29 @@ __global__ __launch_bounds__(NT) void chan_lnv_bwd_kernel(const float* x, const 
 struct LnvCfg {
   int lpr, nt, vpt;
 };
-static LnvCfg lnv_cfg(int64_t C, int64_t B, int64_t L) {
+static LnvCfg lnv_cfg(int64_t C, int64_t B, int64_t L, bool bwd = false) {
   if (C <= 8) return {64, 256, 2};     // 1 KB row segments, 4 rows per pass
   if (C <= 32) return {32, 256, 4};    // 512 B, 8 rows per pass
   if (C <= 64) return {16, 256, 4};    // 256 B, 16 rows per pass
   if (C <= 128) return {8, 256, 4};    // 128 B, 32 rows per pass
-  if (C <= 256) return {8, 1024, 2};   // 128 B, 128 rows per pass
+  if (C <= 256) {  // 128 B segments; 512 threads x 4 passes (1024 x 2 before round 4: ADP_LNV_NT=1024)
+    const char* e = getenv(bwd ? "ADP_LNV_NT_BWD" : "ADP_LNV_NT");
+    if (e && atoi(e) == 1024) return {8, 1024, 2};
+    return {8, 512, 4};
+  }
   // 512 / 1024 channels, 1024-thread workgroups: few positions (depth 8 at batch 4: 512), so the segment narrows until
   // enough workgroups exist (measured at batch 4, step time: 16 positions 14.38 ms, 8 positions 14.42, 4 positions 14.53)
   int lpr = 4;
   while (lpr > 1 && B * adp_cdiv(L, 4 * lpr) < 32) lpr >>= 1;  // (batch 4: 16 positions at depths 5-8 measured best)
+  // 512-thread workgroups, twice the passes in registers (round 4; hipGraph per-launch us at batch 4, 1024 -> 512 threads:
+  // forward C=512 L=1024 9.7 -> 8.0, L=512 6.9 -> 5.6, C=1024 7.4 -> 6.6 / 7.1 -> 6.3; backward 14.0 -> 12.9, 10.9 -> 9.9, 12.5 ->
+  // 12.3, 9.3 -> 9.1: an 8-wave barrier and 8 partials per reduction instead of 16; 256 threads x 16 passes lose again).
+  // ADP_LNV_NT / ADP_LNV_NT_BWD = 1024: the previous shape (A/B).
+  const char* e = getenv(bwd ? "ADP_LNV_NT_BWD" : "ADP_LNV_NT");
+  if (!e || atoi(e) != 1024) {
+    const int lp = (C <= 512 && lpr == 1) ? 2 : lpr;
+    return {lp, 512, C <= 512 ? lp : 2 * lp};
+  }
   if (C <= 512) return {lpr == 1 ? 2 : lpr, 1024, lpr == 4 ? 2 : 1};
   return {lpr, 1024, lpr};  // RPP = 1024 / lpr rows per pass -> lpr passes cover 1024 channels
 }
@@ -967,6 +980,7 @@ int launch_ln_fwd(const float* x, const float* ss, int64_t bstride, int64_t B, i
   }
     ADP_LNV_FWD(64, 256, 2) ADP_LNV_FWD(32, 256, 4) ADP_LNV_FWD(16, 256, 4) ADP_LNV_FWD(8, 256, 4) ADP_LNV_FWD(8, 1024, 2)
     ADP_LNV_FWD(4, 1024, 2) ADP_LNV_FWD(2, 1024, 1) ADP_LNV_FWD(4, 1024, 4) ADP_LNV_FWD(2, 1024, 2) ADP_LNV_FWD(1, 1024, 1)
+    ADP_LNV_FWD(4, 512, 4) ADP_LNV_FWD(4, 512, 8) ADP_LNV_FWD(2, 512, 2) ADP_LNV_FWD(2, 512, 4) ADP_LNV_FWD(1, 512, 2) ADP_LNV_FWD(8, 512, 4)
 #undef ADP_LNV_FWD
   }
   const LnCfg k = ln_cfg(C, B, L);
@@ -995,7 +1009,7 @@ int launch_ln_bwd(const float* x, const float* dy, const float* ss, int64_t bstr
                   const float* stats, const float* dres, int64_t B, int64_t C, int64_t L, float* dx, float* ws,
                   void* stream) {
   if (lnv_ok(L, x, dy, dres, dx, stats)) {
-    const LnvCfg v = lnv_cfg(C, B, L);
+    const LnvCfg v = lnv_cfg(C, B, L, true);
     const int VNTL = (int)adp_cdiv(L, 4 * v.lpr);
     dim3 vgrid((unsigned)VNTL, (unsigned)B);
 #define ADP_LNV_BWD(LPR, NT, VPT)                                                                                      \
@@ -1006,6 +1020,7 @@ int launch_ln_bwd(const float* x, const float* dy, const float* ss, int64_t bstr
   }
     ADP_LNV_BWD(64, 256, 2) ADP_LNV_BWD(32, 256, 4) ADP_LNV_BWD(16, 256, 4) ADP_LNV_BWD(8, 256, 4) ADP_LNV_BWD(8, 1024, 2)
     ADP_LNV_BWD(4, 1024, 2) ADP_LNV_BWD(2, 1024, 1) ADP_LNV_BWD(4, 1024, 4) ADP_LNV_BWD(2, 1024, 2) ADP_LNV_BWD(1, 1024, 1)
+    ADP_LNV_BWD(4, 512, 4) ADP_LNV_BWD(4, 512, 8) ADP_LNV_BWD(2, 512, 2) ADP_LNV_BWD(2, 512, 4) ADP_LNV_BWD(1, 512, 2) ADP_LNV_BWD(8, 512, 4)
 #undef ADP_LNV_BWD
   }
   const LnCfg k = ln_cfg(C, B, L);
