@@ -50,6 +50,8 @@ SIGNATURES = {
     "adp_conv1d_tile": (I, [POINTER(ConvDesc)]),
     "adp_conv1d_wgrad_ws_bytes": (I, [POINTER(WgradDesc)]),
     "adp_conv1d_wgrad": (c_int, [POINTER(WgradDesc), P]),
+    "adp_conv1d_wgrad_partials": (I, [POINTER(WgradDesc)]),
+    "adp_wgrad_reduce_batch": (c_int, [P, P, P, I, I, I, I, I, P]),
     "adp_gn_stats_ws_bytes": (I, [I, I, I, I]),
     "adp_gn_stats": (c_int, [P, I, I, I, I, F, P, P, P]),
     "adp_gn_stats_act": (c_int, [P, I, I, I, I, F, P, P, P, P, P, P]),

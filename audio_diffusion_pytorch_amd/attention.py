@@ -136,11 +136,11 @@ def attention_item(run, p, x: Tensor, context: Optional[Tensor]) -> Tensor:
 
     if run.need_grad:
         def bwd(gy):
-            ops.conv1d_wgrad(o, gy, 1, dw=run.g(p.to_out.weight).view(C, mid, 1), want_bias=False)
+            ops.conv1d_wgrad(o, gy, 1, dw=run.g(p.to_out.weight).view(C, mid, 1), want_bias=False, park=run.wpark)
             do = ops.conv1d(gy, wo, None, transposed=True)
             dq, dkv = ops.attn_bwd(q, kv, o, do, lse, H, D, dkv=bank.dkv_slot(p) if bank is not None else None)
             # q path: weight gradient with the LayerNorm applied in the loader, then LayerNorm backward (+ residual)
-            ops.conv1d_wgrad(xn, dq, 1, dw=run.g(p.to_q.weight).view(mid, C, 1), want_bias=False)
+            ops.conv1d_wgrad(xn, dq, 1, dw=run.g(p.to_q.weight).view(mid, C, 1), want_bias=False, park=run.wpark)
             dxn = ops.conv1d(dq, wq, None, transposed=True)
             # [dgamma | dbeta] land directly in the flat gradient buffer (weight and bias are adjacent parameters)
             dx, _ = ops.ln_bwd(x, dxn, st_x, p.norm.weight, dres=gy, dgb=run.gspan(p.norm.weight, 2 * C))
@@ -148,7 +148,7 @@ def attention_item(run, p, x: Tensor, context: Optional[Tensor]) -> Tensor:
                 bank.put_dkv(p, dkv)
                 return dx
             # k/v path
-            ops.conv1d_wgrad(cn, dkv, 1, dw=run.g(p.to_kv.weight).view(2 * mid, Cc, 1), want_bias=False)
+            ops.conv1d_wgrad(cn, dkv, 1, dw=run.g(p.to_kv.weight).view(2 * mid, Cc, 1), want_bias=False, park=run.wpark)
             dcn = ops.conv1d(dkv, wkv, None, transposed=True)
             gbc = run.gspan(p.norm_context.weight, 2 * Cc)
             if is_cross:

@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256) void wgrad_s1_kernel(adp_wgrad_desc d, int64_t
       const int64_t m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi, rr = r0 + wr0 + l31;
       if (m < M && rr < R) {
         float* o = base + (m * R + rr) * KT + t;
-        *o = (direct && d.accumulate) ? *o + acc[t][r] : acc[t][r];
+        *o = (direct && (d.accumulate & 1)) ? *o + acc[t][r] : acc[t][r];
       }
     }
   if (do_bias && l31 == 0) {
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256) void wgrad_s1_kernel(adp_wgrad_desc d, int64_t
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (m < M) bb[m] = (direct && d.accumulate) ? bb[m] + accb[r] : accb[r];
+      if (m < M) bb[m] = (direct && (d.accumulate & 1)) ? bb[m] + accb[r] : accb[r];
     }
   }
 }
@@ -812,7 +812,7 @@ int launch_wgrad_s1(const adp_wgrad_desc& d, void* stream) {
   dim3 grid((unsigned)nsplit, (unsigned)adp_cdiv(d.M, 64), (unsigned)adp_cdiv(d.R, 64));
   ADP_LAUNCH((wgrad_s1_kernel<KT>), grid, dim3(256), stream, d, CPS, CPB, nsplit);
   if (nsplit > 1) {
-    return adp_wgrad_reduce(d.ws, nsplit, d.M * d.R * KT, d.M, d.dw, d.dbias, (int)d.accumulate, stream);
+    return adp_wgrad_reduce(d.ws, nsplit, d.M * d.R * KT, d.M, d.dw, d.dbias, (int)(d.accumulate & 1), stream);
   }
   return ADP_LAUNCH_OK();
 }
@@ -827,7 +827,7 @@ int launch_wgrad(const adp_wgrad_desc& d, void* stream) {
   const int64_t nsplit = d.B * SPB;
   dim3 grid((unsigned)nsplit, (unsigned)adp_cdiv(d.M, 32), (unsigned)adp_cdiv(d.R, 32));
   ADP_LAUNCH((wgrad_kernel<KT, S>), grid, dim3(256), stream, d, PS, SPB);
-  return adp_wgrad_reduce(d.ws, nsplit, d.M * d.R * KT, d.M, d.dw, d.dbias, (int)d.accumulate, stream);
+  return adp_wgrad_reduce(d.ws, nsplit, d.M * d.R * KT, d.M, d.dw, d.dbias, (int)(d.accumulate & 1), stream);
 }
 
 bool ks_supported(int64_t KT, int64_t S) {
@@ -905,6 +905,26 @@ extern "C" int64_t adp_conv1d_wgrad_ws_bytes(const adp_wgrad_desc* dp) {
     nsplit = dp->B * SPB;
   }
   return nsplit * (dp->M * dp->R * dp->KT + dp->M) * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t adp_conv1d_wgrad_partials(const adp_wgrad_desc* dp) {
+  if (!dp) return ADP_ERR_NULL;
+  if (dp->B <= 0 || dp->R <= 0 || dp->M <= 0 || dp->N <= 0 || dp->Lin <= 0 || dp->up < 1) return ADP_ERR_SHAPE;
+  return adp_wgrad_mm_eligible(*dp) ? adp_wgrad_mm_nsplit(*dp) : 1;  // (only the matrix-core family has a parked form)
+}
+
+extern "C" int adp_wgrad_reduce_batch(const float* const* ws, float* const* dw, float* const* dbias, int64_t n, int64_t nsplit,
+                                      int64_t cnt, int64_t M, int64_t accumulate, void* stream) {
+  if (!ws || !dw) return ADP_ERR_NULL;
+  if (n <= 0 || nsplit < 1 || cnt <= 0 || M <= 0) return ADP_ERR_SHAPE;
+  for (int64_t i = 0; i < n; ++i)
+    if (!ws[i] || !dw[i] || (dbias && !dbias[i])) return ADP_ERR_NULL;
+  for (int64_t i = 0; i < n; i += ADP_WGR_BATCH) {
+    const int k = (int)(n - i < ADP_WGR_BATCH ? n - i : ADP_WGR_BATCH);
+    const int rc = adp_wgrad_reduce_n(ws + i, dw + i, dbias ? dbias + i : nullptr, k, nsplit, cnt, M, (int)(accumulate & 1), stream);
+    if (rc != ADP_OK) return rc;
+  }
+  return ADP_OK;
 }
 
 extern "C" int adp_conv1d_wgrad(const adp_wgrad_desc* dp, void* stream) {

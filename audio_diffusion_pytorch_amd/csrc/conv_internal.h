@@ -18,6 +18,10 @@ int64_t adp_conv_splitk_gn_entries(const adp_conv_desc& d);  // gn_part slices p
 // wgrad_mm.hip: wave-specialised weight gradient of the same convolutions (channels % 32 == 0)
 bool adp_wgrad_mm_eligible(const adp_wgrad_desc& d);
 int64_t adp_wgrad_mm_ws_floats(const adp_wgrad_desc& d);
+int64_t adp_wgrad_mm_nsplit(const adp_wgrad_desc& d);
+constexpr int ADP_WGR_BATCH = 8;
+int adp_wgrad_reduce_n(const float* const* ws, float* const* dw, float* const* dbias, int n, int64_t nsplit, int64_t cnt,
+                       int64_t M, int accumulate, void* stream);
 int adp_wgrad_mm(const adp_wgrad_desc& d, void* stream);
 int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, float* dw, float* dbias, int accumulate,
                      void* stream);

@@ -310,7 +310,7 @@ static int launch_wd8(const adp_wgrad_desc& d, void* stream) {
   if (d.prologue == 1) ADP_LAUNCH((wgrad_direct8_kernel<true>), grid, dim3(256), stream, d, bpb, spans);
   else ADP_LAUNCH((wgrad_direct8_kernel<false>), grid, dim3(256), stream, d, bpb, spans);
   if (ADP_LAUNCH_OK() != ADP_OK) return ADP_ERR_LAUNCH;
-  return adp_wgrad_reduce(d.ws, (int64_t)bpb * d.B, d.M * d.R * d.KT, d.M, d.dw, d.dbias, (int)d.accumulate, stream);
+  return adp_wgrad_reduce(d.ws, (int64_t)bpb * d.B, d.M * d.R * d.KT, d.M, d.dw, d.dbias, (int)(d.accumulate & 1), stream);
 }
 
 // ---- weight gradient of the x4 UpsampleItem conv of the narrow end (<= 32 -> <= 8 channels; conv_direct.hip: conv_up4_kernel)
@@ -460,7 +460,7 @@ static int launch_wdu4(const adp_wgrad_desc& d, void* stream) {
   else if (d.R <= 16) ADP_LAUNCH((wgrad_up4_kernel<2>), grid, dim3(256), stream, d, bpb, spans);
   else ADP_LAUNCH((wgrad_up4_kernel<4>), grid, dim3(256), stream, d, bpb, spans);
   if (ADP_LAUNCH_OK() != ADP_OK) return ADP_ERR_LAUNCH;
-  return adp_wgrad_reduce(d.ws, (int64_t)bpb * d.B, d.M * d.R * d.KT, d.M, d.dw, d.dbias, (int)d.accumulate, stream);
+  return adp_wgrad_reduce(d.ws, (int64_t)bpb * d.B, d.M * d.R * d.KT, d.M, d.dw, d.dbias, (int)(d.accumulate & 1), stream);
 }
 
 struct WdPlan {
@@ -496,7 +496,7 @@ int launch_wd(const adp_wgrad_desc& d, void* stream) {
     ADP_LAUNCH((wgrad_direct_kernel<KT, S, UP, WD_LDS_BIG>), dim3((unsigned)p.blocks), dim3(256), stream, d, p.np2,
                p.tpb, p.ntiles);
   if (ADP_LAUNCH_OK() != ADP_OK) return ADP_ERR_LAUNCH;
-  return adp_wgrad_reduce(d.ws, p.blocks, d.M * d.R * d.KT, d.M, d.dw, d.dbias, (int)d.accumulate, stream);
+  return adp_wgrad_reduce(d.ws, p.blocks, d.M * d.R * d.KT, d.M, d.dw, d.dbias, (int)(d.accumulate & 1), stream);
 }
 
 }  // namespace

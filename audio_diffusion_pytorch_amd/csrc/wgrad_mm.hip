@@ -224,7 +224,7 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
         const int e = lt + i * NLT;
         if (e < BM * DQ && (e % DQ) == 0) {
           const int m = m0 + e / DQ;
-          bb[m] = (direct && d.accumulate) ? bb[m] + s : s;
+          bb[m] = (direct && (d.accumulate & 1)) ? bb[m] + s : s;
         }
       }
     }
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
 
   if (kg == 0) {
     float* base = direct ? d.dw : d.ws + (int64_t)split * cnt;
-    const bool accum = direct && d.accumulate;
+    const bool accum = direct && (d.accumulate & 1);
     if constexpr (KT == 3) {
       // the three taps of an (m, r) pair are adjacent in dw[M][R][3]: ONE 12-byte store per accumulator row -- the 32
       // lanes of a half-wave then write 384 contiguous bytes (the per-tap 4-byte form scattered them over three
@@ -416,8 +416,18 @@ WgPlan wg_plan(const adp_wgrad_desc& d) {
 // partials start at ws + nsplit*cnt).  64 outputs x 16 split lanes per workgroup: rows of 256 contiguous bytes,
 // 16 independent accumulation chains per output instead of one serial walk over all splits; the 16 lane sums are
 // combined in a fixed order (deterministic).
-__global__ __launch_bounds__(1024) void adp_wgrad_reduce_kernel(const float* ws, int64_t nsplit, int64_t cnt, int64_t M,
-                                                                float* dw, float* dbias, int accumulate) {
+// (up to ADP_WGR_BATCH same-shape weight gradients per launch, blockIdx.y = item: adp_wgrad_reduce_batch)
+struct adp_wgr_batch {
+  const float* ws[ADP_WGR_BATCH];
+  float* dw[ADP_WGR_BATCH];
+  float* dbias[ADP_WGR_BATCH];
+};
+
+__global__ __launch_bounds__(1024) void adp_wgrad_reduce_kernel(adp_wgr_batch t, int64_t nsplit, int64_t cnt, int64_t M,
+                                                                int accumulate) {
+  const float* ws = t.ws[blockIdx.y];
+  float* dw = t.dw[blockIdx.y];
+  float* dbias = t.dbias[blockIdx.y];
   __shared__ float part[16][64];
   const int il = threadIdx.x & 63, ks = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + il;
@@ -448,18 +458,20 @@ __global__ __launch_bounds__(1024) void adp_wgrad_reduce_kernel(const float* ws,
   part[ks][il] = s;
   __syncthreads();
   if (ks == 0 && i < tot) {
-    float t = 0.0f;
+    float sum = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += part[k][il];
+    for (int k = 0; k < 16; ++k) sum += part[k][il];
     float* o = (i < cnt) ? dw + i : dbias + (i - cnt);
-    *o = accumulate ? *o + t : t;
+    *o = accumulate ? *o + sum : sum;
   }
 }
 
 // few splits: one thread per output walks them (the 16-lane form would idle most of its lanes)
-__global__ __launch_bounds__(256) void adp_wgrad_reduce_small_kernel(const float* ws, int64_t nsplit, int64_t cnt,
-                                                                     int64_t M, float* dw, float* dbias,
-                                                                     int accumulate) {
+__global__ __launch_bounds__(256) void adp_wgrad_reduce_small_kernel(adp_wgr_batch t, int64_t nsplit, int64_t cnt,
+                                                                     int64_t M, int accumulate) {
+  const float* ws = t.ws[blockIdx.y];
+  float* dw = t.dw[blockIdx.y];
+  float* dbias = t.dbias[blockIdx.y];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < cnt) {
     float s = 0.0f;
@@ -476,17 +488,29 @@ __global__ __launch_bounds__(256) void adp_wgrad_reduce_small_kernel(const float
   }
 }
 
-int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, float* dw, float* dbias, int accumulate,
-                     void* stream) {
-  const int64_t tot = cnt + (dbias ? M : 0);
+// n <= ADP_WGR_BATCH weight gradients of ONE shape (nsplit, cnt, M; dbias all set or all NULL) in one launch
+int adp_wgrad_reduce_n(const float* const* ws, float* const* dw, float* const* dbias, int n, int64_t nsplit, int64_t cnt,
+                       int64_t M, int accumulate, void* stream) {
+  adp_wgr_batch t;
+  for (int i = 0; i < ADP_WGR_BATCH; ++i) {
+    t.ws[i] = ws[i < n ? i : 0];
+    t.dw[i] = dw[i < n ? i : 0];
+    t.dbias[i] = dbias ? dbias[i < n ? i : 0] : nullptr;
+  }
+  const int64_t tot = cnt + (t.dbias[0] ? M : 0);
   if (nsplit <= 8) {
-    ADP_LAUNCH(adp_wgrad_reduce_small_kernel, dim3((unsigned)adp_cdiv(tot, 256)), dim3(256), stream, ws, nsplit, cnt, M,
-               dw, dbias, accumulate);
+    ADP_LAUNCH(adp_wgrad_reduce_small_kernel, dim3((unsigned)adp_cdiv(tot, 256), (unsigned)n), dim3(256), stream, t, nsplit,
+               cnt, M, accumulate);
     return ADP_LAUNCH_OK();
   }
-  ADP_LAUNCH(adp_wgrad_reduce_kernel, dim3((unsigned)adp_cdiv(tot, 64)), dim3(1024), stream, ws, nsplit, cnt, M, dw,
-             dbias, accumulate);
+  ADP_LAUNCH(adp_wgrad_reduce_kernel, dim3((unsigned)adp_cdiv(tot, 64), (unsigned)n), dim3(1024), stream, t, nsplit, cnt, M,
+             accumulate);
   return ADP_LAUNCH_OK();
+}
+
+int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, float* dw, float* dbias, int accumulate,
+                     void* stream) {
+  return adp_wgrad_reduce_n(&ws, &dw, dbias ? &dbias : nullptr, 1, nsplit, cnt, M, accumulate, stream);
 }
 
 namespace {
@@ -498,8 +522,8 @@ int launch_wg(const adp_wgrad_desc& d, const WgPlan& p, void* stream) {
   constexpr int NTH = ((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NLD) * 64;
   ADP_LAUNCH((wgrad_mm_kernel<BM, KT, S, UP, PRO, PD, WN>), grid, dim3(NTH), stream, d, (int)p.cpb, (int)p.cps,
              (int)p.nsplit);
-  if (p.nsplit > 1) {
-    return adp_wgrad_reduce(d.ws, p.nsplit, d.M * d.R * KT, d.M, d.dw, d.dbias, (int)d.accumulate, stream);
+  if (p.nsplit > 1 && !(d.accumulate & 2)) {  // (bit 1 of `accumulate`: the caller parks the second stage, adp.h)
+    return adp_wgrad_reduce(d.ws, p.nsplit, d.M * d.R * KT, d.M, d.dw, d.dbias, (int)(d.accumulate & 1), stream);
   }
   return ADP_LAUNCH_OK();
 }
@@ -539,6 +563,8 @@ bool adp_wgrad_mm_eligible(const adp_wgrad_desc& d) {
   if (d.M / 32 > 65535 || d.R / 32 > 65535) return false;
   return true;
 }
+
+int64_t adp_wgrad_mm_nsplit(const adp_wgrad_desc& d) { return wg_plan(d).nsplit; }
 
 int64_t adp_wgrad_mm_ws_floats(const adp_wgrad_desc& d) {
   const WgPlan p = wg_plan(d);

@@ -80,11 +80,38 @@ def conv1d(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int =
     return out
 
 
+class WgradPark:
+    """Parked second stages of split weight gradients (adp_wgrad_desc.accumulate bit 1): the partial slices stay in their own
+    scratch until flush() sums every parked gradient of one shape in ONE launch (adp_wgrad_reduce_batch) -- the ConvBlock
+    convs of a U-Net depth share their shape, so a block side's four to eight second stages become one."""
+
+    def __init__(self):
+        self.items = []  # (key = (partials, cnt, M, accumulate, has_bias), ws, dw, dbias)
+
+    def add(self, key, ws: Tensor, dw: Tensor, dbias: Optional[Tensor]) -> None:
+        self.items.append((key, ws, dw, dbias))
+
+    def flush(self) -> None:
+        if not self.items:
+            return
+        groups = {}
+        for key, ws, dw, dbias in self.items:
+            groups.setdefault(key, []).append((ws, dw, dbias))
+        self.items = []
+        for (partials, cnt, M, acc, has_bias), g in groups.items():
+            n = len(g)
+            arr = ctypes.c_void_p * n
+            wsa, dwa = arr(*[ptr(t[0]) for t in g]), arr(*[ptr(t[1]) for t in g])
+            dba = arr(*[ptr(t[2]) for t in g]) if has_bias else None
+            _C.tag(bytes=4 * n * (partials + 1) * (cnt + M), shape=f"n{n} P{partials} cnt{cnt}")
+            _C.call("adp_wgrad_reduce_batch", wsa, dwa, dba, n, partials, cnt, M, acc, _C.stream())
+
+
 def conv1d_wgrad(x: Tensor, dy: Tensor, KT: int, *, stride: int = 1, dil: int = 1, pad: int = 0, up: int = 1,
                  x2: Optional[Tensor] = None, prologue: int = 0, pro_stats: Optional[Tensor] = None,
                  pro_gamma: Optional[Tensor] = None, pro_beta: Optional[Tensor] = None, groups: int = 1,
                  dw: Optional[Tensor] = None, dbias: Optional[Tensor] = None, want_bias: bool = True,
-                 accumulate: bool = False):
+                 accumulate: bool = False, park: Optional[WgradPark] = None):
     B, R1, Lin = x.shape
     R = R1 + (x2.shape[1] if x2 is not None else 0)
     _, M, N = dy.shape
@@ -99,6 +126,11 @@ def conv1d_wgrad(x: Tensor, dy: Tensor, KT: int, *, stride: int = 1, dil: int = 
     if _C.PROFILE is not None:  # A_x + A_dy + weight-gradient write
         _C.tag(flops=2 * B * M * N * R * KT, bytes=4 * (B * R * Lin + dy.numel() + dw.numel()),
                shape=f"B{B} R{R} M{M} N{N} KT{KT} s{stride} up{up} pro{prologue}")
+    if park is not None:
+        partials = _C.query("adp_conv1d_wgrad_partials", byref(d))
+        if partials > 1:  # the second stage waits for park.flush(); ws belongs to the parked item until then
+            d.accumulate = int(accumulate) | 2
+            park.add((partials, M * R * KT, M, int(accumulate), dbias is not None), ws, dw, dbias)
     _C.call("adp_conv1d_wgrad", byref(d), _C.stream())
     return dw, dbias
 

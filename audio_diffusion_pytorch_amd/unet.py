@@ -409,6 +409,9 @@ class _Run:
         self.pnames = {id(p): n for n, p in net.named_parameters()}
         self.gn: Optional[ops.GnPart] = None  # GroupNorm partial statistics of the tensor produced last (if any)
         self.mod_sums = ops.ModulationSums()  # parked second stages of the Modulation backwards
+        # parked second stages of the split ConvBlock weight gradients: summed per side of a block in one launch per shape
+        # (ADP_WGRAD_PARK=0: every weight gradient finishes itself, A/B)
+        self.wpark = ops.WgradPark() if os.environ.get("ADP_WGRAD_PARK", "1") != "0" else None
 
     # -- gradient destination views -------------------------------------------------------
     def g(self, p: nn.Parameter) -> Tensor:
@@ -525,12 +528,12 @@ class _Run:
                        pro_beta=p.gn2.bias, groups=G, res=x)
         if self.need_grad:
             def bwd(gy):
-                ops.conv1d_wgrad(h1, gy, 3, pad=1, prologue=1, pro_stats=st2, pro_gamma=p.gn2.weight,
+                ops.conv1d_wgrad(h1, gy, 3, pad=1, park=self.wpark, prologue=1, pro_stats=st2, pro_gamma=p.gn2.weight,
                                  pro_beta=p.gn2.bias, groups=G, dw=self.g(p.conv2.weight), dbias=self.g(p.conv2.bias))
                 dact2 = ops.conv1d(gy, p.conv2.weight, None, pad=1, transposed=True)
                 dh1, _, _ = ops.gn_silu_bwd(h1, dact2, st2, p.gn2.weight, p.gn2.bias, G, dgamma=self.g(p.gn2.weight),
                                             dbeta=self.g(p.gn2.bias))
-                ops.conv1d_wgrad(x, dh1, 3, pad=1, prologue=1, pro_stats=st1, pro_gamma=p.gn1.weight,
+                ops.conv1d_wgrad(x, dh1, 3, pad=1, park=self.wpark, prologue=1, pro_stats=st1, pro_gamma=p.gn1.weight,
                                  pro_beta=p.gn1.bias, groups=G, dw=self.g(p.conv1.weight), dbias=self.g(p.conv1.bias))
                 dact1 = ops.conv1d(dh1, p.conv1.weight, None, pad=1, transposed=True)
                 dx, _, _ = ops.gn_silu_bwd(x, dact1, st1, p.gn1.weight, p.gn1.bias, G, dres=gy,
@@ -552,11 +555,11 @@ class _Run:
         y = ops.conv1d(a2, p.conv2.weight, p.conv2.bias, pad=1, res=x)
         if self.need_grad:
             def bwd(gy):
-                ops.conv1d_wgrad(a2, gy, 3, pad=1, dw=self.g(p.conv2.weight), dbias=self.g(p.conv2.bias))
+                ops.conv1d_wgrad(a2, gy, 3, pad=1, dw=self.g(p.conv2.weight), dbias=self.g(p.conv2.bias), park=self.wpark)
                 dact2 = ops.conv1d(gy, p.conv2.weight, None, pad=1, transposed=True)
                 dh1, _, _ = ops.gn_silu_bwd(h1, dact2, st2, p.gn2.weight, p.gn2.bias, G, dgamma=self.g(p.gn2.weight),
                                             dbeta=self.g(p.gn2.bias))
-                ops.conv1d_wgrad(a1, dh1, 3, pad=1, dw=self.g(p.conv1.weight), dbias=self.g(p.conv1.bias))
+                ops.conv1d_wgrad(a1, dh1, 3, pad=1, dw=self.g(p.conv1.weight), dbias=self.g(p.conv1.bias), park=self.wpark)
                 dact1 = ops.conv1d(dh1, p.conv1.weight, None, pad=1, transposed=True)
                 dx, _, _ = ops.gn_silu_bwd(x, dact1, st1, p.gn1.weight, p.gn1.bias, G, dres=gy,
                                            dgamma=self.g(p.gn1.weight), dbeta=self.g(p.gn1.bias))
@@ -602,6 +605,8 @@ class _Run:
         return attn_host.attention_item(self, p, x, context)
 
     def run_items(self, d: int, which: str, mods, x: Tensor, embedding, channels) -> Tensor:
+        if self.need_grad and self.wpark is not None:  # (first on the tape = last in the backward of this side of the block)
+            self.tape.append((self._flush_wpark, None))
         for i, (t, p) in enumerate(zip(self.net.item_types[d], mods)):
             if t == ITEM_RESNET:
                 x = self.resnet(p, x)
@@ -616,6 +621,10 @@ class _Run:
                 assert embedding is not None, "You must provide a context when using context_features"
                 x = self.attention(p, x, embedding)
         return x
+
+    def _flush_wpark(self, gy):
+        self.wpark.flush()
+        return gy
 
     # -- block recursion ------------------------------------------------------------------
     def block(self, d: int, x: Tensor, x2: Optional[Tensor], embedding, channels, need_dx: bool) -> Tensor:
@@ -672,7 +681,7 @@ class _Run:
                     gskip = ops.conv1d(gy, wc[:, :C, :].contiguous(), None, transposed=True)
                     gskip = ops.axpby(SKIP_CAT_SCALE, gskip, out=gskip)
                     du = ops.conv1d(gy, wc[:, C:, :].contiguous(), None, transposed=True)
-                ops.conv1d_wgrad(h_up, du, 3, pad=1, up=f, dw=self.g(blk.up.weight), dbias=self.g(blk.up.bias))
+                ops.conv1d_wgrad(h_up, du, 3, pad=1, up=f, dw=self.g(blk.up.weight), dbias=self.g(blk.up.bias), park=self.wpark)
                 if native:
                     gh = ops.conv1d(du, blk.up.weight, None, pad=1, transposed=True, store=2 if f > 1 else 0, sp=f)
                 else:  # gradient of the nearest upsample = sum over the f replicas of each source position
@@ -683,7 +692,7 @@ class _Run:
             def bwd_down(gh):
                 gskip = self.skip_grads.pop()
                 if native:
-                    ops.conv1d_wgrad(x, gh, f, stride=f, x2=x2, dw=self.g(wd), dbias=self.g(blk.down.bias))
+                    ops.conv1d_wgrad(x, gh, f, stride=f, x2=x2, dw=self.g(wd), dbias=self.g(blk.down.bias), park=self.wpark)
                 else:
                     ops.conv1d_wgrad(xs, gh, 1, x2=x2s, dw=self.g(wd).view(wd.shape[0], -1, 1),
                                      dbias=self.g(blk.down.bias))
@@ -767,6 +776,8 @@ class _UNetFn(torch.autograd.Function):
         for fn, tag in reversed(run.tape):
             g = fn(g)
             if tag is not None:
+                if run.wpark is not None:
+                    run.wpark.flush()  # (a block's gradients are final when its tag is reached: the data-parallel hook)
                 ra, rb = run.bank_grad_for_depth(tag)
                 if hook is not None:
                     hook(flat, *net.block_param_range(tag))
@@ -774,6 +785,8 @@ class _UNetFn(torch.autograd.Function):
                         w0 = offs["bank_weight"][0]
                         hook(flat, w0 + ra * net.mf, w0 + rb * net.mf)
         run.mod_sums.flush()  # (nothing is left when every Modulation belongs to a tagged block)
+        if run.wpark is not None:
+            run.wpark.flush()
         if run.ctx_bank is not None:
             run.ctx_bank.backward(run)
         dfeat = run.conditioning_backward()

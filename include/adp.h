@@ -115,11 +115,23 @@ typedef struct adp_wgrad_desc {
   float* ws;
   int64_t B, R, R1, Lin, M, N;
   int64_t KT, stride, dil, pad, up;
-  int64_t prologue, groups, accumulate;
+  int64_t prologue, groups;
+  int64_t accumulate;      /* bit 0: dw / dbias += instead of =.  bit 1 (value 2): PARK the second stage -- the launch leaves its
+                              adp_conv1d_wgrad_partials(d) partial slices in ws and the caller sums them later with
+                              adp_wgrad_reduce_batch (set it only when that query returns > 1; ws must stay alive until then) */
 } adp_wgrad_desc;
 
 int64_t adp_conv1d_wgrad_ws_bytes(const adp_wgrad_desc* d);
 int adp_conv1d_wgrad(const adp_wgrad_desc* d, void* stream);
+/* Partial slices a PARKED launch of this problem leaves in ws (see adp_wgrad_desc.accumulate); 1 = the shape has no parked form
+   (the call always finishes dw itself).  Layout of ws: [partials][M*R*KT] followed by [partials][M] (dbias). */
+int64_t adp_conv1d_wgrad_partials(const adp_wgrad_desc* d);
+/* Second stage of n parked weight gradients of ONE shape (partials, cnt = M*R*KT, M) in one launch per 8:
+   dw_i[j] (+)= sum_k ws_i[k*cnt + j], dbias_i[m] (+)= sum_k ws_i[partials*cnt + k*M + m]  (fixed summation order).
+   ws / dw / dbias are HOST arrays of device pointers; dbias may be NULL (no bias gradients).  The ConvBlock convs of one U-Net
+   depth share their shape: their second stages are batched per side of the block. */
+int adp_wgrad_reduce_batch(const float* const* ws, float* const* dw, float* const* dbias, int64_t n, int64_t partials,
+                           int64_t cnt, int64_t M, int64_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm statistics (nn.GroupNorm inside a_unet ConvBlock; components.py:89, resnet_groups :46)

@@ -725,6 +725,31 @@ def test_wgrad_direct_family(dev, B, R, M, L, KT, stride, pad, up):
         assert rel_err(dw2, dw_ref) < TOL
 
 
+@pytest.mark.parametrize("C,L,n,bias,acc", [(32, 4096, 3, True, False), (64, 2048, 10, True, True), (32, 2048, 2, False, False)])
+def test_wgrad_parked_second_stage(dev, C, L, n, bias, acc):
+    """adp_wgrad_desc.accumulate bit 1 + adp_wgrad_reduce_batch: n same-shape split weight gradients leave their partial slices in
+    their own scratch and are summed by one launch per 8 -- same result as the unparked calls (bitwise: same summation order)."""
+    B = 2
+    park = ops.WgradPark()
+    outs, refs = [], []
+    for i in range(n):
+        x, dy = rnd(B, C, L, seed=10 + i).to(dev), rnd(B, C, L, seed=50 + i).to(dev)
+        base, bb = rnd(C, C, 3, seed=90 + i).to(dev), rnd(C, seed=130 + i).to(dev)
+        kw = dict(pad=1, want_bias=bias, accumulate=acc)
+        dw_ref, db_ref = ops.conv1d_wgrad(x, dy, 3, dw=base.clone() if acc else None, dbias=bb.clone() if acc and bias else None, **kw)
+        dw, db = ops.conv1d_wgrad(x, dy, 3, dw=base.clone() if acc else None, dbias=bb.clone() if acc and bias else None,
+                                  park=park, **kw)
+        outs.append((dw, db))
+        refs.append((dw_ref, db_ref))
+    assert len(park.items) == n, "these shapes must take the split matrix-core path"
+    park.flush()
+    assert not park.items
+    for (dw, db), (dw_ref, db_ref) in zip(outs, refs):
+        assert torch.equal(dw.cpu(), dw_ref.cpu())
+        if bias:
+            assert torch.equal(db.cpu(), db_ref.cpu())
+
+
 # ------------------------------------------------------------------ GroupNorm+SiLU backward
 @pytest.mark.parametrize("B,C,L,G", [(2, 8, 3000, 8), (2, 32, 130, 8), (1, 64, 40, 8), (2, 1024, 128, 8)])
 def test_gn_silu_bwd(dev, B, C, L, G):
