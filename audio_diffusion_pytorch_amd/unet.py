@@ -465,16 +465,26 @@ class _Run:
         ops.time_fourier_bwd(self.t, n.time_weights, dcur, dw=self.g(n.time_weights))
         return dfeat
 
-    def bank_grad_for_depth(self, d: int):
+    def bank_grad_all(self) -> None:
+        """The whole conditioning bank's weight / bias gradient in ONE launch (no data-parallel hook: nobody reads a depth's
+        rows before the end of the backward pass; nine launches of 12-27 us become one streaming write of the bank)."""
+        n = self.net
+        if n.bank_total > 0:
+            assert not self.mod_sums.items, "parked Modulation sums while the bank's gradient is formed"
+            ops.linear_bwd_weight(self.dss_all.view(-1), self.feats, act=ACT_SILU, dw=self.g(n.bank_weight),
+                                  dbias=self.g(n.bank_bias), rows=n.bank_total, dy_bstride=n.bank_total)
+
+    def bank_grad_for_depth(self, d: int, defer: bool = False):
         """Weight / bias gradient of depth d's rows of the conditioning bank.  Every Modulation / SkipModulate of
         block d has run its backward when block d's tape entries are done, so these rows are final long before the
         end of the backward pass -- their all-reduce overlaps the shallower blocks instead of trailing the step.
+        `defer`: only the Modulation sums of these rows are flushed; bank_grad_all forms the gradient at the end.
         Returns the (start, end) row range."""
         n = self.net
         a, b = n.bank_depth_rows[d] if n.bank_total > 0 else (0, 0)
         self.mod_sums.flush(a, b)
         assert not any(a <= it[0] < b for it in self.mod_sums.items), "parked Modulation sums inside the rows being read"
-        if b > a:
+        if b > a and not defer:
             K = n.mf
             ops.linear_bwd_weight(self.dss_all.view(-1)[a:], self.feats, act=ACT_SILU,
                                   dw=self.g(n.bank_weight)[a:b], dbias=self.g(n.bank_bias)[a:b], rows=b - a,
@@ -771,6 +781,7 @@ class _UNetFn(torch.autograd.Function):
         # data-parallel hook: called with (flat, start, end) as soon as a contiguous region of the flat
         # gradient buffer is final (deepest blocks first), and with (flat, None, None) at the very end
         hook = getattr(net, "_grad_ready_hook", None)
+        defer_bank = hook is None and os.environ.get("ADP_BANK_DEFER", "1") != "0"  # (A/B switch)
         g = gy.contiguous()
         offs = net._param_offsets()
         for fn, tag in reversed(run.tape):
@@ -778,7 +789,7 @@ class _UNetFn(torch.autograd.Function):
             if tag is not None:
                 if run.wpark is not None:
                     run.wpark.flush()  # (a block's gradients are final when its tag is reached: the data-parallel hook)
-                ra, rb = run.bank_grad_for_depth(tag)
+                ra, rb = run.bank_grad_for_depth(tag, defer=defer_bank)
                 if hook is not None:
                     hook(flat, *net.block_param_range(tag))
                     if rb > ra:  # this depth's weight rows of the conditioning bank (the small bias goes out at the end)
@@ -787,6 +798,8 @@ class _UNetFn(torch.autograd.Function):
         run.mod_sums.flush()  # (nothing is left when every Modulation belongs to a tagged block)
         if run.wpark is not None:
             run.wpark.flush()
+        if defer_bank:
+            run.bank_grad_all()
         if run.ctx_bank is not None:
             run.ctx_bank.backward(run)
         dfeat = run.conditioning_backward()
