@@ -60,6 +60,7 @@ struct f32x4 {
 };
 static inline f32x4 operator+(f32x4 a, f32x4 b) { return f32x4{{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]}}; }
 static inline f32x4 operator*(f32x4 a, float b) { return f32x4{{a[0] * b, a[1] * b, a[2] * b, a[3] * b}}; }
+static inline f32x4 operator*(f32x4 a, f32x4 b) { return f32x4{{a[0] * b[0], a[1] * b[1], a[2] * b[2], a[3] * b[3]}}; }
 
 #define __global__
 #define __device__

@@ -848,7 +848,8 @@ def test_skipmod_bwd(dev):
 @pytest.mark.parametrize("B,K,N,act,post", [(1, 257, 64, 0, 2), (4, 1024, 37, 1, 0), (8, 1500, 20, 2, 0), (37, 96, 50, 1, 0),
                                             (3, 1024, 4100, 1, 0),   # >= 4096 rows: eight rows per wave, ragged last wave
                                             (2, 1300, 4096, 0, 2),   # the same with two K chunks (+ GELU at the end)
-                                            (16, 64, 9, 1, 2)])
+                                            (16, 64, 9, 1, 2),
+                                            (2, 512, 4101, 0, 2), (4, 256, 33, 2, 0)])  # streaming form: 2 / 1 pieces of 256
 def test_linear_fwd_bwd(dev, B, K, N, act, post):
     x = rnd(B, K, seed=1).requires_grad_()
     w = rnd(N, K, seed=2, scale=K ** -0.5).requires_grad_()
