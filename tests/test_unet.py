@@ -351,3 +351,50 @@ def test_unet_odd_channel_counts(dev):
     y_ref.backward(gy)
     y.backward(gy.to(dev))
     compare_grads(net, oracle)
+
+
+def test_parked_weight_gradients_are_final_at_the_block_hook(dev):
+    """Split weight gradients park their second stage (ops.WgradPark) and are summed per block side; when the data-parallel
+    hook is told that a block's slice of the flat gradient buffer is final, nothing of that block may still be parked -- and
+    the gradients equal the oracle's with and without the hook."""
+    cfg = dict(in_channels=2, channels=[32, 32], factors=[1, 2], items=[1, 2], modulation_features=32)
+    oracle, net = build_pair(cfg, dev)
+    inner = net.net if hasattr(net, "net") else net
+    g = torch.Generator().manual_seed(3)
+    x, t = torch.randn(2, 2, 2048, generator=g), torch.tensor([0.2, 0.7])
+    y_ref = oracle(x, t)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    seen = {"parked": 0, "calls": 0}
+    from audio_diffusion_pytorch_amd import ops as _ops
+    add0 = _ops.WgradPark.add
+
+    def counting_add(self, *a):
+        seen["parked"] += 1
+        return add0(self, *a)
+
+    parks = []
+    flush0 = _ops.WgradPark.flush
+
+    def tracking_flush(self):
+        parks.append(self)
+        return flush0(self)
+
+    def hook(flat, a, b):
+        seen["calls"] += 1
+        assert all(not p.items for p in parks), "a block's range was announced while weight gradients were still parked"
+
+    _ops.WgradPark.add, _ops.WgradPark.flush = counting_add, tracking_flush
+    try:
+        for use_hook in (False, True):
+            inner._grad_ready_hook = hook if use_hook else None
+            net.zero_grad(set_to_none=True)
+            y = net(x.to(dev), t.to(dev))
+            y.backward(gy.to(dev))
+            compare_grads(net, oracle)
+    finally:
+        _ops.WgradPark.add, _ops.WgradPark.flush = add0, flush0
+        inner._grad_ready_hook = None
+    assert seen["parked"] > 0, "the test shape must take the split matrix-core weight gradient"
+    assert seen["calls"] > 0
+
