@@ -50,6 +50,7 @@ SIGNATURES = {
     "adp_conv1d_tile": (I, [POINTER(ConvDesc)]),
     "adp_conv1d_wgrad_ws_bytes": (I, [POINTER(WgradDesc)]),
     "adp_conv1d_wgrad": (c_int, [POINTER(WgradDesc), P]),
+    "adp_conv1d_wgrad_batch": (c_int, [POINTER(WgradDesc), I, P]),
     "adp_conv1d_wgrad_partials": (I, [POINTER(WgradDesc)]),
     "adp_wgrad_reduce_batch": (c_int, [P, P, P, I, I, I, I, I, P]),
     "adp_gn_stats_ws_bytes": (I, [I, I, I, I]),

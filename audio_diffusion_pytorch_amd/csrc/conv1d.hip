@@ -927,6 +927,40 @@ extern "C" int adp_wgrad_reduce_batch(const float* const* ws, float* const* dw, 
   return ADP_OK;
 }
 
+extern "C" int adp_conv1d_wgrad(const adp_wgrad_desc* dp, void* stream);
+
+extern "C" int adp_conv1d_wgrad_batch(const adp_wgrad_desc* ds, int64_t n, void* stream) {
+  if (!ds) return ADP_ERR_NULL;
+  if (n <= 0) return ADP_ERR_SHAPE;
+  // one shape: every integer field equal, the same optional pointers present
+  bool same = true, mm = true;
+  for (int64_t i = 0; i < n; ++i) {
+    const adp_wgrad_desc &a = ds[0], &b = ds[i];
+    same = same && a.B == b.B && a.R == b.R && a.R1 == b.R1 && a.Lin == b.Lin && a.M == b.M && a.N == b.N && a.KT == b.KT &&
+           a.stride == b.stride && a.dil == b.dil && a.pad == b.pad && a.up == b.up && a.prologue == b.prologue &&
+           a.groups == b.groups && a.accumulate == b.accumulate && !a.pro_stats == !b.pro_stats &&
+           !a.pro_gamma == !b.pro_gamma && !a.pro_beta == !b.pro_beta && !a.dbias == !b.dbias && !a.x2 == !b.x2;
+    if (!b.x || !b.dy || !b.dw || !b.ws) return ADP_ERR_NULL;
+    if (b.B <= 0 || b.R <= 0 || b.M <= 0 || b.N <= 0 || b.Lin <= 0 || b.up < 1 || b.R1 < 0 || b.R1 > b.R) return ADP_ERR_SHAPE;
+    mm = mm && adp_wgrad_mm_eligible(b) && !(b.prologue != 0 && !b.pro_stats) &&
+         !(b.prologue == 1 && (b.groups < 1 || b.R % b.groups != 0));
+  }
+  if (!same) return ADP_ERR_SHAPE;
+  if (!mm || n == 1) {  // no batched form for this family: one call per item
+    for (int64_t i = 0; i < n; ++i) {
+      const int rc = adp_conv1d_wgrad(ds + i, stream);
+      if (rc != ADP_OK) return rc;
+    }
+    return ADP_OK;
+  }
+  for (int64_t i = 0; i < n; i += ADP_WGR_BATCH) {
+    const int k = (int)(n - i < ADP_WGR_BATCH ? n - i : ADP_WGR_BATCH);
+    const int rc = adp_wgrad_mm_n(ds + i, k, stream);
+    if (rc != ADP_OK) return rc;
+  }
+  return ADP_OK;
+}
+
 extern "C" int adp_conv1d_wgrad(const adp_wgrad_desc* dp, void* stream) {
   if (!dp) return ADP_ERR_NULL;
   const adp_wgrad_desc& d = *dp;

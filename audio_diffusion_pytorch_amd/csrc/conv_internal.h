@@ -19,6 +19,7 @@ int64_t adp_conv_splitk_gn_entries(const adp_conv_desc& d);  // gn_part slices p
 bool adp_wgrad_mm_eligible(const adp_wgrad_desc& d);
 int64_t adp_wgrad_mm_ws_floats(const adp_wgrad_desc& d);
 int64_t adp_wgrad_mm_nsplit(const adp_wgrad_desc& d);
+int adp_wgrad_mm_n(const adp_wgrad_desc* ds, int n, void* stream);
 constexpr int ADP_WGR_BATCH = 8;
 int adp_wgrad_reduce_n(const float* const* ws, float* const* dw, float* const* dbias, int n, int64_t nsplit, int64_t cnt,
                        int64_t M, int accumulate, void* stream);

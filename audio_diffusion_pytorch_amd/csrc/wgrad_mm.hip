@@ -21,6 +21,18 @@
 #include "adp.h"
 #include "conv_internal.h"
 
+// the per-item pointers of a batched launch (adp_conv1d_wgrad_batch): everything else of the items' descriptors is equal
+struct adp_wg_items {
+  const float* x[ADP_WGR_BATCH];
+  const float* dy[ADP_WGR_BATCH];
+  const float* pro_stats[ADP_WGR_BATCH];
+  const float* pro_gamma[ADP_WGR_BATCH];
+  const float* pro_beta[ADP_WGR_BATCH];
+  float* dw[ADP_WGR_BATCH];
+  float* dbias[ADP_WGR_BATCH];
+  float* ws[ADP_WGR_BATCH];
+};
+
 namespace {
 
 struct __attribute__((packed, aligned(4))) adp_f32x3 {  // 12-byte global access (global_store_dwordx3)
@@ -73,7 +85,24 @@ constexpr int WG_NLD = 4;  // loader waves per block
 //     dw0 = P0 + (P1+P2)/2     dw1 = (P1-P2)/2     dw2 = (P1+P2)/2 + P3      (P3 is accumulated with +e1, so: - P3)
 template <int BM, int KT, int S, int UP, int PRO, int PD, bool WN = false>
 __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NLD) * 64) void wgrad_mm_kernel(
-    adp_wgrad_desc d, int CPB, int CPS, int nsplit) {
+    adp_wgrad_desc d_in, int CPB, int CPS, int nsplit, adp_wg_items items, int nitems) {
+  // nitems > 1: `nitems` weight gradients of ONE shape in this launch (adp_conv1d_wgrad_batch): blockIdx.x = item * nsplit + split,
+  // the items differ in their eight pointers only.  The workgroups of consecutive items follow each other on a CU without the
+  // drain / launch / ramp of a kernel boundary between them.
+  adp_wgrad_desc d = d_in;
+  int split_ = blockIdx.x;
+  if (nitems > 1) {
+    const int item = (int)blockIdx.x / nsplit;
+    split_ -= item * nsplit;
+    d.x = items.x[item];
+    d.dy = items.dy[item];
+    d.pro_stats = items.pro_stats[item];
+    d.pro_gamma = items.pro_gamma[item];
+    d.pro_beta = items.pro_beta[item];
+    d.dw = items.dw[item];
+    d.dbias = items.dbias[item];
+    d.ws = items.ws[item];
+  }
   static_assert(!WN || (KT == 3 && S == 1), "Winograd F(2,3): kernel 3, stride 1 (any upsample factor)");
   constexpr int BR = BM, BKN = WG_BKN, NKG = (BM == 64 ? 2 : 4), PPW = BKN / NKG;
   constexpr int NQR = BR / 32, NQ = (BM / 32) * NQR, NMMA = NQ * NKG, NLT = WG_NLD * 64;
@@ -94,7 +123,7 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
 
   const int M = (int)d.M, R = (int)d.R, L = (int)d.Lin, N = (int)d.N, G = (int)d.groups;
   const int Lv = L * UP;
-  const int split = blockIdx.x;
+  const int split = split_;
   const int m0 = blockIdx.y * BM, r0 = blockIdx.z * BR;
   const int total = (int)d.B * CPB;
   const int cbeg = split * CPS, cend = (cbeg + CPS < total) ? cbeg + CPS : total;
@@ -517,24 +546,33 @@ namespace {
 
 // PD: a 64x64 chunk is 2.6 us of MFMAs (one register stage), a 32x32 chunk 0.64 us (two)
 template <int BM, int KT, int S, int UP, int PRO, bool WN = false, int PD = (BM == 64 ? 1 : 2)>
-int launch_wg(const adp_wgrad_desc& d, const WgPlan& p, void* stream) {
-  dim3 grid((unsigned)p.nsplit, (unsigned)(d.M / BM), (unsigned)(d.R / BM));
+int launch_wg(const adp_wgrad_desc* ds, int n, const WgPlan& p, void* stream) {
+  const adp_wgrad_desc& d = ds[0];
+  adp_wg_items it;
+  for (int i = 0; i < ADP_WGR_BATCH; ++i) {
+    const adp_wgrad_desc& e = ds[i < n ? i : 0];
+    it.x[i] = e.x, it.dy[i] = e.dy, it.pro_stats[i] = e.pro_stats, it.pro_gamma[i] = e.pro_gamma, it.pro_beta[i] = e.pro_beta;
+    it.dw[i] = e.dw, it.dbias[i] = e.dbias, it.ws[i] = e.ws;
+  }
+  dim3 grid((unsigned)(p.nsplit * n), (unsigned)(d.M / BM), (unsigned)(d.R / BM));
   constexpr int NTH = ((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NLD) * 64;
   ADP_LAUNCH((wgrad_mm_kernel<BM, KT, S, UP, PRO, PD, WN>), grid, dim3(NTH), stream, d, (int)p.cpb, (int)p.cps,
-             (int)p.nsplit);
+             (int)p.nsplit, it, n);
   if (p.nsplit > 1 && !(d.accumulate & 2)) {  // (bit 1 of `accumulate`: the caller parks the second stage, adp.h)
-    return adp_wgrad_reduce(d.ws, p.nsplit, d.M * d.R * KT, d.M, d.dw, d.dbias, (int)(d.accumulate & 1), stream);
+    if (ADP_LAUNCH_OK() != ADP_OK) return ADP_ERR_LAUNCH;
+    return adp_wgrad_reduce_n(it.ws, it.dw, d.dbias ? it.dbias : nullptr, n, p.nsplit, d.M * d.R * KT, d.M,
+                              (int)(d.accumulate & 1), stream);
   }
   return ADP_LAUNCH_OK();
 }
 
 template <int KT, int S, int UP, int PRO, bool WN = false>
-int pick_wg(const adp_wgrad_desc& d, void* stream) {
-  const WgPlan p = wg_plan(d);
+int pick_wg(const adp_wgrad_desc* ds, int n, void* stream) {
+  const WgPlan p = wg_plan(ds[0]);
   if constexpr (S != 4) {
-    if (p.bm == 64) return launch_wg<64, KT, S, UP, PRO, WN>(d, p, stream);
+    if (p.bm == 64) return launch_wg<64, KT, S, UP, PRO, WN>(ds, n, p, stream);
   }
-  return launch_wg<32, KT, S, UP, PRO, WN>(d, p, stream);
+  return launch_wg<32, KT, S, UP, PRO, WN>(ds, n, p, stream);
 }
 
 // Winograd F(2,3) form of the kernel-3 weight gradients (WN): same switch as the forward / data-gradient convs
@@ -571,13 +609,17 @@ int64_t adp_wgrad_mm_ws_floats(const adp_wgrad_desc& d) {
   return p.nsplit * (d.M * d.R * d.KT + d.M);
 }
 
-int adp_wgrad_mm(const adp_wgrad_desc& d, void* stream) {
-  if (d.stride == 2) return pick_wg<2, 2, 1, 0>(d, stream);
-  if (d.stride == 4) return pick_wg<4, 4, 1, 0>(d, stream);
-  if (d.up == 2) return wg_winograd(d) ? pick_wg<3, 1, 2, 0, true>(d, stream) : pick_wg<3, 1, 2, 0>(d, stream);
-  if (d.up == 4) return wg_winograd(d) ? pick_wg<3, 1, 4, 0, true>(d, stream) : pick_wg<3, 1, 4, 0>(d, stream);
+// n <= ADP_WGR_BATCH weight gradients of one shape (descriptors equal up to their pointers) in one launch
+int adp_wgrad_mm_n(const adp_wgrad_desc* ds, int n, void* stream) {
+  const adp_wgrad_desc& d = ds[0];
+  if (d.stride == 2) return pick_wg<2, 2, 1, 0>(ds, n, stream);
+  if (d.stride == 4) return pick_wg<4, 4, 1, 0>(ds, n, stream);
+  if (d.up == 2) return wg_winograd(d) ? pick_wg<3, 1, 2, 0, true>(ds, n, stream) : pick_wg<3, 1, 2, 0>(ds, n, stream);
+  if (d.up == 4) return wg_winograd(d) ? pick_wg<3, 1, 4, 0, true>(ds, n, stream) : pick_wg<3, 1, 4, 0>(ds, n, stream);
   if (d.KT == 3 && wg_winograd(d))
-    return d.prologue == 1 ? pick_wg<3, 1, 1, 1, true>(d, stream) : pick_wg<3, 1, 1, 0, true>(d, stream);
-  if (d.KT == 3) return d.prologue == 1 ? pick_wg<3, 1, 1, 1>(d, stream) : pick_wg<3, 1, 1, 0>(d, stream);
-  return d.prologue == 1 ? pick_wg<1, 1, 1, 1>(d, stream) : pick_wg<1, 1, 1, 0>(d, stream);
+    return d.prologue == 1 ? pick_wg<3, 1, 1, 1, true>(ds, n, stream) : pick_wg<3, 1, 1, 0, true>(ds, n, stream);
+  if (d.KT == 3) return d.prologue == 1 ? pick_wg<3, 1, 1, 1>(ds, n, stream) : pick_wg<3, 1, 1, 0>(ds, n, stream);
+  return d.prologue == 1 ? pick_wg<1, 1, 1, 1>(ds, n, stream) : pick_wg<1, 1, 1, 0>(ds, n, stream);
 }
+
+int adp_wgrad_mm(const adp_wgrad_desc& d, void* stream) { return adp_wgrad_mm_n(&d, 1, stream); }

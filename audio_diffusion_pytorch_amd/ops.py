@@ -5,6 +5,7 @@ gfx950 kernels; they hold no arithmetic of their own and have no fallback.  Outp
 the caller or with torch.empty on the input's device (PyTorch = device memory + streams only).
 """
 import ctypes
+import os
 from ctypes import byref
 from typing import Optional
 
@@ -85,13 +86,36 @@ class WgradPark:
     scratch until flush() sums every parked gradient of one shape in ONE launch (adp_wgrad_reduce_batch) -- the ConvBlock
     convs of a U-Net depth share their shape, so a block side's four to eight second stages become one."""
 
+    # whole weight-gradient CALLS are collected too (`calls`): small problems, where the inputs of a block side's gradients stay
+    # in the Infinity Cache until the side is done, run as one launch per shape (adp_conv1d_wgrad_batch)
+    BATCH_BYTES = 24 << 20  # x + dy of one call; above it only the second stage is parked
+
     def __init__(self):
         self.items = []  # (key = (partials, cnt, M, accumulate, has_bias), ws, dw, dbias)
+        self.calls = []  # (shape key, WgradDesc, tensors kept alive)
+        if "ADP_WGRAD_BATCH_MB" in os.environ:  # (A/B: 0 = only second stages are parked)
+            self.BATCH_BYTES = int(os.environ["ADP_WGRAD_BATCH_MB"]) << 20
 
     def add(self, key, ws: Tensor, dw: Tensor, dbias: Optional[Tensor]) -> None:
         self.items.append((key, ws, dw, dbias))
 
+    def add_call(self, key, d: WgradDesc, keep) -> None:
+        self.calls.append((key, d, keep))
+
     def flush(self) -> None:
+        if self.calls:
+            groups = {}
+            for key, d, keep in self.calls:
+                groups.setdefault(key, []).append(d)
+            calls, self.calls = self.calls, []
+            for key, ds in groups.items():
+                arr = (WgradDesc * len(ds))(*ds)
+                if _C.PROFILE is not None:
+                    B, R, _, Lin, M, N, KT = key[:7]
+                    _C.tag(flops=2 * B * M * N * R * KT * len(ds), bytes=4 * len(ds) * (B * R * Lin + B * M * N + M * R * KT),
+                           shape=f"n{len(ds)} B{B} R{R} M{M} N{N} KT{KT}")
+                _C.call("adp_conv1d_wgrad_batch", arr, len(ds), _C.stream())
+            del calls
         if not self.items:
             return
         groups = {}
@@ -126,6 +150,12 @@ def conv1d_wgrad(x: Tensor, dy: Tensor, KT: int, *, stride: int = 1, dil: int = 
     if _C.PROFILE is not None:  # A_x + A_dy + weight-gradient write
         _C.tag(flops=2 * B * M * N * R * KT, bytes=4 * (B * R * Lin + dy.numel() + dw.numel()),
                shape=f"B{B} R{R} M{M} N{N} KT{KT} s{stride} up{up} pro{prologue}")
+    if park is not None and x2 is None and 4 * (x.numel() + dy.numel()) <= park.BATCH_BYTES:
+        # the whole call waits for park.flush(): one launch per shape with the block side's other gradients
+        key = (B, R, R1, Lin, M, N, KT, stride, dil, pad, up, prologue, groups, int(accumulate), pro_stats is not None,
+               pro_gamma is not None, pro_beta is not None, dbias is not None)
+        park.add_call(key, d, (x, dy, pro_stats, pro_gamma, pro_beta, dw, dbias, ws))
+        return dw, dbias
     if park is not None:
         partials = _C.query("adp_conv1d_wgrad_partials", byref(d))
         if partials > 1:  # the second stage waits for park.flush(); ws belongs to the parked item until then

@@ -123,6 +123,11 @@ typedef struct adp_wgrad_desc {
 
 int64_t adp_conv1d_wgrad_ws_bytes(const adp_wgrad_desc* d);
 int adp_conv1d_wgrad(const adp_wgrad_desc* d, void* stream);
+/* n weight gradients of ONE shape (descriptors equal in every integer field and in which optional pointers are set; each with
+   its own ws) -- the ConvBlock convs of one side of a U-Net block.  The matrix-core family runs them as ONE launch per 8 (the
+   items' workgroups follow each other on a CU without a kernel boundary) + one batched second stage; other families run item by
+   item.  Nothing on the backward chain waits for a weight gradient, so the caller may collect them until the block side is done. */
+int adp_conv1d_wgrad_batch(const adp_wgrad_desc* descs, int64_t n, void* stream);
 /* Partial slices a PARKED launch of this problem leaves in ws (see adp_wgrad_desc.accumulate); 1 = the shape has no parked form
    (the call always finishes dw itself).  Layout of ws: [partials][M*R*KT] followed by [partials][M] (dbias). */
 int64_t adp_conv1d_wgrad_partials(const adp_wgrad_desc* d);

@@ -725,12 +725,17 @@ def test_wgrad_direct_family(dev, B, R, M, L, KT, stride, pad, up):
         assert rel_err(dw2, dw_ref) < TOL
 
 
+@pytest.mark.parametrize("whole", [False, True])
 @pytest.mark.parametrize("C,L,n,bias,acc", [(32, 4096, 3, True, False), (64, 2048, 10, True, True), (32, 2048, 2, False, False)])
-def test_wgrad_parked_second_stage(dev, C, L, n, bias, acc):
-    """adp_wgrad_desc.accumulate bit 1 + adp_wgrad_reduce_batch: n same-shape split weight gradients leave their partial slices in
-    their own scratch and are summed by one launch per 8 -- same result as the unparked calls (bitwise: same summation order)."""
+def test_wgrad_parked_second_stage(dev, C, L, n, bias, acc, whole):
+    """Parked weight gradients (ops.WgradPark).  whole = False: adp_wgrad_desc.accumulate bit 1 + adp_wgrad_reduce_batch -- n
+    same-shape split weight gradients leave their partial slices in their own scratch and are summed by one launch per 8.
+    whole = True: the calls themselves wait and run as one launch per 8 (adp_conv1d_wgrad_batch: blockIdx.x = item * splits +
+    split) + one batched second stage.  Same result as the plain calls either way (bitwise: same arithmetic, same order)."""
     B = 2
     park = ops.WgradPark()
+    if not whole:
+        park.BATCH_BYTES = 0
     outs, refs = [], []
     for i in range(n):
         x, dy = rnd(B, C, L, seed=10 + i).to(dev), rnd(B, C, L, seed=50 + i).to(dev)
@@ -741,9 +746,9 @@ def test_wgrad_parked_second_stage(dev, C, L, n, bias, acc):
                                   park=park, **kw)
         outs.append((dw, db))
         refs.append((dw_ref, db_ref))
-    assert len(park.items) == n, "these shapes must take the split matrix-core path"
+    assert len(park.calls if whole else park.items) == n, "these shapes must take the split matrix-core path"
     park.flush()
-    assert not park.items
+    assert not park.items and not park.calls
     for (dw, db), (dw_ref, db_ref) in zip(outs, refs):
         assert torch.equal(dw.cpu(), dw_ref.cpu())
         if bias:

@@ -367,11 +367,15 @@ def test_parked_weight_gradients_are_final_at_the_block_hook(dev):
     y_ref.backward(gy)
     seen = {"parked": 0, "calls": 0}
     from audio_diffusion_pytorch_amd import ops as _ops
-    add0 = _ops.WgradPark.add
+    add0, addc0 = _ops.WgradPark.add, _ops.WgradPark.add_call
 
     def counting_add(self, *a):
         seen["parked"] += 1
         return add0(self, *a)
+
+    def counting_add_call(self, *a):
+        seen["parked"] += 1
+        return addc0(self, *a)
 
     parks = []
     flush0 = _ops.WgradPark.flush
@@ -382,9 +386,10 @@ def test_parked_weight_gradients_are_final_at_the_block_hook(dev):
 
     def hook(flat, a, b):
         seen["calls"] += 1
-        assert all(not p.items for p in parks), "a block's range was announced while weight gradients were still parked"
+        assert all(not p.items and not p.calls for p in parks), \
+            "a block's range was announced while weight gradients were still parked"
 
-    _ops.WgradPark.add, _ops.WgradPark.flush = counting_add, tracking_flush
+    _ops.WgradPark.add, _ops.WgradPark.add_call, _ops.WgradPark.flush = counting_add, counting_add_call, tracking_flush
     try:
         for use_hook in (False, True):
             inner._grad_ready_hook = hook if use_hook else None
@@ -393,7 +398,7 @@ def test_parked_weight_gradients_are_final_at_the_block_hook(dev):
             y.backward(gy.to(dev))
             compare_grads(net, oracle)
     finally:
-        _ops.WgradPark.add, _ops.WgradPark.flush = add0, flush0
+        _ops.WgradPark.add, _ops.WgradPark.add_call, _ops.WgradPark.flush = add0, addc0, flush0
         inner._grad_ready_hook = None
     assert seen["parked"] > 0, "the test shape must take the split matrix-core weight gradient"
     assert seen["calls"] > 0
