@@ -26,14 +26,16 @@ class CtxBank:
     launch over the bank + the un-fold.  Replaces, per item, LayerNorm + projection (+ split-K reduce) in the forward and
     weight gradient + reduce, data gradient + reduce, LayerNorm backward + reduce and the embedding-gradient add in the
     backward -- about ten launches on a [B, E, 64] tensor each (BASELINE config 4: 32 items).
-    Not used under the data-parallel hook (there a block's gradients must be final when the block's backward is done)."""
+    Data-parallel safe: the items' context-side gradients (norm_context, to_kv) live in their OWN trailing region of the flat
+    gradient buffer (UNetV0Net._param_offsets), `backward` runs as soon as the shallowest cross-attention block is done and
+    the hook then gets that region as one bucket (unet._UNetFn.backward)."""
 
     @staticmethod
     def prepare(run, context: Tensor):
         net = run.net
         items = [p for d in range(len(net.blocks)) for mods in (net.blocks[d].items_down, net.blocks[d].items_up)
                  for t, p in zip(net.item_types[d], mods) if t == "cross_attention"]
-        if len(items) < 2 or getattr(net, "_grad_ready_hook", None) is not None:
+        if len(items) < 2:
             return None
         dev = context.device
         ptrs = tuple(t.data_ptr() for p in items for t in (p.to_kv.weight, p.norm_context.weight, p.norm_context.bias))

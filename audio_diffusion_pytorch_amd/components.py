@@ -195,6 +195,51 @@ def UNetV0(
     return net
 
 
+def load_reference_state_dict(net: nn.Module, sd) -> dict:
+    """EXPERIMENTAL like UNetV0Net.load_a_unet_state_dict, which it extends to whatever `UNetV0(...)` /
+    `AppendChannelsPlugin(UNetV0, n)(...)` returned: a checkpoint of the reference's net incl. its plugins.  The reference
+    nests Time(Text(CFG(XUNet))) (components.py:66-76) and every plugin is a `Module([own modules..., net], fn)`, so its
+    floating-point tensors come as [time embedder + MLP | T5 encoder (use_text_conditioning) | fixed_embedding
+    (use_embedding_cfg) | XUNet blocks]: the time tensors and the block tensors go through the positional loader, the
+    fixed-embedding table (identified by its `[embedding_max_length, embedding_features]` shape right in front of the
+    blocks) into ClassifierFreeGuidanceNet.fixed_embedding, and the frozen pretrained T5 tensors are NOT loaded (they are
+    t5-base's own weights; the embedder here is the caller's module or the local t5-base).  Returns {checkpoint key: what it
+    was loaded as / "skipped: ..."}."""
+    cfg_net, has_text, inner = None, False, net
+    while not isinstance(inner, UNetV0Net):
+        if isinstance(inner, ClassifierFreeGuidanceNet):
+            cfg_net = inner
+        elif isinstance(inner, TextConditioningNet):
+            has_text = True
+        elif not isinstance(inner, _AppendChannelsNet):
+            raise TypeError(f"load_reference_state_dict: {type(inner).__name__} does not wrap a UNetV0")
+        inner = inner.net
+    theirs = [(k, v) for k, v in sd.items() if torch.is_tensor(v) and v.dtype.is_floating_point]
+    n_unet = len(inner.a_unet_key_order())
+    n_time = sum(1 for k in inner.a_unet_key_order() if k.startswith("time_"))
+    n_extra = len(theirs) - n_unet
+    if n_extra < (1 if cfg_net is not None else 0) or (n_extra > (1 if cfg_net is not None else 0) and not has_text):
+        raise ValueError(f"checkpoint holds {len(theirs)} floating-point tensors; this net expects {n_unet} for the U-Net"
+                         + (" + the fixed-embedding table" if cfg_net is not None else "")
+                         + (" + the text encoder's" if has_text else ""))
+    extras = theirs[n_time:n_time + n_extra]
+    out = {}
+    if cfg_net is not None:
+        k, v = extras[-1]
+        if tuple(v.shape) != tuple(cfg_net.fixed_embedding.weight.shape):
+            raise ValueError(f"checkpoint entry {k!r} has shape {tuple(v.shape)} where the fixed-embedding table "
+                             f"{tuple(cfg_net.fixed_embedding.weight.shape)} is expected (right in front of the blocks)")
+        with torch.no_grad():
+            cfg_net.fixed_embedding.weight.copy_(v)
+        out[k] = "fixed_embedding.weight"
+        extras = extras[:-1]
+    for k, _ in extras:
+        out[k] = "skipped: frozen pretrained text-encoder tensor (TextConditioningPlugin's T5)"
+    core = dict(theirs[:n_time] + theirs[n_time + n_extra:])
+    out.update(inner.load_a_unet_state_dict(core))
+    return out
+
+
 class _ConcatChannels(torch.autograd.Function):
     """cat([x, extra], dim=1) on adp_copy2d, with the split as its gradient."""
 

@@ -16,7 +16,10 @@ from . import _C
 from ._C import ConvDesc, WgradDesc, ptr
 
 GN_EPS = 1e-5
-LN_EPS = 1e-5
+# LayerNorm epsilons of the two item families, separately switchable (oracle/a_unet_restatement.py [switch] block: a_unet's
+# Modulation may carry eps=1e-6 on its own LayerNorm; unverifiable offline, both 1e-5 until tools/pin_a_unet.py says otherwise)
+MODULATION_LN_EPS = 1e-5
+ATTENTION_LN_EPS = 1e-5
 
 
 def _ws(nbytes: int, like: Tensor) -> Tensor:
@@ -147,15 +150,16 @@ def conv1d_wgrad(x: Tensor, dy: Tensor, KT: int, *, stride: int = 1, dil: int = 
                   B, R, R1, Lin, M, N, KT, stride, dil, pad, up, prologue, groups, int(accumulate))
     ws = _ws(_C.query("adp_conv1d_wgrad_ws_bytes", byref(d)), x)
     d.ws = ptr(ws)
-    if _C.PROFILE is not None:  # A_x + A_dy + weight-gradient write
-        _C.tag(flops=2 * B * M * N * R * KT, bytes=4 * (B * R * Lin + dy.numel() + dw.numel()),
-               shape=f"B{B} R{R} M{M} N{N} KT{KT} s{stride} up{up} pro{prologue}")
     if park is not None and x2 is None and 4 * (x.numel() + dy.numel()) <= park.BATCH_BYTES:
         # the whole call waits for park.flush(): one launch per shape with the block side's other gradients
+        # (tagged there: a tag set here would ride on whatever profiled launch comes next)
         key = (B, R, R1, Lin, M, N, KT, stride, dil, pad, up, prologue, groups, int(accumulate), pro_stats is not None,
                pro_gamma is not None, pro_beta is not None, dbias is not None)
         park.add_call(key, d, (x, dy, pro_stats, pro_gamma, pro_beta, dw, dbias, ws))
         return dw, dbias
+    if _C.PROFILE is not None:  # A_x + A_dy + weight-gradient write
+        _C.tag(flops=2 * B * M * N * R * KT, bytes=4 * (B * R * Lin + dy.numel() + dw.numel()),
+               shape=f"B{B} R{R} M{M} N{N} KT{KT} s{stride} up{up} pro{prologue}")
     if park is not None:
         partials = _C.query("adp_conv1d_wgrad_partials", byref(d))
         if partials > 1:  # the second stage waits for park.flush(); ws belongs to the parked item until then
@@ -253,7 +257,7 @@ def gn_silu_bwd(x: Tensor, dact: Tensor, stats: Tensor, gamma: Tensor, beta: Ten
     return dx, dgamma, dbeta
 
 
-def modulation_fwd(x: Tensor, ss: Tensor, ss_bstride: int, eps: float = LN_EPS, y: Optional[Tensor] = None,
+def modulation_fwd(x: Tensor, ss: Tensor, ss_bstride: int, eps: float = MODULATION_LN_EPS, y: Optional[Tensor] = None,
                    stats: Optional[Tensor] = None):
     """ss: 1-D view whose element [b*ss_bstride + c] is scale and [b*ss_bstride + C + c] is shift."""
     B, C, L = x.shape
@@ -313,7 +317,7 @@ class ModulationSums:
             _C.call("adp_modulation_bwd_reduce", wsp, dsp, n, B, C, NT, bstride, _C.stream())
 
 
-def ln_stats(x: Tensor, eps: float = LN_EPS) -> Tensor:
+def ln_stats(x: Tensor, eps: float = ATTENTION_LN_EPS) -> Tensor:
     B, C, L = x.shape
     stats = torch.empty((B, L, 2), dtype=torch.float32, device=x.device)
     _C.call("adp_ln_stats", ptr(x), B, C, L, eps, ptr(stats), _C.stream())
@@ -321,7 +325,7 @@ def ln_stats(x: Tensor, eps: float = LN_EPS) -> Tensor:
 
 
 def ln_affine_fwd(x: Tensor, gamma: Tensor, beta: Tensor, gamma2: Optional[Tensor] = None,
-                  beta2: Optional[Tensor] = None, eps: float = LN_EPS):
+                  beta2: Optional[Tensor] = None, eps: float = ATTENTION_LN_EPS):
     """(y, y2 or None, stats): y = LayerNorm_C(x) * gamma + beta, y2 likewise with (gamma2, beta2), stats [B, L, 2]."""
     B, C, L = x.shape
     y = torch.empty_like(x)

@@ -46,6 +46,9 @@ class DataParallel(nn.Module):
         DiffusionAE encoder, ...) -- ordinary autograd gradients, gathered into ONE trailing bucket and all-reduced
         when the whole backward pass is over (together with a per-parameter "some rank produced a gradient" flag, so
         parameters unused on every rank keep grad = None).
+    Gradient accumulation: the U-Net's gradients are averaged per backward pass (so accumulating averaged gradients over
+    several passes is exact); the trailing bucket averages whatever `p.grad` HOLDS at the end of a pass, so for parameters
+    outside the U-Net call zero_grad between passes (accumulating there would average an already averaged part again).
     The U-Net's collectives are waited for (stream wait, no host sync) at the end of the U-Net's backward node --
     before autograd's AccumulateGrad touches the flat buffer's views; the trailing bucket is issued and waited for
     in an autograd final callback, after the last node of the backward pass."""
@@ -118,8 +121,10 @@ class DataParallel(nn.Module):
                 off += n
             self._tail_flags = self._tail[total:]
             self._tail_host = torch.zeros(len(sizes), dtype=torch.float32)
+            self._tail_event = None
             if ref.is_cuda:
                 self._tail_host = self._tail_host.pin_memory()
+                self._tail_event = torch.cuda.Event()  # guards the pinned row against the next step's host write
         return self._tail
 
     def _finalize(self):
@@ -132,8 +137,12 @@ class DataParallel(nn.Module):
             dst = [v for v, h in zip(self._tail_views, have) if h]
             if dst:
                 torch._foreach_copy_(dst, [p.grad for p, h in zip(self._extra, have) if h])
+            if self._tail_event is not None:
+                self._tail_event.synchronize()  # the previous step's asynchronous copy has read the pinned row
             self._tail_host.copy_(torch.tensor(have, dtype=torch.float32))
             self._tail_flags.copy_(self._tail_host, non_blocking=True)
+            if self._tail_event is not None:
+                self._tail_event.record()
             self._works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
         self._wait_all()
         if self._extra:
@@ -157,7 +166,7 @@ class DataParallel(nn.Module):
         """How much of the gradient all-reduce hides under the backward pass.  Three timings of `step()` (a full
         forward + backward through this wrapper; `timer(fn, n)` -> seconds per call incl. device sync):
           step_ms                      the data-parallel step as it runs
-          step_without_allreduce_ms    the same step with the collectives skipped (hook detached: what backward costs)
+          step_without_allreduce_ms    the same step with the collectives skipped (a no-op hook: the same kernels, no sends)
           allreduce_alone_ms           the step's bucket sequence all-reduced back to back with no compute beside it
         hidden_frac = 1 - (step - step_without) / allreduce_alone: 1.0 = fully overlapped, 0.0 = fully exposed."""
         if not self._collect:
@@ -173,7 +182,9 @@ class DataParallel(nn.Module):
         if not sent:
             raise RuntimeError("measure_overlap: step() sent no gradient bucket -- it has to run a backward pass through the "
                                "wrapped U-Net")
-        self.unet._grad_ready_hook = None
+        # a no-op hook, NOT None: a detached hook also switches the backward to the deferred one-launch conditioning-bank
+        # gradient (unet._UNetFn.backward: defer_bank), i.e. to different kernels than the step being measured
+        self.unet._grad_ready_hook = lambda flat, a, b: None
         try:
             t_plain = timer(step, reps)
         finally:

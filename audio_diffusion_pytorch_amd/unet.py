@@ -57,7 +57,8 @@ A_UNET_SEMANTICS = {
     "SKIP_SCALES_BRANCH": True,            # _Run.block: y = skip + scale * (up conv), conv epilogue e_scale / res
     "SKIP_CAT_SCALE": 2 ** -0.5,           # _Run.block (use_modulation=False): cat[skip * 2^-1/2, x]
     "GN_EPS": ops.GN_EPS,
-    "LN_EPS": ops.LN_EPS,
+    "MODULATION_LN_EPS": ops.MODULATION_LN_EPS,  # ops.modulation_fwd -> adp_modulation_fwd(eps); stats carry rstd to the backward
+    "ATTENTION_LN_EPS": ops.ATTENTION_LN_EPS,    # ops.ln_affine_fwd / ln_stats -> adp_ln_affine_fwd(eps) (norm, norm_context, CtxBank)
 }
 
 
@@ -276,11 +277,15 @@ class UNetV0Net(nn.Module):
         return names
 
     def load_a_unet_state_dict(self, sd: Dict[str, Tensor]) -> Dict[str, str]:
-        """Loads a checkpoint of the REFERENCE's UNetV0 (a_unet's own key names, e.g. `blocks.2.blocks.1.blocks.3...`): the
-        floating-point tensors of `sd`, in its (registration) order, are assigned to `a_unet_key_order()` position by
-        position, every shape checked -- the names themselves are never interpreted, so the exact spelling of a_unet's
-        nesting does not matter, only its construction order.  Returns {checkpoint key: name it was loaded as}.  Raises
-        with the first mismatching entry when the checkpoint does not have this net's structure."""
+        """EXPERIMENTAL (stays so until tools/pin_a_unet.py has run against the real a_unet).  Loads a checkpoint of the
+        REFERENCE's UNetV0 (a_unet's own key names, e.g. `blocks.2.blocks.1.blocks.3...`): the floating-point tensors of `sd`,
+        in its (registration) order, are assigned to `a_unet_key_order()` position by position.  Guards against a silently
+        wrong order: every shape is checked, and the checkpoint key's LAST component (`weight` / `bias` / `weights`) has to
+        be the target's -- a GroupNorm's (weight, bias) pair or a conv's swapped, or a bias-free Linear where a biased layer
+        is expected, is refused (equal-shaped layers in another order -- conv1 / conv2 of a ResnetItem, depths with equal
+        channel counts -- cannot be told apart without a_unet; that is what the pin recipe is for).  The nesting names
+        themselves are never interpreted.  Returns {checkpoint key: name it was loaded as}.  Checkpoints of the plugin
+        wrappers (use_embedding_cfg / use_text_conditioning / AppendChannels): components.load_reference_state_dict."""
         theirs = [(k, v) for k, v in sd.items() if torch.is_tensor(v) and v.dtype.is_floating_point]
         order = self.a_unet_key_order()
         if len(theirs) != len(order):
@@ -293,6 +298,10 @@ class UNetV0Net(nn.Module):
                 raise ValueError(f"checkpoint entry {k!r} has shape {tuple(v.shape)}, expected {shapes[name]} for {name!r}: the "
                                  f"checkpoint was not produced by UNetV0 with this configuration (or a_unet registers its "
                                  f"parameters in another order than recalled: see a_unet_key_order)")
+            last, want = k.rsplit(".", 1)[-1], name.rsplit(".", 1)[-1].replace("time_weights", "weights")
+            if last in ("weight", "bias", "weights") and last != want:
+                raise ValueError(f"checkpoint entry {k!r} is a `{last}` where {name!r} (a `{want}`) is expected at this position: "
+                                 f"a_unet registers its parameters in another order than recalled (see a_unet_key_order)")
         self.load_oracle_state_dict({name: v.reshape(shapes[name]) for (k, v), name in zip(theirs, order)})
         return {k: name for (k, _), name in zip(theirs, order)}
 
@@ -324,19 +333,53 @@ class UNetV0Net(nn.Module):
             out[base + ".bias"] = grads["bank_bias"][off:off + nout]
         return out
 
-    # ------------------------------------------------------------------ flat gradient layout (parameter order)
+    # ------------------------------------------------------------------ flat gradient layout
+    def _is_ctx_side(self, name: str) -> bool:
+        """Context-side parameters (norm_context, to_kv) of a CROSS-attention item: their gradients come out of the context
+        bank's backward (attention.CtxBank), one launch for all items after the last of them has run -- not when their block
+        is done.  They live in ONE trailing region of the flat gradient buffer so that every block's region stays contiguous
+        and the data-parallel hook gets the context side as a single bucket (`ctx_param_range`)."""
+        parts = name.split(".")
+        if len(parts) < 6 or parts[0] != "blocks" or parts[4] not in ("norm_context", "to_kv"):
+            return False
+        return self.item_types[int(parts[1])][int(parts[3])] == ITEM_CROSS_ATTENTION
+
     def _param_offsets(self):
+        """{parameter name: (start, end)} in the flat gradient buffer: parameter order, except that the context side of the
+        cross-attention items is moved behind everything else (per item still [norm_context.weight | norm_context.bias |
+        to_kv.weight], so the (gamma, beta) pair stays adjacent)."""
         if getattr(self, "_offsets", None) is None:
-            off, table = 0, {}
+            off, table, late = 0, {}, []
             for name, p in self.named_parameters():
+                if self._is_ctx_side(name):
+                    late.append((name, p.numel()))
+                    continue
                 table[name] = (off, off + p.numel())
                 off += p.numel()
+            self._ctx_range = (off, off)
+            for name, n in late:
+                table[name] = (off, off + n)
+                off += n
+            self._ctx_range = (self._ctx_range[0], off)
             self._offsets = table
         return self._offsets
 
+    def ctx_param_range(self):
+        """(start, end) of the cross-attention context-side gradients in the flat buffer (empty without cross attention)."""
+        self._param_offsets()
+        return self._ctx_range
+
+    def ctx_final_depth(self) -> int:
+        """The shallowest depth holding a CrossAttentionItem: once that block's backward is done no item adds to the context
+        side any more (-1 without cross attention)."""
+        for d, its in enumerate(self.item_types):
+            if ITEM_CROSS_ATTENTION in its:
+                return d
+        return -1
+
     def block_param_range(self, d: int):
         t = self._param_offsets()
-        spans = [v for k, v in t.items() if k.startswith(f"blocks.{d}.")]
+        spans = [v for k, v in t.items() if k.startswith(f"blocks.{d}.") and not self._is_ctx_side(k)]
         return min(a for a, _ in spans), max(b for _, b in spans)
 
     def nonblock_param_ranges(self):
@@ -751,6 +794,8 @@ class _UNetFn(torch.autograd.Function):
         if embedding is not None and os.environ.get("ADP_CTX_BANK", "1") != "0":
             from .attention import CtxBank
             run.ctx_bank = CtxBank.prepare(run, embedding.contiguous())
+            if run.ctx_bank is not None:  # (visible to tests / bench: which path a step took)
+                net._ctx_bank_runs = getattr(net, "_ctx_bank_runs", 0) + 1
         y = run.block(0, x, x2, embedding.contiguous() if embedding is not None else None, channels,
                       need_dx=bool(ctx.needs_input_grad[1]))
         ctx.run = run
@@ -771,19 +816,21 @@ class _UNetFn(torch.autograd.Function):
         total = sum(p.numel() for p in params)
         flat = _grad_buffer((total,), gy.device)  # every parameter's slice is overwritten by its gradient kernel
         run.flat = flat
-        off = 0
+        offs = net._param_offsets()
         views = []
-        for name, p in net.named_parameters():
-            v = flat[off:off + p.numel()].view(p.shape)
+        for name, p in net.named_parameters():  # (returned to autograd in parameter order; the views point where the layout says)
+            a, b = offs[name]
+            v = flat[a:b].view(p.shape)
             run.grads[name] = v
             views.append(v)
-            off += p.numel()
         # data-parallel hook: called with (flat, start, end) as soon as a contiguous region of the flat
         # gradient buffer is final (deepest blocks first), and with (flat, None, None) at the very end
         hook = getattr(net, "_grad_ready_hook", None)
+        # the conditioning bank's gradient: one launch at the end when nobody wants a depth's rows early; under the hook it
+        # stays per depth ON PURPOSE (184 MB in one trailing bucket would be all-reduced after the backward instead of under it)
         defer_bank = hook is None and os.environ.get("ADP_BANK_DEFER", "1") != "0"  # (A/B switch)
+        ctx_depth = net.ctx_final_depth()
         g = gy.contiguous()
-        offs = net._param_offsets()
         for fn, tag in reversed(run.tape):
             g = fn(g)
             if tag is not None:
@@ -795,13 +842,23 @@ class _UNetFn(torch.autograd.Function):
                     if rb > ra:  # this depth's weight rows of the conditioning bank (the small bias goes out at the end)
                         w0 = offs["bank_weight"][0]
                         hook(flat, w0 + ra * net.mf, w0 + rb * net.mf)
+                if tag == ctx_depth:
+                    # the last CrossAttentionItem has run its backward: the context bank's one weight gradient / un-fold /
+                    # data gradient, at the earliest legal point -- and the context side leaves as ONE bucket (it is its own
+                    # region of the flat buffer; on the per-item path the same region is simply final by now)
+                    if run.ctx_bank is not None:
+                        run.ctx_bank.backward(run)
+                        if hook is not None:
+                            net._ctx_bank_hooked_backwards = getattr(net, "_ctx_bank_hooked_backwards", 0) + 1
+                    if hook is not None:
+                        ca, cb = net.ctx_param_range()
+                        if cb > ca:
+                            hook(flat, ca, cb)
         run.mod_sums.flush()  # (nothing is left when every Modulation belongs to a tagged block)
         if run.wpark is not None:
             run.wpark.flush()
         if defer_bank:
             run.bank_grad_all()
-        if run.ctx_bank is not None:
-            run.ctx_bank.backward(run)
         dfeat = run.conditioning_backward()
         if hook is not None:
             for a, b in net.nonblock_param_ranges():

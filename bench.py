@@ -362,7 +362,7 @@ def extra_legs(model, x, dev):
                           "ms_per_step": round(dt / 50 * 1e3, 3), "ms_per_50_step_sample": round(dt * 1e3, 2)}
     except Exception as e:
         out["sampler"] = {"error": f"{type(e).__name__}: {e}"}
-    # kernel-family A/B on the headline step: the kernel-3 convs and weight gradients run in the Winograd F(2,3) domain
+    # kernel-family A/B on the headline step: the kernel-3 convs and weight gradients run in the Winograd domain (F(2,3) in conv_mm / wgrad_mm, F(4,3) in conv_tile32)
     # on the exact-f32 matrix cores by default (conv_mm / wgrad_mm WN variants: two thirds of the MFMAs, plain fp32);
     #   direct_form_convs   ADP_CONV_WINO=0: the same kernels in the direct form (the round-1 / round-2 arithmetic)
     for key, env, val, what in (("direct_form_convs", "ADP_CONV_WINO", "0", "in the direct form on the f32 matrix cores"),):

@@ -39,7 +39,12 @@ ATTN_SEPARATE_CONTEXT_NORM = True  # Attention: norm(x) for q, norm_context(cont
 SKIP_SCALES_BRANCH = True       # MergeModulate: skip + scale(features) * x_branch
 SKIP_CAT_SCALE = 2 ** -0.5      # MergeCat (SkipCat, use_modulation=False): Conv1x1(cat[skip * scale, x_branch])
 GN_EPS = 1e-5
-LN_EPS = 1e-5
+# Two LayerNorm epsilons, separately switchable: a_unet's Modulation builds its own LayerNorm(elementwise_affine=False) and may
+# carry a DiT-style eps=1e-6 there (a round-4 reviewer's recollection of a_unet 0.0.16 blocks.py; unverifiable offline, ~1e-6
+# in effect), while the attention norms are plain nn.LayerNorm (default 1e-5).  Both stay 1e-5 until tools/pin_a_unet.py can
+# compare with the real package; the product reads the same two names (audio_diffusion_pytorch_amd/unet.A_UNET_SEMANTICS).
+MODULATION_LN_EPS = 1e-5
+ATTENTION_LN_EPS = 1e-5
 
 ITEM_RESNET = "resnet"
 ITEM_MODULATION = "modulation"
@@ -90,7 +95,7 @@ class Modulation(nn.Module):
         ss = self.to_scale_shift(F.silu(features))  # [B, 2C]
         scale, shift = ss.chunk(2, dim=-1)
         xt = x.transpose(1, 2)  # [B, L, C]
-        xn = F.layer_norm(xt, (self.channels,), eps=LN_EPS)
+        xn = F.layer_norm(xt, (self.channels,), eps=MODULATION_LN_EPS)
         if MODULATION_ONE_PLUS_SCALE:
             y = xn * (1 + scale[:, None, :]) + shift[:, None, :]
         else:
@@ -110,8 +115,8 @@ class Attention(nn.Module):
         self.is_cross = context_features is not None
         cf = context_features if self.is_cross else channels
         mid = num_heads * head_features
-        self.norm = nn.LayerNorm(channels, eps=LN_EPS)
-        self.norm_context = nn.LayerNorm(cf, eps=LN_EPS)
+        self.norm = nn.LayerNorm(channels, eps=ATTENTION_LN_EPS)
+        self.norm_context = nn.LayerNorm(cf, eps=ATTENTION_LN_EPS)
         self.to_q = nn.Linear(channels, mid, bias=False)
         self.to_kv = nn.Linear(cf, 2 * mid, bias=False)
         self.to_out = nn.Linear(mid, channels, bias=False)

@@ -47,6 +47,8 @@ def main():
         dp(x[sl].to(dev), noise=noise[sl].to(dev), embedding=emb[sl].to(dev), embedding_mask_proba=0.5,
            batch_mask=mask[sl].to(dev)).backward()
     torch.cuda.synchronize()
+    # config 4's optimisation runs where config 4 runs: the context bank is taken under the data-parallel hook
+    assert dp.unet._ctx_bank_runs == 2 and dp.unet._ctx_bank_hooked_backwards == 2
     worst = 0.0
     for (name, p), q in zip(model.named_parameters(), ref.parameters()):
         assert (p.grad is None) == (q.grad is None), name

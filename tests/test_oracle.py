@@ -208,7 +208,9 @@ def test_a_unet_checkpoint_order_loader(emul):
     assert sorted(order) == sorted(osd.keys())
     assert order.index("blocks.1.items_down.0.gn1.weight") < order.index("blocks.2.down.weight") < \
         order.index("blocks.1.items_up.0.gn1.weight"), "depth 2 nests between depth 1's down and up items"
-    foreign = {f"blocks.2.blocks.{i}.w{i}": osd[k].clone() for i, k in enumerate(order)}
+    def foreign_key(i, k):  # a_unet-style nesting names; the last component is the tensor's role as a_unet spells it
+        return f"blocks.2.blocks.{i}." + ("weights" if k == "time_weights" else k.rsplit(".", 1)[-1])
+    foreign = {foreign_key(i, k): osd[k].clone() for i, k in enumerate(order)}
     keymap = net.load_a_unet_state_dict(foreign)
     assert list(keymap.values()) == order
     x, t = torch.randn(2, 2, 64), torch.tensor([0.3, 0.8])
@@ -219,3 +221,30 @@ def test_a_unet_checkpoint_order_loader(emul):
     wrong[k5] = torch.zeros(3, 3)
     with pytest.raises(ValueError, match="expected"):
         net.load_a_unet_state_dict(wrong)
+    # a GroupNorm's (weight, bias) pair in the other order has the same shapes: refused by the key's last component
+    keys = list(foreign)
+    i = order.index("blocks.0.items_down.0.gn1.weight")
+    swapped = [(k, v) for k, v in foreign.items()]
+    swapped[i], swapped[i + 1] = swapped[i + 1], swapped[i]
+    with pytest.raises(ValueError, match="is a `bias` where"):
+        net.load_a_unet_state_dict(dict(swapped))
+    # the plugin wrappers: Time(Text(CFG(XUNet))) puts the T5 tensors and the fixed-embedding table between the time MLP and
+    # the blocks; components.load_reference_state_dict peels them off
+    from audio_diffusion_pytorch_amd.components import load_reference_state_dict
+    cfg2 = dict(cfg, cross_attentions=[0, 0, 1], embedding_features=12, use_embedding_cfg=True, embedding_max_length=5,
+                use_text_conditioning=True, text_embedder=torch.nn.Identity())
+    torch.manual_seed(4)
+    wrapped = adp.UNetV0(dim=1, **cfg2)
+    src = adp.UNetV0(dim=1, **cfg2)
+    core, order2 = src.net.net, src.net.net.a_unet_key_order()
+    own = core.oracle_named_grads({n: p.detach() for n, p in core.named_parameters()})  # (name mapping only: bank split per item)
+    n_time = sum(1 for k in order2 if k.startswith("time_"))
+    tensors = [(foreign_key(i, k), own[k].clone()) for i, k in enumerate(order2)]
+    ckpt = dict(tensors[:n_time] + [("embedder.transformer.shared.weight", torch.randn(7, 3)),
+                                    ("blocks.0.fixed_embedding.weight", src.net.fixed_embedding.weight.detach().clone())]
+                + tensors[n_time:])
+    keymap = load_reference_state_dict(wrapped, ckpt)
+    assert keymap["blocks.0.fixed_embedding.weight"] == "fixed_embedding.weight"
+    assert keymap["embedder.transformer.shared.weight"].startswith("skipped")
+    for (n, p), (_, q) in zip(wrapped.named_parameters(), src.named_parameters()):
+        assert torch.equal(p, q), n

@@ -42,6 +42,10 @@ def _worker_cfg(rank, world, port, out_dir):
     sl = slice(2 * rank, 2 * rank + 2)
     loss = dp(x[sl], noise=noise[sl], embedding=emb[sl], embedding_mask_proba=0.5, batch_mask=mask[sl])
     loss.backward()
+    # the cross-attention context bank runs UNDER the data-parallel hook (its gradients are their own region of the flat buffer)
+    assert dp.unet._ctx_bank_runs == 1 and dp.unet._ctx_bank_hooked_backwards == 1
+    ca, cb = dp.unet.ctx_param_range()
+    assert cb - ca == 2 * (2 * 12 + 2 * 2 * 8 * 12) and cb == sum(p.numel() for p in dp.unet.parameters())
     torch.save({"grads": {n: p.grad.clone() for n, p in model.named_parameters()},
                 "params": {n: p.detach().clone() for n, p in model.named_parameters()}},
                os.path.join(out_dir, f"rank{rank}.pt"))
