@@ -101,6 +101,9 @@ SIGNATURES = {
     "adp_attn_fwd_ws_bytes": (I, [I, I, I, I, I]),
     "adp_attn_bwd_ws_bytes": (I, [I, I, I, I, I]),
     "adp_attn_bwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P, P]),
+    "adp_probe_copy": (c_int, [P, P, I, P]),
+    "adp_probe_mfma": (I, [I, P, I, P]),
+    "adp_probe_launch": (c_int, [I, P]),
 }
 
 

@@ -277,6 +277,197 @@ def _replay_convblock(model, x):
             "replay_frac": round(gbps / PEAK_HBM_GBPS, 4)}
 
 
+def _read_clocks():
+    """sclk / mclk / power as the driver exposes them right now (sysfs first, rocm-smi as a fallback); best effort."""
+    import glob
+    import re
+    info = {}
+    for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+        try:
+            for key, fn in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk"), ("fclk_mhz", "pp_dpm_fclk")):
+                path = os.path.join(card, fn)
+                if os.path.exists(path):
+                    levels = open(path).read().strip().splitlines()
+                    act = [l for l in levels if l.rstrip().endswith("*")]
+                    mhz = re.findall(r"(\d+)\s*[Mm][Hh]z", (act or levels[-1:])[0]) if levels else []
+                    top = re.findall(r"(\d+)\s*[Mm][Hh]z", levels[-1]) if levels else []
+                    if mhz:
+                        info[key] = int(mhz[0])
+                    if top:
+                        info[key.replace("_mhz", "_max_mhz")] = int(top[0])
+            for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
+                for key, fn in (("power_cap_w", "power1_cap"), ("power_w", "power1_average"), ("power_w", "power1_input")):
+                    path = os.path.join(hw, fn)
+                    if os.path.exists(path) and key not in info:
+                        info[key] = round(int(open(path).read().strip()) / 1e6, 1)
+            if info:
+                info["source"] = card
+                break
+        except (OSError, ValueError, IndexError):
+            continue
+    if not info:
+        try:
+            import subprocess
+            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower", "--json"], capture_output=True,
+                                 text=True, timeout=15).stdout
+            data = json.loads(out[out.index("{"):])
+            card = data[sorted(data)[0]]
+            info = {k: v for k, v in card.items() if any(t in k.lower() for t in ("sclk", "mclk", "fclk", "power"))}
+            info["source"] = "rocm-smi"
+        except Exception as e:
+            info = {"error": f"no clock source readable ({type(e).__name__})"}
+    return info
+
+
+def calibration(dev, busy=None):
+    """What THIS box does on three kernels whose ideal rates are known (csrc/probe.hip), measured in the benchmarked
+    process before the timed window -- so that two bench lines of the same code on two boxes can be told apart from a
+    regression: 16-byte copy GB/s at 256 MB (HBM), register-only exact-f32 MFMA TFLOP/s (matrix pipes x clock), the
+    dependent-launch gap inside a hipGraph (100 empty kernels), and the clocks / power cap the driver reports idle and
+    (`busy`: a callable that queues ~1 s of asynchronous work) under load."""
+    from audio_diffusion_pytorch_amd import _C
+    from audio_diffusion_pytorch_amd._C import ptr
+    out = {}
+
+    def ev_ms(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    try:
+        n = 64 << 20
+        src, dst = torch.randn(n, device=dev), torch.empty(n, device=dev)
+        ms = ev_ms(lambda: _C.call("adp_probe_copy", ptr(src), ptr(dst), n, _C.stream()), 10)
+        out["copy_256MB_gbps"] = round(8 * n / ms / 1e6, 1)
+        del src, dst
+        buf = torch.empty(512 * 256, device=dev)
+        flops = [0]
+
+        def mfma():
+            flops[0] = _C.call_value("adp_probe_mfma", 8000, ptr(buf), buf.numel(), _C.stream())
+        ms = ev_ms(mfma, 5)
+        out["mfma_f32_probe_tflops"] = round(flops[0] / ms / 1e9, 1)
+        out["mfma_f32_probe_frac_of_peak"] = round(flops[0] / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            _C.call("adp_probe_launch", 1, _C.stream())
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(100):
+                _C.call("adp_probe_launch", 1, _C.stream())
+        out["graph_launch_gap_us"] = round(ev_ms(g.replay, 10) * 10.0, 3)  # ms per 100 launches -> us per launch
+        del g
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"
+    out["clocks_idle"] = _read_clocks()
+    if busy is not None:
+        try:
+            busy()                      # asynchronous: the GPU is working while the host reads the clocks
+            time.sleep(0.5)
+            out["clocks_under_load"] = _read_clocks()
+            torch.cuda.synchronize()
+        except Exception as e:
+            out["clocks_under_load"] = {"error": f"{type(e).__name__}: {e}"}
+    out["what"] = ("probes of csrc/probe.hip timed with HIP events in this process before the timed window: 256 MB float4 copy "
+                   "(read + write bytes / time; 6290 GB/s is the best copy this pool has shown), register-only v_mfma_f32_32x32x2 "
+                   f"loop against the {PEAK_F32_MFMA_TFLOPS} TF peak, hipGraph of 100 dependent empty kernels")
+    return out
+
+
+def _dp1_worker() -> None:
+    """Child process of the `dp1` leg: a ONE-rank RCCL group in a process of its own (so that nothing RCCL does can take the
+    bench line down), the data-parallel wrapper with force_collectives=True -- bucketed AVG all-reduces from inside
+    backward on RCCL's stream, exactly the code path of N > 1 -- against the same eager step without the wrapper."""
+    import socket
+    import torch.distributed as dist
+    import audio_diffusion_pytorch_amd as adp
+    from audio_diffusion_pytorch_amd import parallel
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    res = {}
+
+    def leg(model, batch, kw, reps):
+        x = torch.randn(batch, 2, LENGTH, device=dev)
+
+        def zero():
+            for p in model.parameters():
+                p.grad = None
+
+        def plain():
+            zero()
+            model(x, **kw).backward()
+        t_plain = _time(plain, reps, warmup=3)
+        dp = parallel.DataParallel(model, force_collectives=True)
+        sent, orig = [], dp._send
+        dp._send = lambda flat, a, b: (sent.append((a, b)), orig(flat, a, b))[1]
+
+        def step():
+            zero()
+            dp(x, **kw).backward()
+        step()
+        dp._send = orig
+        buckets = [round((b - a) * 4 / 2 ** 20, 1) for a, b in sent]
+        t_dp = _time(step, reps, warmup=3)
+        dp.unet._grad_ready_hook = None
+        t_plain2 = _time(plain, reps, warmup=2)  # (again after the wrapped steps: same clocks / allocator state)
+        t_ref = min(t_plain, t_plain2)
+        return {"ms_per_step": round(t_dp * 1e3, 3), "ms_per_step_without_wrapper": round(t_ref * 1e3, 3),
+                "dp_over_plain": round(t_dp / t_ref, 4), "buckets_mb": buckets, "launch": "eager (both)",
+                "ctx_bank_runs_under_hook": int(getattr(dp.unet, "_ctx_bank_hooked_backwards", 0))}
+
+    try:
+        res["headline"] = leg(build_model(dev), 4, {}, 10)
+        res["headline"]["workload"] = "BASELINE configs[1]: batch 4, [4,2,2**18]"
+    except Exception as e:
+        res["headline"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        torch.manual_seed(0)
+        m4 = adp.DiffusionModel(net_t=adp.UNetV0, in_channels=2, channels=CHANNELS, factors=FACTORS, items=ITEMS,
+                                cross_attentions=[0, 0, 0, 1, 1, 1, 1, 1, 1], embedding_features=768, attention_heads=8,
+                                attention_features=64).to(dev)
+        res["config4"] = leg(m4, 1, dict(embedding=torch.randn(1, 64, 768, device=dev)), 10)
+        res["config4"]["workload"] = ("BASELINE configs[3] layout (cross attention at depths 3-8, embedding [1,64,768]) at the "
+                                      "per-GPU batch of batch 8 over 8 GPUs: [1,2,2**18]")
+    except Exception as e:
+        res["config4"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.synchronize()
+    print("DP1_WORKER " + json.dumps(res), flush=True)
+    dist.destroy_process_group()
+
+
+def dp1_leg(timeout: float = 240.0):
+    """The multi-GPU code path on the one GPU a box has: see _dp1_worker.  backend nccl == RCCL."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--dp1-worker"], capture_output=True, text=True,
+                             timeout=timeout)
+        for line in out.stdout.splitlines():
+            if line.startswith("DP1_WORKER "):
+                res = json.loads(line[len("DP1_WORKER "):])
+                res["what"] = ("parallel.DataParallel(force_collectives=True) on a one-rank RCCL group in a child process: "
+                               "the bucketed ReduceOp.AVG all-reduces issued from inside backward as at N > 1, eager launches, "
+                               "against the same eager step without the wrapper (median-free mean of 10 steps each)")
+                return res
+        return {"error": "dp1 worker printed no result", "rc": out.returncode, "stderr_tail": out.stderr[-600:]}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def _graphed(step, zero):
     """Captures `step` in a hipGraph (after two eager warm-ups on a side stream); returns the replay callable."""
     side = torch.cuda.Stream()
@@ -415,6 +606,8 @@ def extra_legs(model, x, dev):
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":
         return _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
+    if len(sys.argv) >= 2 and sys.argv[1] == "--dp1-worker":
+        return _dp1_worker()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -430,6 +623,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch-1 / sampler / attention legs")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the calibration probes and the 1 s pre-warm")
+    ap.add_argument("--no-dp1", action="store_true", help="skip the one-rank RCCL data-parallel leg")
     args = ap.parse_args()
 
     from audio_diffusion_pytorch_amd import parallel
@@ -488,6 +683,18 @@ def main():
 
     step = graph.replay if graph is not None else eager_step
 
+    calib = None
+    if world == 1 and not args.no_calibration:
+        # >= 1 s of the step itself before anything is timed (clocks and power management settle under THIS load); the
+        # calibration probes run first, and the clocks are read while the pre-warm replays are queued
+        def busy():
+            for _ in range(80):
+                step()
+        try:
+            calib = calibration(dev, busy)
+        except Exception as e:
+            calib = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -505,6 +712,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
+    windows = [dt / args.steps * 1e3]
+    if world == 1 and not args.no_calibration:  # two more windows of the same K steps: is the first one representative?
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            windows.append((time.perf_counter() - t1) / args.steps * 1e3)
     ms = dt / args.steps * 1e3
     value = world * args.steps / dt  # denoising steps (U-Net fwd+bwd evaluations on a batch) per second, whole job
     line = {
@@ -522,6 +738,11 @@ def main():
                    "collective_world_size": (dist.get_world_size() if world > 1 else 1),
                    "optimizer": "none (the metric is fwd+bwd; gradients for all 176M parameters are produced)"},
     }
+    if len(windows) > 1:
+        line["ms_per_step_windows"] = [round(w, 3) for w in windows]
+        line["ms_per_step_best_of_3"] = round(min(windows), 3)
+    if calib is not None:
+        line["calibration"] = calib
     if world > 1 and args.dp_overlap:
         # outside the timed region, every rank in lockstep: how much of the gradient all-reduce hides under backward
         # (opt-in: three more untimed phases with collectives -- kept out of the default multi-GPU run)
@@ -547,6 +768,8 @@ def main():
             line["roofline"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_extras:
         line.update(extra_legs(model, x, dev))
+    if rank == 0 and world == 1 and not args.no_dp1:
+        line["dp1"] = dp1_leg()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.batch)
     if rank == 0:

@@ -342,6 +342,20 @@ int adp_copy2d(const float* src, int64_t src_stride, float* dst, int64_t dst_str
 int adp_unshuffle(const float* x, int64_t rows, int64_t L, int64_t f, float* out, void* stream);
 int adp_pool_sum(const float* x, int64_t rows, int64_t Lout, int64_t f, const float* res, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Calibration probes (csrc/probe.hip).  Measurement infrastructure: bench.py times them in the benchmarked process
+ * before the timed window so that the line says how fast THIS box streams, multiplies and launches (the reference has
+ * no counterpart; GPU boxes of one pool differ by up to 12 % on the whole step).
+ *   adp_probe_copy   : dst[i] = src[i], n floats (n % 4 == 0, 16-byte aligned), 16-byte accesses  -> HBM GB/s
+ *   adp_probe_mfma   : 512 workgroups x 4 waves, each `iters` rounds of four independent v_mfma_f32_32x32x2_f32 with
+ *                      register operands; out receives one float per thread (out_elems >= 512 * 256); returns the
+ *                      launch's flops (negative: error code)                                        -> f32 matrix TFLOP/s
+ *   adp_probe_launch : an empty kernel of `workgroups` single-wave workgroups                       -> launch gap
+ * ------------------------------------------------------------------------------------------ */
+int adp_probe_copy(const float* src, float* dst, int64_t n, void* stream);
+int64_t adp_probe_mfma(int64_t iters, float* out, int64_t out_elems, void* stream);
+int adp_probe_launch(int64_t workgroups, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1050,3 +1050,24 @@ def test_gn_stats_act(dev, B, C, L, G):
     assert rel_err(act, ref_gn_silu(x, G, gamma, beta)) < TOL
     ref_stats = ops.gn_stats(x.to(dev), G)
     assert rel_err(stats, ref_stats) < 1e-6
+
+
+def test_calibration_probes(dev):
+    """csrc/probe.hip (bench.py's `calibration` object): the streaming copy copies, the MFMA probe reports the flops of its
+    launch and leaves the value its four accumulator chains add up to, the empty launch succeeds; argument errors are codes."""
+    x = rnd(4096, seed=1).to(dev)
+    y = torch.zeros_like(x)
+    _C.call("adp_probe_copy", _C.ptr(x), _C.ptr(y), x.numel(), _C.stream())
+    assert torch.equal(y.cpu(), x.cpu())
+    out = torch.zeros(512 * 256).to(dev)
+    iters = 2
+    flops = _C.call_value("adp_probe_mfma", iters, _C.ptr(out), out.numel(), _C.stream())
+    assert flops == 512 * 4 * iters * 4 * 4096
+    # A[i][k] = lane * 1e-3 with k = lane >> 5, B likewise 2e-3: every accumulator element (i, j) sums over k = 0, 1
+    lane = torch.arange(64, dtype=torch.float64)
+    a, b = (lane * 1e-3).view(2, 32), (lane * 2e-3).view(2, 32)   # [k][i], [k][j]
+    tile = torch.einsum("ki,kj->ij", a, b) * iters                  # one accumulator tile after `iters` MFMAs
+    assert abs(out.cpu().double().sum().item() / (512 * 4 * 4) - tile.sum().item()) < 1e-3 * tile.sum().item()
+    _C.call("adp_probe_launch", 3, _C.stream())
+    assert _C.lib().adp_probe_copy(None, None, 4, 0) == -5 and _C.lib().adp_probe_launch(0, 0) == -1
+    assert _C.lib().adp_probe_mfma(1, _C.ptr(out), 16, 0) == -1
