@@ -44,7 +44,8 @@ class CtxBank:
             if context.is_cuda and torch.cuda.is_current_stream_capturing():
                 return None  # (the pointer tables are uploaded outside a capture; this call takes the per-item path)
             offs = net._param_offsets()
-            names = {id(q): n for n, q in net.named_parameters()}
+            net._named_params()
+            names = net._pname_cache
             tab = torch.tensor([[p.to_kv.weight.data_ptr() for p in items], [p.norm_context.weight.data_ptr() for p in items],
                                 [p.norm_context.bias.data_ptr() for p in items]], dtype=torch.int64).to(dev)
             dw_off = torch.tensor([offs[names[id(p.to_kv.weight)]][0] for p in items], dtype=torch.int64).to(dev)

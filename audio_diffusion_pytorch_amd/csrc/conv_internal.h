@@ -27,6 +27,12 @@ int adp_wgrad_mm(const adp_wgrad_desc& d, void* stream);
 int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, float* dw, float* dbias, int accumulate,
                      void* stream);
 
+// conv_mm4.hip: Winograd F(4,3) variant of the same block for the wide kernel-3 'same' convs without prologue (>= 128 channels,
+// >= 200 blocks of 32 rows x 128 positions): MMA waves split the six Winograd planes and the chunk's channels
+bool adp_conv_mm4_eligible(const adp_conv_desc& d);
+int adp_conv_mm4(const adp_conv_desc& d, void* stream);
+int64_t adp_conv_mm4_gn_entries(const adp_conv_desc& d);  // two entries (row pairs) per row quad and 128-position tile
+
 // conv_tile.hip: barrier-free wave-tile kernel (wave-private LDS tile, Winograd F(2,3)) for the HBM-bound 32 -> 32 channel
 // kernel-3 ConvBlock convs and their data gradients (depth 1)
 bool adp_conv_tile_eligible(const adp_conv_desc& d);

@@ -1,0 +1,357 @@
+// Winograd F(4,3) implicit-GEMM Conv1d for the wide ResnetItem ConvBlock convs and their data gradients
+// (kernel 3, stride 1, 'same' padding, >= 128 channels, SiLU(GroupNorm(.)) already materialised by the statistics' second
+// stage; /root/reference/audio_diffusion_pytorch/components.py:89).  Same machine model as
+// conv_mm_impl.h -- wave-specialised block, loaders that only copy, exact-f32 v_mfma_f32_32x32x2_f32 -- with one change of
+// tile economy:
+//   * column l31 of an MMA tile is an output QUAD (positions n0 + 4*l31 ..+3), so a 32 x 32 MFMA tile covers 32 rows x 128
+//     positions, and the six Winograd planes  P_p = sum_c U_p[m][c] * V_p[c][quad]  replace the 12 tap x position-tile
+//     products of the direct form (F(2,3): 8): 6 MFMAs per channel pair and 128 positions = HALF the direct form's matrix work,
+//     three quarters of F(2,3)'s.
+//   * the PLANES are what the MMA waves of a block split (next to the channels of a staged chunk): wave = (plane group pg,
+//     K group kg); plane group 0 owns planes 0-2, group 1 planes 3-5.  Every wave reads the same untransformed LDS tiles --
+//     three taps and a 16-byte input quad plus one halo value (its left / right neighbour through a DPP lane shift, the
+//     tile edge through a broadcast read) -- and forms only ITS three planes of
+//         U' = (g0, g0+g1+g2, g0-g1+g2 | g0+2g1+4g2, g0-2g1+4g2, g2)           (G without its constants)
+//         V  = (4d0-5d2+d4, t1+t2, t1-t2 | t3+2t4, t3-2t4, 4d1-5d3+d5)         t1 = d4-4d2, t2 = d3-4d1, t3 = d4-d2, t4 = d3-d1
+//     with 9 VALU ops per 3 MFMAs, in the shadow of the 64-cycle MFMAs (tools/probe/alu_probe: ~5 issue slots per MFMA are free).
+//     Three accumulator tiles per wave (48 registers) instead of four.
+//   * the planes and K groups meet in LDS once, after the K loop: every wave sums two accumulator rows of all 24 partial tiles
+//     in a fixed order, applies the plane constants (1/4, -1/6, -1/6, 1/24, 1/24, 1) and A^T, and stores 16 bytes per lane:
+//         y0 = p0+p1+p2+p3+p4   y1 = (p1-p2) + 2(p3-p4)   y2 = (p1+p2) + 4(p3+p4)   y3 = (p1-p2) + 8(p3-p4) + p5
+//   * a block is 32 rows x 128 positions x all channels: 8 MMA waves (2 per SIMD) + 4 loader waves, 256 blocks for the
+//     [4, 1024, 256] layers of depth 7 -- one resident generation on 256 CUs.
+// fp32 throughout; error against fp64 ~1e-6 of the output's max norm (F(4,3)'s constants; tests/test_kernels.py).
+#include <stdlib.h>
+#include "adp_rt.h"
+#include "adp.h"
+#include "conv_internal.h"
+
+namespace {
+
+constexpr int M4_BM = 32, M4_BN = 128, M4_KT = 3;
+constexpr int M4_NKG = 4, M4_NPG = 2, M4_NMMA = M4_NKG * M4_NPG, M4_NLD = 4;
+constexpr int M4_NLT = M4_NLD * 64;
+constexpr int M4_XSP = M4_BN + 8, M4_XQ = M4_XSP / 4;         // X row: positions n0-4 .. n0+131
+constexpr int M4_RED = M4_NKG * 6 * 1024;                     // 24 parked partial tiles
+
+// BKT: channels per staged chunk (32, or 64: half the barriers per K, 16 channels per K group and chunk)
+template <bool TR, int PD, int BKT>
+__global__ __launch_bounds__((M4_NMMA + M4_NLD) * 64) void conv_mm4_kernel(adp_conv_desc d) {
+  constexpr int M4_QK = BKT * M4_KT;                            // floats of a forward weight row per chunk
+  constexpr int M4_AROWS = TR ? BKT : M4_BM;
+  constexpr int M4_AS = (TR ? M4_BM * M4_KT : M4_QK) + 4;       // A row stride (4 mod 8 dwords)
+  constexpr int M4_AQ = (TR ? M4_BM * M4_KT : M4_QK) / 4;       // float4 per A row
+  constexpr int M4_A_ELEMS = M4_AROWS * M4_AS, M4_X_ELEMS = BKT * M4_XSP;
+  constexpr int M4_NA4 = (M4_AROWS * M4_AQ + M4_NLT - 1) / M4_NLT, M4_NX4 = (BKT * M4_XQ + M4_NLT - 1) / M4_NLT;
+  constexpr int M4_STAGE = 2 * (M4_A_ELEMS + M4_X_ELEMS);
+  constexpr int M4_SM = M4_RED > M4_STAGE ? M4_RED : M4_STAGE;
+  constexpr int CPK = BKT / M4_NKG;                             // channels of a chunk one K group multiplies (8 or 16)
+  __shared__ __attribute__((aligned(16))) float smem[M4_SM];
+  constexpr int KT = M4_KT, AS = M4_AS, XSP = M4_XSP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int M = (int)d.M, R = (int)d.R, L = (int)d.Lin, N = (int)d.N;
+
+  // ---- XCD-aware decode of the 1-D grid (each XCD gets a contiguous range of weight row tiles)
+  int id = blockIdx.x;
+  const int total = gridDim.x;
+  if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+  const int ntn = (N + M4_BN - 1) / M4_BN, per_m = ntn * (int)d.B;
+  const int mt = id / per_m, rem = id - mt * per_m;
+  const int b = rem / ntn, nt = rem - b * ntn;
+  const int m0 = mt * M4_BM, n0 = nt * M4_BN;
+  const int nchunks = R / BKT;
+  const int nrounds = ((nchunks + PD - 1) / PD) * PD;
+
+  if (wave >= M4_NMMA) {
+    // =========================== loader waves (pure copies: global -> registers -> LDS) ===========================
+    const int lt = tid - M4_NMMA * 64;
+    const float* xb = d.x + (int64_t)b * R * L;
+    const float* wbase = TR ? d.w + (int64_t)m0 * KT : d.w + (int64_t)m0 * R * KT;
+    int a_src[M4_NA4], a_dst[M4_NA4];
+#pragma unroll
+    for (int i = 0; i < M4_NA4; ++i) {
+      const int e = (lt + i * M4_NLT) % (M4_AROWS * M4_AQ);
+      const int row = e / M4_AQ, qq = e - row * M4_AQ;
+      a_dst[i] = row * AS + 4 * qq;
+      a_src[i] = TR ? row * M * KT + 4 * qq : row * R * KT + 4 * qq;
+    }
+    int x_src[M4_NX4], x_dst[M4_NX4];
+    bool x_ok[M4_NX4];
+#pragma unroll
+    for (int i = 0; i < M4_NX4; ++i) {
+      const int e = (lt + i * M4_NLT) % (BKT * M4_XQ);
+      const int rl = e / M4_XQ, pq = e - rl * M4_XQ;
+      const int u = n0 - 4 + 4 * pq;
+      x_dst[i] = rl * XSP + 4 * pq;
+      x_ok[i] = (u >= 0 && u < L);  // L % 4 == 0: a quad is entirely inside or outside the row
+      x_src[i] = rl * L + (x_ok[i] ? u : 0);
+    }
+    f32x4 ra[PD][M4_NA4], rx[PD][M4_NX4];
+    auto load_chunk = [&](f32x4 (&a)[M4_NA4], f32x4 (&x)[M4_NX4], int chunk) {
+      const int rn = (chunk < nchunks ? chunk : nchunks - 1) * BKT;  // (the tail re-reads the last chunk: never consumed)
+      const float* wp = TR ? wbase + (int64_t)rn * M * KT : wbase + rn * KT;
+#pragma unroll
+      for (int i = 0; i < M4_NA4; ++i) a[i] = *reinterpret_cast<const f32x4*>(wp + a_src[i]);
+      const float* xp = xb + (int64_t)rn * L;
+#pragma unroll
+      for (int i = 0; i < M4_NX4; ++i) x[i] = *reinterpret_cast<const f32x4*>(xp + x_src[i]);
+    };
+    auto store_chunk = [&](const f32x4 (&a)[M4_NA4], const f32x4 (&x)[M4_NX4], int chunk) {
+      float* Ab = smem + (chunk & 1) * (M4_A_ELEMS + M4_X_ELEMS);
+      float* Xb = Ab + M4_A_ELEMS;
+#pragma unroll
+      for (int i = 0; i < M4_NA4; ++i) *reinterpret_cast<f32x4*>(Ab + a_dst[i]) = a[i];
+#pragma unroll
+      for (int i = 0; i < M4_NX4; ++i) {
+        f32x4 v = x[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = x_ok[i] ? v[j] : 0.0f;  // zero padding
+        *reinterpret_cast<f32x4*>(Xb + x_dst[i]) = v;
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < PD; ++s) load_chunk(ra[s], rx[s], s);
+    // Hazard note (as conv_mm): the store of chunk c goes to LDS[c & 1], last read by the MFMAs of chunk c-2; every MMA wave
+    // finished those before it arrived at barrier B_{c-1}, which this wave passed before starting iteration c.
+    for (int c0 = 0; c0 < nrounds; c0 += PD) {
+#pragma unroll
+      for (int s = 0; s < PD; ++s) {
+        store_chunk(ra[s], rx[s], c0 + s);
+        load_chunk(ra[s], rx[s], c0 + s + PD);
+        __syncthreads();  // B_c
+      }
+    }
+    __syncthreads();  // staging buffers free
+    __syncthreads();  // partial tiles parked
+    return;
+  }
+
+  // =========================== MMA waves ===========================
+  const int pg = wave & 1, kg = wave >> 1;
+  f32x16 acc[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+
+  // epilogue operands of the two accumulator rows this wave finishes, fetched NOW (their latency lies under the K loop)
+  const int nq = n0 + 4 * l31;
+  f32x4 pre_res[2];
+  float pre_bias[2], pre_scale[2];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int r = 2 * wave + rr;
+    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    const int mc = m < M ? m : M - 1;
+    pre_bias[rr] = d.bias ? d.bias[mc] : 0.0f;
+    pre_scale[rr] = d.e_scale ? d.e_scale[b * (d.e_bstride ? d.e_bstride : M) + mc] : 1.0f;
+    pre_res[rr] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (d.res && m < M && nq < N) pre_res[rr] = *reinterpret_cast<const f32x4*>(d.res + ((int64_t)b * M + m) * N + nq);
+  }
+
+  const int xfrag = 4 * hi * XSP + 4 * l31 + 4;                         // + (ci + cc) * XSP: the lane's input quad d1..d4
+  const int hfrag = 4 * hi * XSP + (pg == 0 ? 3 : 4 + M4_BN);           // tile-edge halo (d0 of quad 0 / d5 of quad 31)
+  const int afrag = TR ? 4 * hi * AS + l31 * KT : l31 * AS + 4 * hi * KT;
+  const bool edge = pg == 0 ? (l31 == 0) : (l31 == 31);
+
+  for (int c = 0; c < nrounds; ++c) {
+    __syncthreads();  // B_c: chunk c is in LDS[c & 1]
+    if (c < nchunks) {
+      const float* Ab = smem + (c & 1) * (M4_A_ELEMS + M4_X_ELEMS);
+      const float* Xb = Ab + M4_A_ELEMS;
+#pragma unroll
+      for (int sub = 0; sub < CPK / 8; ++sub) {
+      const int ci = kg * CPK + sub * 8;
+      float av[4 * KT];  // av[cc * 3 + t] = tap t of channel ci + cc + 4 * hi for this lane's output row
+      if (!TR) {
+        const float* ap = Ab + afrag + ci * KT;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(ap + 4 * j);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) av[4 * j + k] = q[k];
+        }
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+          for (int t = 0; t < KT; ++t) av[cc * KT + t] = Ab[afrag + (ci + cc) * AS + (KT - 1 - t)];
+      }
+      f32x4 qx[4];
+      float hx[4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        qx[cc] = *reinterpret_cast<const f32x4*>(Xb + xfrag + (ci + cc) * XSP);
+        hx[cc] = Xb[hfrag + (ci + cc) * XSP];  // one address per half-wave: a broadcast read
+      }
+      if (pg == 0) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const float d1 = qx[cc][0], d2 = qx[cc][1], d3 = qx[cc][2], d4 = qx[cc][3];
+          const float nb = adp_lane_prev(0.0f, d4);         // the left neighbour quad's last input
+          const float d0 = edge ? hx[cc] : nb;
+          const float g0 = av[cc * KT], g1 = av[cc * KT + 1], g2 = av[cc * KT + 2];
+          const float t1 = fmaf(-4.0f, d2, d4), t2 = fmaf(-4.0f, d1, d3);
+          const float gs = g0 + g2;
+          acc[0] = adp_mfma32(g0, fmaf(4.0f, d0, fmaf(-5.0f, d2, d4)), acc[0]);
+          acc[1] = adp_mfma32(gs + g1, t1 + t2, acc[1]);
+          acc[2] = adp_mfma32(gs - g1, t1 - t2, acc[2]);
+        }
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const float d1 = qx[cc][0], d2 = qx[cc][1], d3 = qx[cc][2], d4 = qx[cc][3];
+          const float nb = adp_lane_next(0.0f, d1);         // the right neighbour quad's first input
+          const float d5 = edge ? hx[cc] : nb;
+          const float g0 = av[cc * KT], g1 = av[cc * KT + 1], g2 = av[cc * KT + 2];
+          const float t3 = d4 - d2, t4 = d3 - d1;
+          const float gq = fmaf(4.0f, g2, g0);
+          acc[0] = adp_mfma32(fmaf(2.0f, g1, gq), fmaf(2.0f, t4, t3), acc[0]);
+          acc[1] = adp_mfma32(fmaf(-2.0f, g1, gq), fmaf(-2.0f, t4, t3), acc[1]);
+          acc[2] = adp_mfma32(g2, fmaf(4.0f, d1, fmaf(-5.0f, d3, d5)), acc[2]);
+        }
+      }
+      }
+    }
+  }
+  __syncthreads();  // the staging buffers are free
+
+  // ---- plane / K-group exchange through LDS: tile (kg, plane P) at smem[(kg * 6 + P) * 1024 + r * 64 + lane]
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    float* rp = smem + (kg * 6 + pg * 3 + p) * 1024 + lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rp[r * 64] = acc[p][r];
+  }
+  __syncthreads();
+
+  // ---- output transform + epilogue: this wave finishes accumulator rows 2 * wave, 2 * wave + 1 (both halves of a row-quad pair)
+  const bool nok = nq < N;  // N % 4 == 0: a quad is inside or outside
+  float vfin[2][4];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int r = 2 * wave + rr;
+    float s[6];
+#pragma unroll
+    for (int P = 0; P < 6; ++P) {
+      float v = 0.0f;
+#pragma unroll
+      for (int g = 0; g < M4_NKG; ++g) v += smem[(g * 6 + P) * 1024 + r * 64 + lane];  // fixed order: deterministic
+      s[P] = v;
+    }
+    const float p0 = 0.25f * s[0], p1 = s[1] * (-1.0f / 6.0f), p2 = s[2] * (-1.0f / 6.0f);
+    const float p3 = s[3] * (1.0f / 24.0f), p4 = s[4] * (1.0f / 24.0f), p5 = s[5];
+    const float a12 = p1 + p2, d12 = p1 - p2, a34 = p3 + p4, d34 = p3 - p4;
+    f32x4 y;
+    y[0] = p0 + a12 + a34;
+    y[1] = fmaf(2.0f, d34, d12);
+    y[2] = fmaf(4.0f, a34, a12);
+    y[3] = fmaf(8.0f, d34, d12) + p5;
+    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    const bool ok = (m < M) && nok;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vfin[rr][k] = 0.0f;
+    if (!ok) continue;
+    const int64_t o = ((int64_t)b * M + m) * N + nq;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[k] += pre_bias[rr];
+    if (d.out_pre) *reinterpret_cast<f32x4*>(d.out_pre + o) = y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[k] = fmaf(y[k], pre_scale[rr], pre_res[rr][k]);
+    *reinterpret_cast<f32x4*>(d.out + o) = y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vfin[rr][k] = y[k];
+  }
+
+  // ---- GroupNorm partial statistics of the tile just stored: one (mean, M2, count) entry per (half of a row quad = the two
+  // rows this wave finished) x (128-position tile); the consumer Chan-combines the entries whatever their counts
+  if (d.gn_part != nullptr && n0 < N) {
+    const int cntv = (N - n0) < M4_BN ? (N - n0) : M4_BN;
+    const float fcnt = 2.0f * (float)cntv;
+    float sv = 0.0f;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sv += vfin[rr][k];
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) sv += __shfl_xor(sv, o, 64);
+    const float mean = sv / fcnt;
+    float qv = 0.0f;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dv = nok ? vfin[rr][k] - mean : 0.0f;
+        qv = fmaf(dv, dv, qv);
+      }
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) qv += __shfl_xor(qv, o, 64);
+    const int r = 2 * wave;
+    const int m = m0 + 8 * (r >> 2) + 4 * hi;  // first channel of the row quad
+    if (l31 == 0 && m < M) {
+      float* e = d.gn_part + (((int64_t)b * (M / 4) + (m >> 2)) * (2 * ntn) + 2 * nt + (wave & 1)) * 3;
+      e[0] = mean;
+      e[1] = qv;
+      e[2] = fcnt;
+    }
+  }
+}
+
+int64_t m4_min_blocks() {
+  const char* e = getenv("ADP_MM4_MIN_BLOCKS");  // (the tests reach this block with small problems through it)
+  return e ? atoll(e) : 200;
+}
+
+}  // namespace
+
+// ADP_CONV_WINO4 (read per call): unset / "1" = this kernel for every eligible conv; "0" = conv_mm's F(2,3) variant (A/B, tests)
+bool adp_conv_mm4_eligible(const adp_conv_desc& d) {
+  if (!adp_winograd_enabled()) return false;
+  const char* e = getenv("ADP_CONV_WINO4");
+  if (e && e[0] == '0') return false;
+  if (d.KT != 3 || d.stride != 1 || d.dil != 1 || d.pad != 1 || d.up != 1 || d.R1 != d.R || d.x2) return false;
+  if (d.prologue != 0 || d.store != 0) return false;
+  if (d.N != d.Lin || d.N % 4 != 0) return false;
+  const char* mr = getenv("ADP_WINO4_MIN_R");
+  // (round 5, whole step at batch 4 on one box: from 128 channels 12.22 ms, from 512 12.15 -- the short-K layers of depths 3-4
+  //  keep conv_mm's wide-N F(2,3) blocks, whose per-block skeleton is lighter)
+  if (d.R < (mr ? atoll(mr) : 512) || d.R % 32 != 0 || d.M % M4_BM != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.w) | reinterpret_cast<uintptr_t>(d.out) |
+       reinterpret_cast<uintptr_t>(d.res) | reinterpret_cast<uintptr_t>(d.out_pre)) & 15)
+    return false;
+  if (d.B * d.R * d.Lin >= (int64_t)1 << 31 || d.M * d.R * d.KT >= (int64_t)1 << 31) return false;
+  // one block per CU and more: below that the 64-position blocks of conv_mm (with their K split at batch 1) fill the chip better
+  return (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B >= m4_min_blocks();
+}
+
+int64_t adp_conv_mm4_gn_entries(const adp_conv_desc& d) { return 2 * adp_cdiv(d.N, M4_BN); }
+
+int adp_conv_mm4(const adp_conv_desc& d, void* stream) {
+  const int64_t blocks = (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B;
+  const dim3 block((M4_NMMA + M4_NLD) * 64);
+  // 64-channel chunks (24 MFMAs per wave and barrier instead of 12) unless ADP_MM4_BKT=32: step 12.15 -> 12.09 ms
+  const char* e = getenv("ADP_MM4_BKT");
+  const int bkt = (e ? atoi(e) : 64) == 64 && d.R % 64 == 0 ? 64 : 32;
+  if (bkt == 64) {
+    const char* p = getenv("ADP_MM4_PD");
+    const int pd = p ? atoi(p) : 1;
+    if (pd == 2 && d.R / 64 >= 4) {
+      if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 2, 64>), dim3((unsigned)blocks), block, stream, d);
+      else ADP_LAUNCH((conv_mm4_kernel<false, 2, 64>), dim3((unsigned)blocks), block, stream, d);
+      return ADP_LAUNCH_OK();
+    }
+    if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64>), dim3((unsigned)blocks), block, stream, d);
+    else ADP_LAUNCH((conv_mm4_kernel<false, 1, 64>), dim3((unsigned)blocks), block, stream, d);
+    return ADP_LAUNCH_OK();
+  }
+  const bool pd2 = d.R / 32 >= 4;
+  if (d.transposed) {
+    if (pd2) ADP_LAUNCH((conv_mm4_kernel<true, 2, 32>), dim3((unsigned)blocks), block, stream, d);
+    else ADP_LAUNCH((conv_mm4_kernel<true, 1, 32>), dim3((unsigned)blocks), block, stream, d);
+  } else {
+    if (pd2) ADP_LAUNCH((conv_mm4_kernel<false, 2, 32>), dim3((unsigned)blocks), block, stream, d);
+    else ADP_LAUNCH((conv_mm4_kernel<false, 1, 32>), dim3((unsigned)blocks), block, stream, d);
+  }
+  return ADP_LAUNCH_OK();
+}

@@ -83,7 +83,15 @@ constexpr int WG_NLD = 4;  // loader waves per block
 // transforms are a handful of VALU adds on the fragments the lane has read anyway, issued in the shadow of the
 // 64-cycle MFMAs; G^T (with its halves) is applied once to the accumulators at the end:
 //     dw0 = P0 + (P1+P2)/2     dw1 = (P1-P2)/2     dw2 = (P1+P2)/2 + P3      (P3 is accumulated with +e1, so: - P3)
-template <int BM, int KT, int S, int UP, int PRO, int PD, bool WN = false>
+//
+// W4 = true (with WN): the same in the F(4,3) domain -- per output QUAD n = (p .. p+3) with e = dy[p .. p+3] and d = x[p-1 .. p+4]
+//     dw[0..2] += G^T [ (A e) * (B^T d) ]      A e   = (e0, e0+e1+e2+e3, e0-e1+e2-e3, e0+2e1+4e2+8e3, e0-2e1+4e2-8e3, e3)
+//                                               B^T d = (4d0-5d2+d4, t1+t2, t1-t2, t3+2t4, t3-2t4, 4d1-5d3+d5)
+// (t1 = d4-4d2, t2 = d3-4d1, t3 = d4-d2, t4 = d3-d1): SIX rank-1 updates per four positions where F(2,3) spends eight and the
+// direct form twelve; six accumulator tiles; G^T with its constants once at the end:
+//     dw0 = P0/4 - (P1+P2)/6 + (P3+P4)/24     dw1 = (P2-P1)/6 + (P3-P4)/12     dw2 = -(P1+P2)/6 + (P3+P4)/6 + P5
+// 21 VALU ops per 6 MFMAs on fragments the lane reads anyway (the F(2,3) form: 7 per 8); fp32 error ~1e-6 of the max norm.
+template <int BM, int KT, int S, int UP, int PRO, int PD, bool WN = false, bool W4 = false>
 __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NLD) * 64) void wgrad_mm_kernel(
     adp_wgrad_desc d_in, int CPB, int CPS, int nsplit, adp_wg_items items, int nitems) {
   // nitems > 1: `nitems` weight gradients of ONE shape in this launch (adp_conv1d_wgrad_batch): blockIdx.x = item * nsplit + split,
@@ -104,6 +112,7 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
     d.ws = items.ws[item];
   }
   static_assert(!WN || (KT == 3 && S == 1), "Winograd F(2,3): kernel 3, stride 1 (any upsample factor)");
+  static_assert(!W4 || WN, "F(4,3) is a variant of the Winograd form");
   constexpr int BR = BM, BKN = WG_BKN, NKG = (BM == 64 ? 2 : 4), PPW = BKN / NKG;
   constexpr int NQR = BR / 32, NQ = (BM / 32) * NQR, NMMA = NQ * NKG, NLT = WG_NLD * 64;
   constexpr int PAD = (KT - 1) / 2;
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
   // =========================== MMA waves ===========================
   const int quad = wave % NQ, kg = wave / NQ;
   const int wm0 = (quad / NQR) * 32, wr0 = (quad % NQR) * 32;
-  constexpr int NACC = WN ? 4 : KT;
+  constexpr int NACC = W4 ? 6 : (WN ? 4 : KT);
   f32x16 acc[NACC];
 #pragma unroll
   for (int t = 0; t < NACC; ++t)
@@ -294,7 +303,21 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
 #pragma unroll
             for (int j = 0; j < 4; ++j) xq[4 + j] = v[j];
           }
-          if constexpr (WN) {
+          if constexpr (W4) {
+            // xq[i] = x[base - 4 + i]: the lane's quad = positions base .. base+3 with d = xq[3..8]; the MFMA K pair is (this
+            // half-wave's quad, the other half-wave's quad)
+            const float e0 = dq[0], e1 = dq[1], e2 = dq[2], e3 = dq[3];
+            const float d0 = xq[3], d1 = xq[4], d2 = xq[5], d3 = xq[6], d4 = xq[7], d5 = xq[8];
+            const float s02 = e0 + e2, s13 = e1 + e3;
+            const float et = fmaf(4.0f, e2, e0), ev = fmaf(4.0f, e3, e1);
+            const float t1 = fmaf(-4.0f, d2, d4), t2 = fmaf(-4.0f, d1, d3), t3 = d4 - d2, t4 = d3 - d1;
+            acc[0] = adp_mfma32(e0, fmaf(4.0f, d0, fmaf(-5.0f, d2, d4)), acc[0]);
+            acc[1] = adp_mfma32(s02 + s13, t1 + t2, acc[1]);
+            acc[2] = adp_mfma32(s02 - s13, t1 - t2, acc[2]);
+            acc[3] = adp_mfma32(fmaf(2.0f, ev, et), fmaf(2.0f, t4, t3), acc[3]);
+            acc[4] = adp_mfma32(fmaf(-2.0f, ev, et), fmaf(-2.0f, t4, t3), acc[4]);
+            acc[5] = adp_mfma32(e3, fmaf(4.0f, d1, fmaf(-5.0f, d3, d5)), acc[5]);
+          } else if constexpr (WN) {
             // xq[i] = x[base - 4 + i]: pair 0 = positions (base, base+1) with d = xq[3..6], pair 1 = (base+2, base+3)
             // with d = xq[5..8]; the MFMA K pair is (this half-wave's pair, the other half-wave's pair)
 #pragma unroll
@@ -329,7 +352,16 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
     }
   }
   __syncthreads();
-  if constexpr (WN) {  // G^T: planes -> taps (linear, so applied to this K group's partial sums)
+  if constexpr (W4) {  // G^T of F(4,3): six planes -> three taps (linear, so applied to this K group's partial sums)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p0 = acc[0][r], p1 = acc[1][r], p2 = acc[2][r], p3 = acc[3][r], p4 = acc[4][r], p5 = acc[5][r];
+      const float a12 = (p1 + p2) * (-1.0f / 6.0f), a34 = p3 + p4;
+      acc[0][r] = fmaf(0.25f, p0, fmaf(1.0f / 24.0f, a34, a12));
+      acc[1][r] = fmaf(1.0f / 6.0f, p2 - p1, (1.0f / 12.0f) * (p3 - p4));
+      acc[2][r] = fmaf(1.0f / 6.0f, a34, a12) + p5;
+    }
+  } else if constexpr (WN) {  // G^T: planes -> taps (linear, so applied to this K group's partial sums)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float p0 = acc[0][r], p1 = acc[1][r], p2 = acc[2][r], p3 = acc[3][r];
@@ -545,7 +577,7 @@ int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, fl
 namespace {
 
 // PD: a 64x64 chunk is 2.6 us of MFMAs (one register stage), a 32x32 chunk 0.64 us (two)
-template <int BM, int KT, int S, int UP, int PRO, bool WN = false, int PD = (BM == 64 ? 1 : 2)>
+template <int BM, int KT, int S, int UP, int PRO, bool WN = false, bool W4 = false, int PD = (BM == 64 ? 1 : 2)>
 int launch_wg(const adp_wgrad_desc* ds, int n, const WgPlan& p, void* stream) {
   const adp_wgrad_desc& d = ds[0];
   adp_wg_items it;
@@ -556,7 +588,7 @@ int launch_wg(const adp_wgrad_desc* ds, int n, const WgPlan& p, void* stream) {
   }
   dim3 grid((unsigned)(p.nsplit * n), (unsigned)(d.M / BM), (unsigned)(d.R / BM));
   constexpr int NTH = ((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NLD) * 64;
-  ADP_LAUNCH((wgrad_mm_kernel<BM, KT, S, UP, PRO, PD, WN>), grid, dim3(NTH), stream, d, (int)p.cpb, (int)p.cps,
+  ADP_LAUNCH((wgrad_mm_kernel<BM, KT, S, UP, PRO, PD, WN, W4>), grid, dim3(NTH), stream, d, (int)p.cpb, (int)p.cps,
              (int)p.nsplit, it, n);
   if (p.nsplit > 1 && !(d.accumulate & 2)) {  // (bit 1 of `accumulate`: the caller parks the second stage, adp.h)
     if (ADP_LAUNCH_OK() != ADP_OK) return ADP_ERR_LAUNCH;
@@ -566,9 +598,17 @@ int launch_wg(const adp_wgrad_desc* ds, int n, const WgPlan& p, void* stream) {
   return ADP_LAUNCH_OK();
 }
 
+bool wg_winograd4(const adp_wgrad_desc& d);
+
 template <int KT, int S, int UP, int PRO, bool WN = false>
 int pick_wg(const adp_wgrad_desc* ds, int n, void* stream) {
   const WgPlan p = wg_plan(ds[0]);
+  if constexpr (WN) {  // the F(4,3) form of the kernel-3 weight gradients (wg_winograd4)
+    if (wg_winograd4(ds[0])) {
+      if (p.bm == 64) return launch_wg<64, KT, S, UP, PRO, true, true>(ds, n, p, stream);
+      return launch_wg<32, KT, S, UP, PRO, true, true>(ds, n, p, stream);
+    }
+  }
   if constexpr (S != 4) {
     if (p.bm == 64) return launch_wg<64, KT, S, UP, PRO, WN>(ds, n, p, stream);
   }
@@ -582,6 +622,17 @@ bool wg_winograd(const adp_wgrad_desc& d) {
   const char* mr = getenv("ADP_WINO_WGRAD_MIN_R");
   const int64_t min_r = mr ? atoll(mr) : 32;
   return d.KT == 3 && d.stride == 1 && d.pad == 1 && d.R >= min_r;
+}
+
+// F(4,3) form (W4) of the same: ADP_WGRAD_WINO4 (read per call; "0" = F(2,3)), layers with at least ADP_WINO4_WGRAD_MIN_R
+// (default 64) channels
+bool wg_winograd4(const adp_wgrad_desc& d) {
+  const char* e = getenv("ADP_WGRAD_WINO4");
+  if (e && e[0] == '0') return false;
+  const char* mr = getenv("ADP_WINO4_WGRAD_MIN_R");
+  const char* u = getenv("ADP_WGRAD_WINO4_UP");  // (A/B: "0" keeps the UpsampleItem convs' gradients on F(2,3))
+  if (d.up != 1 && u && u[0] == '0') return false;
+  return wg_winograd(d) && d.R >= (mr ? atoll(mr) : 64);
 }
 
 }  // namespace

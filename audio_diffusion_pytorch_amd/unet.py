@@ -344,13 +344,23 @@ class UNetV0Net(nn.Module):
             return False
         return self.item_types[int(parts[1])][int(parts[3])] == ITEM_CROSS_ATTENTION
 
+    def _named_params(self):
+        """[(name, parameter)] in registration order, walked ONCE: the module tree holds ~600 parameters and a traversal costs
+        1-2 ms of host time -- four of them per step were a tenth of an eager step (the data-parallel path at N > 1 is eager).
+        The Parameter objects of a built net never change (`.to()` swaps their storage, not the objects)."""
+        cached = getattr(self, "_named_cache", None)
+        if cached is None:
+            cached = self._named_cache = list(self.named_parameters())
+            self._pname_cache = {id(p): n for n, p in cached}
+        return cached
+
     def _param_offsets(self):
         """{parameter name: (start, end)} in the flat gradient buffer: parameter order, except that the context side of the
         cross-attention items is moved behind everything else (per item still [norm_context.weight | norm_context.bias |
         to_kv.weight], so the (gamma, beta) pair stays adjacent)."""
         if getattr(self, "_offsets", None) is None:
             off, table, late = 0, {}, []
-            for name, p in self.named_parameters():
+            for name, p in self._named_params():
                 if self._is_ctx_side(name):
                     late.append((name, p.numel()))
                     continue
@@ -378,23 +388,28 @@ class UNetV0Net(nn.Module):
         return -1
 
     def block_param_range(self, d: int):
-        t = self._param_offsets()
-        spans = [v for k, v in t.items() if k.startswith(f"blocks.{d}.") and not self._is_ctx_side(k)]
-        return min(a for a, _ in spans), max(b for _, b in spans)
+        cache = self.__dict__.setdefault("_block_ranges", {})
+        if d not in cache:
+            t = self._param_offsets()
+            spans = [v for k, v in t.items() if k.startswith(f"blocks.{d}.") and not self._is_ctx_side(k)]
+            cache[d] = (min(a for a, _ in spans), max(b for _, b in spans))
+        return cache[d]
 
     def nonblock_param_ranges(self):
         """Maximal contiguous ranges of the parameters outside the blocks and the conditioning bank's weight (time
         MLP + bank bias); their gradients are final only after conditioning_backward.  (The bank weight is handed
         out per depth.)"""
-        t = self._param_offsets()
-        spans = sorted(v for k, v in t.items() if not k.startswith("blocks.") and k != "bank_weight")
-        out = []
-        for a, b in spans:
-            if out and out[-1][1] == a:
-                out[-1] = (out[-1][0], b)
-            else:
-                out.append((a, b))
-        return out
+        if getattr(self, "_nonblock_ranges", None) is None:
+            t = self._param_offsets()
+            spans = sorted(v for k, v in t.items() if not k.startswith("blocks.") and k != "bank_weight")
+            out = []
+            for a, b in spans:
+                if out and out[-1][1] == a:
+                    out[-1] = (out[-1][0], b)
+                else:
+                    out.append((a, b))
+            self._nonblock_ranges = out
+        return self._nonblock_ranges
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: Tensor, time: Optional[Tensor] = None, *, features: Optional[Tensor] = None,
@@ -407,7 +422,7 @@ class UNetV0Net(nn.Module):
                             "`time` was given")
         if self.bank_total > 0 and not self.use_time:
             assert features is not None, "ModulationItem requires `features` when use_time_conditioning=False"
-        params = list(self.parameters())
+        params = [p for _, p in self._named_params()]
         ctx_list = [c for c in (channels or []) if c is not None]
         if not x.is_cuda:  # CPU tensors only reach the kernels through the test-suite's SIMT emulator build
             return _UNetFn.apply(self, x, time, features, embedding, x_append, channels, len(ctx_list), *ctx_list,
@@ -449,7 +464,8 @@ class _Run:
         self.need_grad = need_grad
         self.tape: List = []           # list of callables g -> g_prev
         self.grads: Dict[str, Tensor] = {}
-        self.pnames = {id(p): n for n, p in net.named_parameters()}
+        net._named_params()
+        self.pnames = net._pname_cache
         self.gn: Optional[ops.GnPart] = None  # GroupNorm partial statistics of the tensor produced last (if any)
         self.mod_sums = ops.ModulationSums()  # parked second stages of the Modulation backwards
         # parked second stages of the split ConvBlock weight gradients: summed per side of a block in one launch per shape
@@ -812,13 +828,13 @@ class _UNetFn(torch.autograd.Function):
             raise RuntimeError("the U-Net tape was released by a previous backward through this forward; "
                                "run the forward again (retain_graph is not supported by the one-node U-Net)")
         net = run.net
-        params = list(net.parameters())
-        total = sum(p.numel() for p in params)
+        named = net._named_params()
+        offs = net._param_offsets()
+        total = max(b for _, b in offs.values())
         flat = _grad_buffer((total,), gy.device)  # every parameter's slice is overwritten by its gradient kernel
         run.flat = flat
-        offs = net._param_offsets()
         views = []
-        for name, p in net.named_parameters():  # (returned to autograd in parameter order; the views point where the layout says)
+        for name, p in named:  # (returned to autograd in parameter order; the views point where the layout says)
             a, b = offs[name]
             v = flat[a:b].view(p.shape)
             run.grads[name] = v

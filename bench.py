@@ -423,11 +423,15 @@ def _dp1_worker() -> None:
         dp._send = orig
         buckets = [round((b - a) * 4 / 2 ** 20, 1) for a, b in sent]
         t_dp = _time(step, reps, warmup=3)
+        try:  # where the difference goes: the same kernels with a no-op hook, and the bucket sequence alone
+            ov = dp.measure_overlap(step, lambda fn, n: _time(fn, n, warmup=1), reps=5)
+        except Exception as e:
+            ov = {"error": f"{type(e).__name__}: {e}"}
         dp.unet._grad_ready_hook = None
         t_plain2 = _time(plain, reps, warmup=2)  # (again after the wrapped steps: same clocks / allocator state)
         t_ref = min(t_plain, t_plain2)
         return {"ms_per_step": round(t_dp * 1e3, 3), "ms_per_step_without_wrapper": round(t_ref * 1e3, 3),
-                "dp_over_plain": round(t_dp / t_ref, 4), "buckets_mb": buckets, "launch": "eager (both)",
+                "dp_over_plain": round(t_dp / t_ref, 4), "buckets_mb": buckets, "launch": "eager (both)", "overlap": ov,
                 "ctx_bank_runs_under_hook": int(getattr(dp.unet, "_ctx_bank_hooked_backwards", 0))}
 
     try:

@@ -416,6 +416,50 @@ def test_conv_tile32_trained_weight_dynamic_range(dev):
     assert ((dx.double().cpu() - dref).abs() / dcond).max().item() < 1e-4
 
 
+@pytest.mark.parametrize("B,R,M,L,tr", [(2, 128, 64, 256, False), (1, 160, 160, 132, False), (2, 128, 128, 128, True),
+                                        (1, 256, 32, 260, True), (3, 128, 96, 4, False), (1, 128, 64, 1024, False)])
+@pytest.mark.parametrize("bkt", ["32", "64"])
+def test_conv_mm4_winograd_f43(dev, B, R, M, L, tr, bkt, monkeypatch):
+    """conv_mm4.hip: the Winograd F(4,3) block of the wide kernel-3 convs (MMA waves split the six planes and the chunk's
+    channels; 32 rows x 128 positions per block): forward with bias / e_scale / residual / out_pre and the GroupNorm partial
+    statistics of the output (row-pair entries per 128-position tile), data gradient through the transposed weight view;
+    ragged last tiles (L = 132, 260), a tile shorter than one quad row (L = 4), several tiles per row (L = 1024); against fp64."""
+    from ctypes import byref
+    monkeypatch.setenv("ADP_MM4_MIN_BLOCKS", "1")
+    monkeypatch.setenv("ADP_WINO4_MIN_R", "128")
+    monkeypatch.setenv("ADP_MM4_BKT", bkt)
+    G = 8
+    x = rnd(B, R, L, seed=1)
+    w = rnd(R, M, 3, seed=2, scale=0.05) if tr else rnd(M, R, 3, seed=2, scale=0.05)
+    b, res, sc = rnd(M, seed=3), rnd(B, M, L, seed=4), rnd(B * M, seed=5)
+    xd, wd = x.to(dev), w.to(dev)
+    d = _C.ConvDesc(_C.ptr(xd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(xd), None, B, R, R, L, M, L,
+                    3, 1, 1, 1, 1, int(tr), 0, 1, 0, 1, 0)
+    assert _C.query("adp_conv1d_tile", byref(d)) == 64032128, "case must dispatch to the F(4,3) block"
+    if tr:
+        ref = F.conv_transpose1d(x.double(), w.double(), None, padding=1)
+    else:
+        ref = F.conv1d(x.double(), w.double(), None, padding=1)
+    pre_ref = ref + b.double()[None, :, None]
+    ref = pre_ref * sc.double().view(B, M, 1) + res.double()
+    pre = torch.empty(B, M, L).to(dev)
+    gn = ops.GnPart()
+    out = ops.conv1d(xd, wd, b.to(dev), pad=1, transposed=tr, e_scale=sc.to(dev), res=res.to(dev), out_pre=pre, gn=gn)
+    assert rel_err(out, ref) < 1e-5 and rel_err(pre, pre_ref) < 1e-5
+    assert gn.part is not None and gn.part.shape[2] == 2 * ((L + 127) // 128)
+    assert gn.part[..., 2].sum(dim=2).eq(4 * L).all()
+    if M % (4 * G) == 0:
+        st = ops.gn_finalize(gn.part, G)
+        g64 = ref.view(B, G, -1)
+        assert rel_err(st[..., 0], g64.mean(-1)) < 2e-5
+        assert rel_err(st[..., 1], (g64.var(-1, unbiased=False) + 1e-5).rsqrt()) < 2e-5
+    # plain call (no epilogue operands) and the switch back to conv_mm's F(2,3) variant agree
+    plain = ops.conv1d(xd, wd, None, pad=1, transposed=tr)
+    monkeypatch.setenv("ADP_CONV_WINO4", "0")
+    assert _C.query("adp_conv1d_tile", byref(d)) != 64032128
+    assert rel_err(plain, ops.conv1d(xd, wd, None, pad=1, transposed=tr)) < 1e-5
+
+
 MM_RESAMPLE_CASES = [
     # B, R, M, Lin, KT, stride, pad, up -- DownsampleItem (kernel = stride) and UpsampleItem (nearest + k3) on conv_mm
     (2, 32, 64, 256, 2, 2, 0, 1),
@@ -652,17 +696,24 @@ WGMM_CASES = [
 ]
 
 
-@pytest.mark.parametrize("wino", ["0", "1"])
+def _wgrad_family_env(monkeypatch, wino):
+    """wino: "0" direct form, "1" Winograd F(2,3) (WN), "4" Winograd F(4,3) (W4) -- each switched in for every channel count."""
+    monkeypatch.setenv("ADP_CONV_WINO", "0" if wino == "0" else "1")
+    monkeypatch.setenv("ADP_WINO_WGRAD_MIN_R", "32")
+    monkeypatch.setenv("ADP_WGRAD_WINO4", "1" if wino == "4" else "0")
+    monkeypatch.setenv("ADP_WINO4_WGRAD_MIN_R", "32")
+
+
+@pytest.mark.parametrize("wino", ["0", "1", "4"])
 @pytest.mark.parametrize("B,R,M,L,KT", WGMM_CASES)
 def test_wgrad_mm_family(dev, B, R, M, L, KT, wino, monkeypatch):
     """wino = 1: the kernel-3 cases on the Winograd F(2,3) weight-gradient variant (WN; four rank-1 updates per
-    output pair instead of six), switched in for every channel count."""
+    output pair instead of six); wino = 4: the F(4,3) variant (W4; six rank-1 updates per output quad instead of twelve)."""
     if dev.type != "cuda" and R * M > 65536:
         pytest.skip("emulating 256 16-wave workgroups takes minutes; covered on the GPU")
-    if wino == "1" and KT != 3:
-        pytest.skip("Winograd F(2,3) is the kernel-3 form")
-    monkeypatch.setenv("ADP_CONV_WINO", wino)
-    monkeypatch.setenv("ADP_WINO_WGRAD_MIN_R", "32")
+    if wino != "0" and KT != 3:
+        pytest.skip("the Winograd forms are kernel-3 forms")
+    _wgrad_family_env(monkeypatch, wino)
     G = 8
     pad = (KT - 1) // 2
     x = rnd(B, R, L, seed=1) * 1.3 + 0.2
@@ -689,15 +740,15 @@ def test_wgrad_mm_family(dev, B, R, M, L, KT, wino, monkeypatch):
     assert rel_err(db, db_ref + db0) < TOL
 
 
-@pytest.mark.parametrize("wino", ["0", "1"])
+@pytest.mark.parametrize("wino", ["0", "1", "4"])
 @pytest.mark.parametrize("B,R,M,L,KT,stride,pad,up", MM_RESAMPLE_CASES + [(2, 64, 64, 128, 2, 2, 0, 1),
                                                                          (2, 64, 128, 20, 3, 1, 1, 4)])
 def test_wgrad_mm_resample(dev, B, R, M, L, KT, stride, pad, up, wino, monkeypatch):
-    """Weight gradients of DownsampleItem (kernel = stride) and UpsampleItem (nearest + k3) on wgrad_mm."""
-    if wino == "1" and KT != 3:
-        pytest.skip("Winograd F(2,3) is the kernel-3 form")
-    monkeypatch.setenv("ADP_CONV_WINO", wino)
-    monkeypatch.setenv("ADP_WINO_WGRAD_MIN_R", "32")
+    """Weight gradients of DownsampleItem (kernel = stride) and UpsampleItem (nearest + k3) on wgrad_mm (direct form, Winograd
+    F(2,3), Winograd F(4,3): the LDS tile holds the virtual upsampled positions, so the quads are those of the upsampled row)."""
+    if wino != "0" and KT != 3:
+        pytest.skip("the Winograd forms are kernel-3 forms")
+    _wgrad_family_env(monkeypatch, wino)
     x = rnd(B, R, L, seed=1)
     w = rnd(M, R, KT, seed=2, scale=0.2).requires_grad_()
     b = rnd(M, seed=3).requires_grad_()
@@ -710,6 +761,23 @@ def test_wgrad_mm_resample(dev, B, R, M, L, KT, stride, pad, up, wino, monkeypat
     dw, db = ops.conv1d_wgrad(x.to(dev), dy.to(dev), KT, stride=stride, pad=pad, up=up)
     assert rel_err(dw, dw_ref) < TOL
     assert rel_err(db, db_ref) < TOL
+
+
+@pytest.mark.parametrize("B,C,L", [(4, 128, 1024), (2, 64, 4096)])
+def test_wgrad_winograd_f43_accuracy(dev, B, C, L, monkeypatch):
+    """The F(4,3) weight gradient sums B * L positions through transform constants up to 8 (A e) and 5 (B^T d): bound its fp32
+    error against fp64 next to the F(2,3) and direct forms on long rows (measured on the GPU: see DESIGN.md section 4)."""
+    if dev.type != "cuda" and B * C * L > 300000:
+        pytest.skip("emulator: the long-row case runs on the GPU only")
+    x, dy = rnd(B, C, L, seed=1), rnd(B, C, L, seed=2)
+    w = torch.zeros(C, C, 3, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(F.conv1d(x.double(), w, None, padding=1), w, dy.double())
+    errs = {}
+    for wino in ("0", "1", "4"):
+        _wgrad_family_env(monkeypatch, wino)
+        dw, _ = ops.conv1d_wgrad(x.to(dev), dy.to(dev), 3, pad=1)
+        errs[wino] = rel_err(dw, ref)
+    assert errs["4"] < 1e-5 and errs["1"] < 1e-5 and errs["0"] < 1e-5, errs
 
 
 @pytest.mark.parametrize("R1,R2,M,L", [(8, 0, 8, 2304), (5, 3, 8, 1100), (2, 0, 6, 516), (8, 0, 8, 36)])
