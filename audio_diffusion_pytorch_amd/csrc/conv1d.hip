@@ -865,7 +865,11 @@ extern "C" int64_t adp_conv1d_ws_bytes(const adp_conv_desc* dp) {
   if (!dp) return ADP_ERR_NULL;
   const adp_conv_desc& d = *dp;
   if (d.B <= 0 || d.R <= 0 || d.M <= 0 || d.N <= 0 || d.Lin <= 0) return ADP_ERR_SHAPE;
-  if (adp_conv_tile_eligible(d) || adp_conv_mm4_eligible(d)) return 0;
+  if (adp_conv_tile_eligible(d)) return 0;
+  if (adp_conv_mm4_eligible(d)) {
+    const int64_t ks4 = adp_conv_mm4_ksplit(d);
+    return ks4 > 1 ? ks4 * d.B * d.M * d.N * (int64_t)sizeof(float) : 0;
+  }
   if (!adp_conv_mm_eligible(d)) return 0;
   const int64_t ks = adp_conv_mm_ksplit(d);
   return ks > 1 ? ks * d.B * d.M * d.N * (int64_t)sizeof(float) : 0;

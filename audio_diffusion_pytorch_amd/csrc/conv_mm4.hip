@@ -29,14 +29,18 @@
 namespace {
 
 constexpr int M4_BM = 32, M4_BN = 128, M4_KT = 3;
-constexpr int M4_NKG = 4, M4_NPG = 2, M4_NMMA = M4_NKG * M4_NPG, M4_NLD = 4;
+constexpr int M4_NPG = 2, M4_NLD = 4;
 constexpr int M4_NLT = M4_NLD * 64;
 constexpr int M4_XSP = M4_BN + 8, M4_XQ = M4_XSP / 4;         // X row: positions n0-4 .. n0+131
-constexpr int M4_RED = M4_NKG * 6 * 1024;                     // 24 parked partial tiles
 
 // BKT: channels per staged chunk (32, or 64: half the barriers per K, 16 channels per K group and chunk)
-template <bool TR, int PD, int BKT>
-__global__ __launch_bounds__((M4_NMMA + M4_NLD) * 64) void conv_mm4_kernel(adp_conv_desc d) {
+// NKG: K groups (MMA waves per plane group): 4 = the 12-wave block of the long-K layers (one per CU: 96 KB of partial tiles);
+//      2 = an 8-wave block with 60 KB of LDS for the short-K layers -- two of them share a CU, one's loads / exchange / stores
+//      under the other's MFMAs (a 4-chunk K loop is all ramp and drain otherwise)
+template <bool TR, int PD, int BKT, int M4_NKG>
+__global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64) void conv_mm4_kernel(adp_conv_desc d) {
+  constexpr int M4_NMMA = M4_NKG * M4_NPG, RPW = 16 / M4_NMMA;  // accumulator rows finished per wave (2 or 4)
+  constexpr int M4_RED = M4_NKG * 6 * 1024;                     // parked partial tiles
   constexpr int M4_QK = BKT * M4_KT;                            // floats of a forward weight row per chunk
   constexpr int M4_AROWS = TR ? BKT : M4_BM;
   constexpr int M4_AS = (TR ? M4_BM * M4_KT : M4_QK) + 4;       // A row stride (4 mod 8 dwords)
@@ -60,7 +64,14 @@ __global__ __launch_bounds__((M4_NMMA + M4_NLD) * 64) void conv_mm4_kernel(adp_c
   const int mt = id / per_m, rem = id - mt * per_m;
   const int b = rem / ntn, nt = rem - b * ntn;
   const int m0 = mt * M4_BM, n0 = nt * M4_BN;
-  const int nchunks = R / BKT;
+  // Cross-workgroup K split (gridDim.y = KS > 1: grids of fewer than ~200 blocks, e.g. the [4, 1024, 128] layers of depth 8):
+  // this block reduces channel chunks [c_lo, c_lo + nchunks) only and parks its raw (output-transformed) partial tile in
+  // d.ws[ks]; bias / e_scale / residual / GroupNorm partials then run in conv_splitk_reduce[_gn]_kernel (conv_mm.hip), which
+  // sums the KS partials in a fixed order.
+  const int ks = blockIdx.y, KS = gridDim.y;
+  const int cps = (R / BKT + KS - 1) / KS;
+  const int c_lo = ks * cps;
+  const int nchunks = (R / BKT - c_lo) < cps ? (R / BKT - c_lo) : cps;
   const int nrounds = ((nchunks + PD - 1) / PD) * PD;
 
   if (wave >= M4_NMMA) {
@@ -89,7 +100,7 @@ __global__ __launch_bounds__((M4_NMMA + M4_NLD) * 64) void conv_mm4_kernel(adp_c
     }
     f32x4 ra[PD][M4_NA4], rx[PD][M4_NX4];
     auto load_chunk = [&](f32x4 (&a)[M4_NA4], f32x4 (&x)[M4_NX4], int chunk) {
-      const int rn = (chunk < nchunks ? chunk : nchunks - 1) * BKT;  // (the tail re-reads the last chunk: never consumed)
+      const int rn = (c_lo + (chunk < nchunks ? chunk : nchunks - 1)) * BKT;  // (the tail re-reads the last chunk: never consumed)
       const float* wp = TR ? wbase + (int64_t)rn * M * KT : wbase + rn * KT;
 #pragma unroll
       for (int i = 0; i < M4_NA4; ++i) a[i] = *reinterpret_cast<const f32x4*>(wp + a_src[i]);
@@ -137,17 +148,17 @@ __global__ __launch_bounds__((M4_NMMA + M4_NLD) * 64) void conv_mm4_kernel(adp_c
 
   // epilogue operands of the two accumulator rows this wave finishes, fetched NOW (their latency lies under the K loop)
   const int nq = n0 + 4 * l31;
-  f32x4 pre_res[2];
-  float pre_bias[2], pre_scale[2];
+  f32x4 pre_res[RPW];
+  float pre_bias[RPW], pre_scale[RPW];
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int r = 2 * wave + rr;
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int r = RPW * wave + rr;
     const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
     const int mc = m < M ? m : M - 1;
     pre_bias[rr] = d.bias ? d.bias[mc] : 0.0f;
     pre_scale[rr] = d.e_scale ? d.e_scale[b * (d.e_bstride ? d.e_bstride : M) + mc] : 1.0f;
     pre_res[rr] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (d.res && m < M && nq < N) pre_res[rr] = *reinterpret_cast<const f32x4*>(d.res + ((int64_t)b * M + m) * N + nq);
+    if (d.res && m < M && nq < N && KS == 1) pre_res[rr] = *reinterpret_cast<const f32x4*>(d.res + ((int64_t)b * M + m) * N + nq);
   }
 
   const int xfrag = 4 * hi * XSP + 4 * l31 + 4;                         // + (ci + cc) * XSP: the lane's input quad d1..d4
@@ -226,12 +237,12 @@ __global__ __launch_bounds__((M4_NMMA + M4_NLD) * 64) void conv_mm4_kernel(adp_c
   }
   __syncthreads();
 
-  // ---- output transform + epilogue: this wave finishes accumulator rows 2 * wave, 2 * wave + 1 (both halves of a row-quad pair)
+  // ---- output transform + epilogue: this wave finishes accumulator rows RPW * wave .. (for both halves of the wave)
   const bool nok = nq < N;  // N % 4 == 0: a quad is inside or outside
-  float vfin[2][4];
+  float vfin[RPW][4];
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int r = 2 * wave + rr;
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int r = RPW * wave + rr;
     float s[6];
 #pragma unroll
     for (int P = 0; P < 6; ++P) {
@@ -253,6 +264,10 @@ __global__ __launch_bounds__((M4_NMMA + M4_NLD) * 64) void conv_mm4_kernel(adp_c
 #pragma unroll
     for (int k = 0; k < 4; ++k) vfin[rr][k] = 0.0f;
     if (!ok) continue;
+    if (KS > 1) {  // raw partial tile; the epilogue runs in the reduce kernel
+      *reinterpret_cast<f32x4*>(d.ws + (((int64_t)ks * d.B + b) * M + m) * N + nq) = y;
+      continue;
+    }
     const int64_t o = ((int64_t)b * M + m) * N + nq;
 #pragma unroll
     for (int k = 0; k < 4; ++k) y[k] += pre_bias[rr];
@@ -264,14 +279,14 @@ __global__ __launch_bounds__((M4_NMMA + M4_NLD) * 64) void conv_mm4_kernel(adp_c
     for (int k = 0; k < 4; ++k) vfin[rr][k] = y[k];
   }
 
-  // ---- GroupNorm partial statistics of the tile just stored: one (mean, M2, count) entry per (half of a row quad = the two
-  // rows this wave finished) x (128-position tile); the consumer Chan-combines the entries whatever their counts
-  if (d.gn_part != nullptr && n0 < N) {
+  // ---- GroupNorm partial statistics of the tile just stored: one (mean, M2, count) entry per (the RPW rows of a row quad this
+  // wave finished: half a quad or all of it) x (128-position tile); the consumer Chan-combines the entries whatever their counts
+  if (d.gn_part != nullptr && n0 < N && KS == 1) {
     const int cntv = (N - n0) < M4_BN ? (N - n0) : M4_BN;
-    const float fcnt = 2.0f * (float)cntv;
+    const float fcnt = (float)RPW * (float)cntv;
     float sv = 0.0f;
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr)
+    for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
       for (int k = 0; k < 4; ++k) sv += vfin[rr][k];
 #pragma unroll
@@ -279,7 +294,7 @@ __global__ __launch_bounds__((M4_NMMA + M4_NLD) * 64) void conv_mm4_kernel(adp_c
     const float mean = sv / fcnt;
     float qv = 0.0f;
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr)
+    for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float dv = nok ? vfin[rr][k] - mean : 0.0f;
@@ -287,10 +302,11 @@ __global__ __launch_bounds__((M4_NMMA + M4_NLD) * 64) void conv_mm4_kernel(adp_c
       }
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) qv += __shfl_xor(qv, o, 64);
-    const int r = 2 * wave;
+    const int r = RPW * wave;
     const int m = m0 + 8 * (r >> 2) + 4 * hi;  // first channel of the row quad
     if (l31 == 0 && m < M) {
-      float* e = d.gn_part + (((int64_t)b * (M / 4) + (m >> 2)) * (2 * ntn) + 2 * nt + (wave & 1)) * 3;
+      constexpr int EPT = 4 / RPW;  // entries per row quad and tile
+      float* e = d.gn_part + (((int64_t)b * (M / 4) + (m >> 2)) * (EPT * ntn) + EPT * nt + (EPT == 2 ? (wave & 1) : 0)) * 3;
       e[0] = mean;
       e[1] = qv;
       e[2] = fcnt;
@@ -305,6 +321,8 @@ int64_t m4_min_blocks() {
 
 }  // namespace
 
+int64_t adp_conv_mm4_ksplit(const adp_conv_desc& d);
+
 // ADP_CONV_WINO4 (read per call): unset / "1" = this kernel for every eligible conv; "0" = conv_mm's F(2,3) variant (A/B, tests)
 bool adp_conv_mm4_eligible(const adp_conv_desc& d) {
   if (!adp_winograd_enabled()) return false;
@@ -314,44 +332,74 @@ bool adp_conv_mm4_eligible(const adp_conv_desc& d) {
   if (d.prologue != 0 || d.store != 0) return false;
   if (d.N != d.Lin || d.N % 4 != 0) return false;
   const char* mr = getenv("ADP_WINO4_MIN_R");
-  // (round 5, whole step at batch 4 on one box: from 128 channels 12.22 ms, from 512 12.15 -- the short-K layers of depths 3-4
-  //  keep conv_mm's wide-N F(2,3) blocks, whose per-block skeleton is lighter)
-  if (d.R < (mr ? atoll(mr) : 512) || d.R % 32 != 0 || d.M % M4_BM != 0) return false;
+  // (from 128 channels: the materialised-activation layers; with the 12-wave block only, the short-K layers of depths 3-4 lost
+  //  to conv_mm's wide-N F(2,3) blocks -- 12.22 vs 12.15 ms per step -- the light block wins them back: m4_nkg)
+  if (d.R < (mr ? atoll(mr) : 128) || d.R % 32 != 0 || d.M % M4_BM != 0) return false;
   if ((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.w) | reinterpret_cast<uintptr_t>(d.out) |
        reinterpret_cast<uintptr_t>(d.res) | reinterpret_cast<uintptr_t>(d.out_pre)) & 15)
     return false;
   if (d.B * d.R * d.Lin >= (int64_t)1 << 31 || d.M * d.R * d.KT >= (int64_t)1 << 31) return false;
-  // one block per CU and more: below that the 64-position blocks of conv_mm (with their K split at batch 1) fill the chip better
-  return (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B >= m4_min_blocks();
+  // one block per CU and more (with the K split: adp_conv_mm4_ksplit); below that conv_mm's 64-position blocks fill the chip better
+  return (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B * adp_conv_mm4_ksplit(d) >= m4_min_blocks();
 }
 
-int64_t adp_conv_mm4_gn_entries(const adp_conv_desc& d) { return 2 * adp_cdiv(d.N, M4_BN); }
+// Cross-workgroup K split of the F(4,3) block: 2 / 4 slices (>= 4 chunks of 64 channels each) when the tiles alone leave the
+// chip half empty -- the [4, 1024, 128] layers of depth 8 are 128 tiles.  ADP_MM4_KS_MAX caps it (1 = never: A/B, default 2).
+int64_t adp_conv_mm4_ksplit(const adp_conv_desc& d) {
+  const char* e = getenv("ADP_MM4_KS_MAX");
+  const int64_t ksmax = e ? atoll(e) : 2;
+  const int64_t blocks = (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B, nchunks = d.R / 64;
+  int64_t ks = 1;
+  // (every slice keeps >= 8 chunks of 64 channels: at batch 1 the 512-channel layers would qualify with 4 and lose to conv_mm's
+  //  64-position blocks -- batch-1 step 6.46 -> 6.53 ms; depth 8 at batch 4: step 12.16 -> 12.11 ms)
+  while (ks < ksmax && blocks * ks < m4_min_blocks() && d.R % 64 == 0 && nchunks / (ks * 2) >= 8) ks *= 2;
+  return ks;
+}
+
+// K groups of the block: 2 = the light 8-wave block, taken when the grid has at least two blocks per CU (ADP_MM4_LIGHT_MIN_BLOCKS,
+// default 400) so that two of them share a CU; else the 12-wave block.  Isolated launches at batch 4, us (tools/mm4_micro.py,
+// conv_mm F(2,3) -> 12-wave F(4,3) -> light): C=512 L=1024 45.9 -> 44.9 -> 39.8; C=256 L=2048 29.2 -> 29.0 -> 25.4; C=128 L=4096
+// 18.7 -> 21.3 -> 17.4; with one block per CU the light block loses (C=512 L=512 25.6 -> 22.5 -> 24.9).
+static int m4_nkg(const adp_conv_desc& d) {
+  const char* e = getenv("ADP_MM4_LIGHT_MIN_BLOCKS");
+  const int64_t blocks = (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B;
+  return blocks >= (e ? atoll(e) : 400) ? 2 : 4;
+}
+
+int64_t adp_conv_mm4_gn_entries(const adp_conv_desc& d) {
+  if (d.ws && adp_conv_mm4_ksplit(d) > 1) return adp_conv_splitk_gn_entries(d);
+  return (m4_nkg(d) == 2 ? 1 : 2) * adp_cdiv(d.N, M4_BN);
+}
 
 int adp_conv_mm4(const adp_conv_desc& d, void* stream) {
   const int64_t blocks = (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B;
-  const dim3 block((M4_NMMA + M4_NLD) * 64);
+  const int64_t ks = d.ws ? adp_conv_mm4_ksplit(d) : 1;  // (without the caller's scratch: the unsplit path, still correct)
+  const dim3 grid((unsigned)blocks, (unsigned)ks);
+  if (m4_nkg(d) == 2) {  // light block: 32-channel chunks (60 KB of LDS: two blocks per CU)
+    const dim3 block((2 * M4_NPG + M4_NLD) * 64);
+    if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 32, 2>), grid, block, stream, d);
+    else ADP_LAUNCH((conv_mm4_kernel<false, 1, 32, 2>), grid, block, stream, d);
+    if (ADP_LAUNCH_OK() != ADP_OK) return ADP_ERR_LAUNCH;
+    return ks > 1 ? adp_conv_splitk_reduce(d, ks, stream) : ADP_OK;
+  }
+  const dim3 block((4 * M4_NPG + M4_NLD) * 64);
   // 64-channel chunks (24 MFMAs per wave and barrier instead of 12) unless ADP_MM4_BKT=32: step 12.15 -> 12.09 ms
   const char* e = getenv("ADP_MM4_BKT");
   const int bkt = (e ? atoi(e) : 64) == 64 && d.R % 64 == 0 ? 64 : 32;
-  if (bkt == 64) {
-    const char* p = getenv("ADP_MM4_PD");
-    const int pd = p ? atoi(p) : 1;
-    if (pd == 2 && d.R / 64 >= 4) {
-      if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 2, 64>), dim3((unsigned)blocks), block, stream, d);
-      else ADP_LAUNCH((conv_mm4_kernel<false, 2, 64>), dim3((unsigned)blocks), block, stream, d);
-      return ADP_LAUNCH_OK();
-    }
-    if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64>), dim3((unsigned)blocks), block, stream, d);
-    else ADP_LAUNCH((conv_mm4_kernel<false, 1, 64>), dim3((unsigned)blocks), block, stream, d);
-    return ADP_LAUNCH_OK();
-  }
-  const bool pd2 = d.R / 32 >= 4;
-  if (d.transposed) {
-    if (pd2) ADP_LAUNCH((conv_mm4_kernel<true, 2, 32>), dim3((unsigned)blocks), block, stream, d);
-    else ADP_LAUNCH((conv_mm4_kernel<true, 1, 32>), dim3((unsigned)blocks), block, stream, d);
+  if (bkt == 64) {  // (one register stage: a second one with 64-channel chunks spills)
+    if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64, 4>), grid, block, stream, d);
+    else ADP_LAUNCH((conv_mm4_kernel<false, 1, 64, 4>), grid, block, stream, d);
   } else {
-    if (pd2) ADP_LAUNCH((conv_mm4_kernel<false, 2, 32>), dim3((unsigned)blocks), block, stream, d);
-    else ADP_LAUNCH((conv_mm4_kernel<false, 1, 32>), dim3((unsigned)blocks), block, stream, d);
+    const bool pd2 = d.R / 32 / ks >= 4;
+    if (d.transposed) {
+      if (pd2) ADP_LAUNCH((conv_mm4_kernel<true, 2, 32, 4>), grid, block, stream, d);
+      else ADP_LAUNCH((conv_mm4_kernel<true, 1, 32, 4>), grid, block, stream, d);
+    } else {
+      if (pd2) ADP_LAUNCH((conv_mm4_kernel<false, 2, 32, 4>), grid, block, stream, d);
+      else ADP_LAUNCH((conv_mm4_kernel<false, 1, 32, 4>), grid, block, stream, d);
+    }
   }
-  return ADP_LAUNCH_OK();
+  if (ADP_LAUNCH_OK() != ADP_OK) return ADP_ERR_LAUNCH;
+  if (ks > 1) return adp_conv_splitk_reduce(d, ks, stream);
+  return ADP_OK;
 }

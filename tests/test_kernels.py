@@ -418,7 +418,7 @@ def test_conv_tile32_trained_weight_dynamic_range(dev):
 
 @pytest.mark.parametrize("B,R,M,L,tr", [(2, 128, 64, 256, False), (1, 160, 160, 132, False), (2, 128, 128, 128, True),
                                         (1, 256, 32, 260, True), (3, 128, 96, 4, False), (1, 128, 64, 1024, False)])
-@pytest.mark.parametrize("bkt", ["32", "64"])
+@pytest.mark.parametrize("bkt", ["32", "64", "light"])
 def test_conv_mm4_winograd_f43(dev, B, R, M, L, tr, bkt, monkeypatch):
     """conv_mm4.hip: the Winograd F(4,3) block of the wide kernel-3 convs (MMA waves split the six planes and the chunk's
     channels; 32 rows x 128 positions per block): forward with bias / e_scale / residual / out_pre and the GroupNorm partial
@@ -427,7 +427,11 @@ def test_conv_mm4_winograd_f43(dev, B, R, M, L, tr, bkt, monkeypatch):
     from ctypes import byref
     monkeypatch.setenv("ADP_MM4_MIN_BLOCKS", "1")
     monkeypatch.setenv("ADP_WINO4_MIN_R", "128")
-    monkeypatch.setenv("ADP_MM4_BKT", bkt)
+    if bkt == "light":  # the 8-wave block with two K groups (short-K layers, two blocks per CU): one GroupNorm entry per tile
+        monkeypatch.setenv("ADP_MM4_LIGHT_MIN_BLOCKS", "1")
+    else:
+        monkeypatch.setenv("ADP_MM4_LIGHT_MIN_BLOCKS", "1000000")
+        monkeypatch.setenv("ADP_MM4_BKT", bkt)
     G = 8
     x = rnd(B, R, L, seed=1)
     w = rnd(R, M, 3, seed=2, scale=0.05) if tr else rnd(M, R, 3, seed=2, scale=0.05)
@@ -446,7 +450,7 @@ def test_conv_mm4_winograd_f43(dev, B, R, M, L, tr, bkt, monkeypatch):
     gn = ops.GnPart()
     out = ops.conv1d(xd, wd, b.to(dev), pad=1, transposed=tr, e_scale=sc.to(dev), res=res.to(dev), out_pre=pre, gn=gn)
     assert rel_err(out, ref) < 1e-5 and rel_err(pre, pre_ref) < 1e-5
-    assert gn.part is not None and gn.part.shape[2] == 2 * ((L + 127) // 128)
+    assert gn.part is not None and gn.part.shape[2] == (1 if bkt == "light" else 2) * ((L + 127) // 128)
     assert gn.part[..., 2].sum(dim=2).eq(4 * L).all()
     if M % (4 * G) == 0:
         st = ops.gn_finalize(gn.part, G)
@@ -458,6 +462,37 @@ def test_conv_mm4_winograd_f43(dev, B, R, M, L, tr, bkt, monkeypatch):
     monkeypatch.setenv("ADP_CONV_WINO4", "0")
     assert _C.query("adp_conv1d_tile", byref(d)) != 64032128
     assert rel_err(plain, ops.conv1d(xd, wd, None, pad=1, transposed=tr)) < 1e-5
+
+
+@pytest.mark.parametrize("B,R,M,L,tr,ksmax", [(1, 1024, 32, 128, False, 2), (2, 2048, 32, 132, True, 4), (1, 1024, 64, 8, False, 2)])
+def test_conv_mm4_cross_workgroup_split_k(dev, B, R, M, L, tr, ksmax, monkeypatch):
+    """conv_mm4 with fewer tiles than the chip has CUs (depth 8 at batch 4: 128 tiles of 32 x 128): the channel reduction is cut
+    into 2 / 4 slices run by separate workgroups, the raw output-transformed partial tiles go to the caller's scratch and
+    conv_splitk_reduce[_gn] sums them in a fixed order and owns the epilogue + the GroupNorm partials."""
+    from ctypes import byref
+    monkeypatch.setenv("ADP_WINO4_MIN_R", "128")
+    monkeypatch.setenv("ADP_MM4_KS_MAX", str(ksmax))
+    blocks = (M // 32) * ((L + 127) // 128) * B
+    monkeypatch.setenv("ADP_MM4_MIN_BLOCKS", str(blocks * ksmax))
+    x = rnd(B, R, L, seed=1)
+    w = rnd(R, M, 3, seed=2, scale=0.05) if tr else rnd(M, R, 3, seed=2, scale=0.05)
+    b, res, sc = rnd(M, seed=3), rnd(B, M, L, seed=4), rnd(B * M, seed=5)
+    xd, wd = x.to(dev), w.to(dev)
+    d = _C.ConvDesc(_C.ptr(xd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(xd), None, B, R, R, L, M, L,
+                    3, 1, 1, 1, 1, int(tr), 0, 1, 0, 1, 0)
+    assert _C.query("adp_conv1d_tile", byref(d)) == 64032128
+    assert _C.query("adp_conv1d_ws_bytes", byref(d)) == ksmax * B * M * L * 4, "this shape is meant to take the split-K path"
+    ref = F.conv_transpose1d(x.double(), w.double(), None, padding=1) if tr else F.conv1d(x.double(), w.double(), None, padding=1)
+    pre_ref = ref + b.double()[None, :, None]
+    ref = pre_ref * sc.double().view(B, M, 1) + res.double()
+    pre = torch.empty(B, M, L).to(dev)
+    gn = ops.GnPart()
+    out = ops.conv1d(xd, wd, b.to(dev), pad=1, transposed=tr, e_scale=sc.to(dev), res=res.to(dev), out_pre=pre, gn=gn)
+    assert rel_err(out, ref) < 1e-5 and rel_err(pre, pre_ref) < 1e-5
+    assert gn.part is not None and gn.part[..., 2].sum(dim=2).eq(4 * L).all()
+    st = ops.gn_finalize(gn.part, 8)
+    g64 = ref.view(B, 8, -1)
+    assert rel_err(st[..., 0], g64.mean(-1)) < 2e-5 and rel_err(st[..., 1], (g64.var(-1, unbiased=False) + 1e-5).rsqrt()) < 2e-5
 
 
 MM_RESAMPLE_CASES = [
