@@ -659,6 +659,14 @@ int run_tile(const adp_conv_desc& d, void* stream) {
   }
   if (d.prologue == 1)
     return tr ? launch_pd<BM, 1, 1, 1, true, 1, 32>(d, stream) : launch_pd<BM, 1, 1, 1, false, 1, 32>(d, stream);
+  // 1x1 convs (the DownsampleItem data gradients as a 1x1 over the space-to-depth view, attention projections): one tap per
+  // channel pair = 8 MFMAs per wave and barrier with 32-channel chunks -- 64-channel chunks halve the barriers per MFMA
+  // (ADP_MM_K1_BKT=32: the old chunk; not with the cross-workgroup K split, whose slices are counted in 32-channel chunks)
+  {
+    const char* e = getenv("ADP_MM_K1_BKT");
+    if ((!e || atoi(e) == 64) && d.R % 64 == 0 && d.R >= 256 && (!d.ws || adp_conv_mm_ksplit(d) == 1))
+      return tr ? launch_pd<BM, 1, 1, 1, true, 0, 64>(d, stream) : launch_pd<BM, 1, 1, 1, false, 0, 64>(d, stream);
+  }
   return tr ? launch_pd<BM, 1, 1, 1, true, 0, 32>(d, stream) : launch_pd<BM, 1, 1, 1, false, 0, 32>(d, stream);
 }
 

@@ -19,8 +19,22 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
-def init_process_group_from_env(backend: Optional[str] = None) -> int:
-    """Initialises torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract)."""
+def graph_safe_rccl_env() -> None:
+    """Environment under which a training step WITH its RCCL all-reduces can be captured in a hipGraph (set before the
+    process group exists).  ProcessGroupNCCL's watchdog thread polls the collectives' events; an event query from another
+    thread while a stream capture is open is what killed the round-3 capture attempt (segmentation fault inside
+    libtorch_hip).  With the watchdog's error handling and monitoring off the captured step replays correctly -- one-rank RCCL
+    group on MI355X / ROCm 7 / torch 2.10, tools/dp_capture_probe.py: 15.5-16.5 ms eager -> 13.3 ms replayed at batch 4, 16.5 ->
+    7.6 ms at batch 1, gradients bit-identical to the eager step's.  The price: a hung collective is no longer aborted by the
+    watchdog (it hangs until the launcher's own timeout).  `setdefault`: a caller's explicit setting wins."""
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+    os.environ.setdefault("TORCH_NCCL_ENABLE_MONITORING", "0")
+    os.environ.setdefault("TORCH_NCCL_DUMP_ON_TIMEOUT", "0")
+
+
+def init_process_group_from_env(backend: Optional[str] = None, graph_safe: bool = True) -> int:
+    """Initialises torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).  `graph_safe`
+    (default): with the settings of graph_safe_rccl_env, so that the data-parallel step can be replayed from a hipGraph."""
     if dist.is_initialized():
         return dist.get_rank()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -28,6 +42,8 @@ def init_process_group_from_env(backend: Optional[str] = None) -> int:
         return 0
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if graph_safe:
+        graph_safe_rccl_env()
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
@@ -137,11 +153,14 @@ class DataParallel(nn.Module):
             dst = [v for v, h in zip(self._tail_views, have) if h]
             if dst:
                 torch._foreach_copy_(dst, [p.grad for p, h in zip(self._extra, have) if h])
-            if self._tail_event is not None:
+            # (under a stream capture the copy becomes a node of the graph and the event is left alone: a captured event
+            #  cannot be waited for from the host)
+            guard = self._tail_event is not None and not torch.cuda.is_current_stream_capturing()
+            if guard:
                 self._tail_event.synchronize()  # the previous step's asynchronous copy has read the pinned row
             self._tail_host.copy_(torch.tensor(have, dtype=torch.float32))
             self._tail_flags.copy_(self._tail_host, non_blocking=True)
-            if self._tail_event is not None:
+            if guard:
                 self._tail_event.record()
             self._works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
         self._wait_all()

@@ -396,6 +396,7 @@ def _dp1_worker() -> None:
         port = sk.getsockname()[1]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
+    parallel.graph_safe_rccl_env()
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("nccl", rank=0, world_size=1)
@@ -427,11 +428,23 @@ def _dp1_worker() -> None:
             ov = dp.measure_overlap(step, lambda fn, n: _time(fn, n, warmup=1), reps=5)
         except Exception as e:
             ov = {"error": f"{type(e).__name__}: {e}"}
+        # the same two steps replayed from hipGraphs: the wrapped one holds its RCCL all-reduces (what bench.py times at N > 1)
+        try:
+            t_dp_graph = _time(_graphed(step, zero), 20)
+        except Exception as e:
+            t_dp_graph = None
+            graph_err = f"{type(e).__name__}: {e}"
+            torch.cuda.synchronize()
         dp.unet._grad_ready_hook = None
         t_plain2 = _time(plain, reps, warmup=2)  # (again after the wrapped steps: same clocks / allocator state)
         t_ref = min(t_plain, t_plain2)
-        return {"ms_per_step": round(t_dp * 1e3, 3), "ms_per_step_without_wrapper": round(t_ref * 1e3, 3),
-                "dp_over_plain": round(t_dp / t_ref, 4), "buckets_mb": buckets, "launch": "eager (both)", "overlap": ov,
+        t_plain_graph = _time(_graphed(plain, zero), 20)
+        graphs = ({"ms_per_step": round(t_dp_graph * 1e3, 3), "ms_per_step_without_wrapper": round(t_plain_graph * 1e3, 3),
+                   "dp_over_plain": round(t_dp_graph / t_plain_graph, 4)} if t_dp_graph is not None
+                  else {"error": graph_err, "ms_per_step_without_wrapper": round(t_plain_graph * 1e3, 3)})
+        return {"hipgraph_replay": graphs,
+                "ms_per_step": round(t_dp * 1e3, 3), "ms_per_step_without_wrapper": round(t_ref * 1e3, 3),
+                "dp_over_plain": round(t_dp / t_ref, 4), "buckets_mb": buckets, "launch": "eager (both; hipgraph_replay: replayed)", "overlap": ov,
                 "ctx_bank_runs_under_hook": int(getattr(dp.unet, "_ctx_bank_hooked_backwards", 0))}
 
     try:
@@ -464,8 +477,10 @@ def dp1_leg(timeout: float = 240.0):
             if line.startswith("DP1_WORKER "):
                 res = json.loads(line[len("DP1_WORKER "):])
                 res["what"] = ("parallel.DataParallel(force_collectives=True) on a one-rank RCCL group in a child process: "
-                               "the bucketed ReduceOp.AVG all-reduces issued from inside backward as at N > 1, eager launches, "
-                               "against the same eager step without the wrapper (median-free mean of 10 steps each)")
+                               "the bucketed ReduceOp.AVG all-reduces issued from inside backward as at N > 1, against the same step "
+                               "without the wrapper -- eager launches (mean of 10 steps each; host-bound, varies with the box's "
+                               "host load) and, `hipgraph_replay`, both replayed from hipGraphs (the wrapped graph holds its "
+                               "collectives; this is how bench.py runs at N > 1)")
                 return res
         return {"error": "dp1 worker printed no result", "rc": out.returncode, "stderr_tail": out.stderr[-600:]}
     except Exception as e:
@@ -651,7 +666,9 @@ def main():
         model = parallel.DataParallel(model)
     torch.manual_seed(1234 + rank)
     x = torch.randn(args.batch, 2, LENGTH).to(dev)  # synthetic waveforms, resident in HBM before timing
-    use_graph = args.graph if args.graph >= 0 else (1 if world == 1 else 0)
+    # hipGraph replay also with RCCL (round 5: the collectives issued from inside backward are captured with the step once
+    # ProcessGroupNCCL's watchdog is kept away from the capture -- parallel.graph_safe_rccl_env); --graph 0 = eager launches
+    use_graph = args.graph if args.graph >= 0 else 1
 
     def zero():
         for p in model.parameters():
@@ -684,6 +701,11 @@ def main():
                       file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
+        if world > 1:  # every rank replays, or every rank launches eagerly (a graph holds its collectives)
+            ok = torch.tensor([1.0 if graph is not None else 0.0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() < 1.0:
+                graph = None
 
     step = graph.replay if graph is not None else eager_step
 
@@ -740,6 +762,7 @@ def main():
                    "parallelism": f"dp{world}" if world > 1 else "single",
                    "collective_backend": (dist.get_backend() if world > 1 else None),
                    "collective_world_size": (dist.get_world_size() if world > 1 else 1),
+                   "collectives_in_graph": bool(world > 1 and graph is not None),
                    "optimizer": "none (the metric is fwd+bwd; gradients for all 176M parameters are produced)"},
     }
     if len(windows) > 1:

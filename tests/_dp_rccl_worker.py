@@ -20,10 +20,17 @@ def main():
     torch.cuda.set_device(rank)
     dev = torch.device("cuda", rank)
     import audio_diffusion_pytorch_amd as adp
-    from audio_diffusion_pytorch_amd.parallel import DataParallel
+    from audio_diffusion_pytorch_amd.parallel import DataParallel, graph_safe_rccl_env
     from test_parallel import CFG_GUIDED
     from test_unet import FixedSigmas
+    graph_safe_rccl_env()  # (the watchdog stays away from the stream capture below)
     dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    class FixedSigmas(FixedSigmas):  # noqa: F811  (device-resident: a captured step cannot copy from pageable host memory)
+        def __call__(self, num_samples, device=torch.device("cpu")):
+            if getattr(self, "_dev", None) is None or self._dev.device != torch.device(device):
+                self._dev = self.vals.to(device)
+            return self._dev[:num_samples]
     per = 2
     sig = [0.2, 0.7, 0.4, 0.9][:per * world]
     g = torch.Generator().manual_seed(7)
@@ -56,7 +63,32 @@ def main():
             den = max(q.grad.abs().max().item(), 1e-6)
             worst = max(worst, (p.grad - q.grad).abs().max().item() / den)
     assert worst < 1e-4, worst
-    print(f"rank {rank}/{world}: DataParallel over RCCL ok, worst relative gradient difference {worst:.2e}", flush=True)
+    # the same step CAPTURED in a hipGraph with its RCCL all-reduces (how bench.py runs at N > 1) and replayed twice
+    eager = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+    args = (x[sl].to(dev),)
+    kw = dict(noise=noise[sl].to(dev), embedding=emb[sl].to(dev), embedding_mask_proba=0.5, batch_mask=mask[sl].to(dev))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for p in model.parameters():
+            p.grad = None
+        dp(*args, **kw).backward()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for p in model.parameters():
+        p.grad = None
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        dp(*args, **kw).backward()
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    for (name, p), e in zip(model.named_parameters(), eager):
+        assert (p.grad is None) == (e is None), name
+        if e is not None:
+            assert torch.equal(p.grad, e), f"replayed data-parallel step differs from the eager one at {name}"
+    print(f"rank {rank}/{world}: DataParallel over RCCL ok, worst relative gradient difference {worst:.2e}; the step replays "
+          f"from a hipGraph with its collectives, bit-identical", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -495,6 +495,24 @@ def test_conv_mm4_cross_workgroup_split_k(dev, B, R, M, L, tr, ksmax, monkeypatc
     assert rel_err(st[..., 0], g64.mean(-1)) < 2e-5 and rel_err(st[..., 1], (g64.var(-1, unbiased=False) + 1e-5).rsqrt()) < 2e-5
 
 
+@pytest.mark.parametrize("bkt", ["32", "64"])
+@pytest.mark.parametrize("B,R,M,L,tr,big", [(2, 256, 64, 200, False, False), (1, 320, 96, 132, True, False),
+                                             (2, 256, 128, 260, True, True), (1, 512, 64, 64, False, True)])
+def test_conv_mm_1x1_wide_chunks(dev, B, R, M, L, tr, big, bkt, monkeypatch):
+    """1x1 convs on conv_mm with 64-channel staged chunks (16 instead of 8 MFMAs per wave and barrier: the DownsampleItem data
+    gradients over the space-to-depth view, the attention projections) against the 32-channel chunks and torch: 32- and 64-row
+    tiles (`big`: with the wide-N block), ragged last tile, a channel count that is a multiple of 64 but not of 128."""
+    monkeypatch.setenv("ADP_MM_K1_BKT", bkt)
+    if big:
+        monkeypatch.setenv("ADP_MM_MIN_BLOCKS", "1")
+    x = rnd(B, R, L, seed=1)
+    w = rnd(R, M, 1, seed=2, scale=0.05) if tr else rnd(M, R, 1, seed=2, scale=0.05)
+    b, res = rnd(M, seed=3), rnd(B, M, L, seed=4)
+    ref = (F.conv_transpose1d(x, w, None) + b[None, :, None] if tr else F.conv1d(x, w, b)) + res
+    out = ops.conv1d(x.to(dev), w.to(dev), b.to(dev), transposed=tr, res=res.to(dev))
+    assert rel_err(out, ref) < TOL
+
+
 MM_RESAMPLE_CASES = [
     # B, R, M, Lin, KT, stride, pad, up -- DownsampleItem (kernel = stride) and UpsampleItem (nearest + k3) on conv_mm
     (2, 32, 64, 256, 2, 2, 0, 1),
