@@ -352,7 +352,11 @@ int64_t adp_conv_mm4_ksplit(const adp_conv_desc& d) {
   int64_t ks = 1;
   // (every slice keeps >= 8 chunks of 64 channels: at batch 1 the 512-channel layers would qualify with 4 and lose to conv_mm's
   //  64-position blocks -- batch-1 step 6.46 -> 6.53 ms; depth 8 at batch 4: step 12.16 -> 12.11 ms)
-  while (ks < ksmax && blocks * ks < m4_min_blocks() && d.R % 64 == 0 && nchunks / (ks * 2) >= 8) ks *= 2;
+  const char* mc = getenv("ADP_MM4_KS_MINCH");
+  const int64_t minch = mc ? atoll(mc) : 8;
+  const char* tg = getenv("ADP_MM4_KS_TARGET");
+  const int64_t target = tg ? atoll(tg) : m4_min_blocks();
+  while (ks < ksmax && blocks * ks < target && d.R % 64 == 0 && nchunks / (ks * 2) >= minch) ks *= 2;
   return ks;
 }
 
@@ -362,7 +366,7 @@ int64_t adp_conv_mm4_ksplit(const adp_conv_desc& d) {
 // 18.7 -> 21.3 -> 17.4; with one block per CU the light block loses (C=512 L=512 25.6 -> 22.5 -> 24.9).
 static int m4_nkg(const adp_conv_desc& d) {
   const char* e = getenv("ADP_MM4_LIGHT_MIN_BLOCKS");
-  const int64_t blocks = (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B;
+  const int64_t blocks = (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B * adp_conv_mm4_ksplit(d);
   return blocks >= (e ? atoll(e) : 400) ? 2 : 4;
 }
 

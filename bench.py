@@ -106,6 +106,22 @@ def _cpu_model() -> str:
     return "unknown"
 
 
+def winograd_fraction(kernel: str) -> float:
+    """Share of the direct-form flops a kernel instantiation EXECUTES on the matrix cores: 1/2 for the Winograd F(4,3) kernels
+    (conv_mm4, wgrad_mm's W4 flag, conv_tile32), 2/3 for F(2,3) (the WN flag of conv_mm / wgrad_mm), 1 otherwise.  The `roofline`
+    objects rate kernels in DIRECT-FORM flops (the work the reference's conv does), so an F(4,3) kernel can read above 1.0 of the
+    f32 MFMA peak; `frac_executed` = frac x this share is what the matrix pipes actually sustain."""
+    head, _, rest = kernel.partition("<")
+    args = [a.strip() for a in rest.rsplit(">", 1)[0].split(",")] if rest else []
+    if head.endswith("conv_mm4_kernel") or head.endswith("conv_tile32_kernel"):
+        return 0.5
+    if head.endswith("wgrad_mm_kernel") and len(args) >= 7:
+        return 0.5 if (len(args) >= 8 and args[7] == "true") else (2.0 / 3.0 if args[6] == "true" else 1.0)
+    if head.endswith("conv_mm_kernel") and len(args) >= 9:
+        return 2.0 / 3.0 if args[8] == "true" else 1.0
+    return 1.0
+
+
 def profiled_step(model, step):
     """Runs `step()` once with every C-ABI launch bracketed by HIP events on its launch stream; returns the records
     [(call, kernel, meta, ms), ...] (see audio_diffusion_pytorch_amd._C.profile_collect)."""
@@ -170,6 +186,10 @@ def roofline_leg(model, x, top: int = 14):
              "achieved": round(tf, 2) if mfma else round(gb, 1), "peak": PEAK_F32_MFMA_TFLOPS if mfma else PEAK_HBM_GBPS,
              "unit": "TFLOP/s" if mfma else "GB/s"}
         e["frac"] = round(e["achieved"] / e["peak"], 4)
+        if mfma:  # Winograd kernels: rated in direct-form flops, executing 1/2 (F(4,3)) or 2/3 (F(2,3)) of them
+            wf = winograd_fraction(name)
+            e["executed_share_of_direct_form_flops"] = round(wf, 4)
+            e["frac_executed"] = round(e["frac"] * wf, 4)
         t = pmc.get(name.split(" | ")[0])
         e["traffic"] = t.get("hbm_bytes_per_launch") if t else None
         e["traffic_source"] = ("stored rocprofv3 PMC pass of this command (profiles/pmc_traffic.json: separate FETCH_SIZE / "
@@ -232,6 +252,8 @@ def roofline_leg(model, x, top: int = 14):
         e = entry(k, a)
         table[k] = {"launches": e["launches"], "avg_us": e["avg_us"], "total_ms": round(a["ms"], 3),
                     "bound": e["bound"], "achieved": e["achieved"], "unit": e["unit"], "frac": e["frac"]}
+        if "frac_executed" in e:
+            table[k]["frac_executed"] = e["frac_executed"]
     return rf, hbm, table, round(total_ms, 3)
 
 

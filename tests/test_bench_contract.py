@@ -60,3 +60,14 @@ def test_clock_reader_never_raises():
     info = bench._read_clocks()
     assert isinstance(info, dict) and info
     json.dumps(info)
+
+
+def test_winograd_fraction_by_kernel_instantiation():
+    """The roofline objects rate kernels in direct-form flops; `frac_executed` needs the share each instantiation executes."""
+    f = bench.winograd_fraction
+    assert f("conv_mm4_kernel<false, 1, 64, 4>") == 0.5 and f("conv_tile32_kernel<false, 1, 16, true, false>") == 0.5
+    assert f("wgrad_mm_kernel<64, 3, 1, 1, 0, 1, true, true>") == 0.5
+    assert abs(f("wgrad_mm_kernel<64, 3, 1, 1, 0, 1, true, false>") - 2 / 3) < 1e-9
+    assert abs(f("conv_mm_kernel<64, 3, 1, 1, true, 0, 32, 2, true, 1>") - 2 / 3) < 1e-9
+    assert f("conv_mm_kernel<64, 1, 1, 1, true, 0, 32, 2, false, 1>") == 1.0 and f("gn_bwd_apply_vec_kernel<256>") == 1.0
+    assert f("wgrad_mm_kernel<64, 2, 2, 1, 0, 1, false, false>") == 1.0
