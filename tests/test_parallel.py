@@ -9,6 +9,16 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port() -> int:
+    """A port the OS hands out now (a fixed pid-derived port can still sit in TIME_WAIT from a previous run)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 CFG = dict(in_channels=2, channels=[8, 16], factors=[2, 2], items=[1, 1], modulation_features=32)
 
 
@@ -56,7 +66,7 @@ def _worker_cfg(rank, world, port, out_dir):
 def test_dp2_gloo_reduces_parameters_outside_the_unet(emul, tmp_path):
     import audio_diffusion_pytorch_amd as adp
     from test_unet import FixedSigmas
-    port = 30100 + (os.getpid() % 500)
+    port = _free_port()
     mp.spawn(_worker_cfg, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
     r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
@@ -126,7 +136,7 @@ def _worker(rank, world, port, out_dir):
 def test_dp2_gloo_equals_single_process(emul, tmp_path):
     import audio_diffusion_pytorch_amd as adp
     from test_unet import FixedSigmas
-    port = 29500 + (os.getpid() % 500)
+    port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
     r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
@@ -155,7 +165,7 @@ def test_dp2_gloo_equals_single_process(emul, tmp_path):
 
 def _run_rccl_workers(world):
     import subprocess
-    port = str(30700 + (os.getpid() % 500))
+    port = str(_free_port())
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_rccl_worker.py"), str(r), str(world), port],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
