@@ -104,6 +104,7 @@ SIGNATURES = {
     "adp_probe_copy": (c_int, [P, P, I, P]),
     "adp_probe_mfma": (I, [I, P, I, P]),
     "adp_probe_launch": (c_int, [I, P]),
+    "adp_probe_chase": (c_int, [P, I, P, P]),
 }
 
 

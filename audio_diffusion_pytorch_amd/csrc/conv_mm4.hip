@@ -343,11 +343,13 @@ bool adp_conv_mm4_eligible(const adp_conv_desc& d) {
   return (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B * adp_conv_mm4_ksplit(d) >= m4_min_blocks();
 }
 
-// Cross-workgroup K split of the F(4,3) block: 2 / 4 slices (>= 4 chunks of 64 channels each) when the tiles alone leave the
-// chip half empty -- the [4, 1024, 128] layers of depth 8 are 128 tiles.  ADP_MM4_KS_MAX caps it (1 = never: A/B, default 2).
+// Cross-workgroup K split of the F(4,3) block: 2 / 4 slices when the tiles alone leave the chip half empty -- the [4, 1024, 128]
+// layers of depth 8 are 128 tiles.  OFF by default (ADP_MM4_KS_MAX=2 / 4 switches it on): measured at batch 4 it is worth
+// 12.16 -> 12.11 ms and 11.90 -> 11.875 ms per step (the reduce launch eats most of what the matrix cores save) for 32 more
+// launches per step; depth 8 stays on conv_mm's 64-position F(2,3) blocks.
 int64_t adp_conv_mm4_ksplit(const adp_conv_desc& d) {
   const char* e = getenv("ADP_MM4_KS_MAX");
-  const int64_t ksmax = e ? atoll(e) : 2;
+  const int64_t ksmax = e ? atoll(e) : 1;
   const int64_t blocks = (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B, nchunks = d.R / 64;
   int64_t ks = 1;
   // (every slice keeps >= 8 chunks of 64 channels: at batch 1 the 512-channel layers would qualify with 4 and lose to conv_mm's

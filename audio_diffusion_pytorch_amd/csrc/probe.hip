@@ -3,6 +3,7 @@
 //   adp_probe_copy    16-byte streaming copy                     -> HBM GB/s
 //   adp_probe_mfma    register-only v_mfma_f32_32x32x2_f32 loop  -> exact-f32 matrix TFLOP/s
 //   adp_probe_launch  an empty kernel                            -> dependent-launch gap inside a hipGraph
+//   adp_probe_chase   one lane following a pointer chain         -> load-to-use latency of L2 / Infinity Cache / HBM
 #include "adp_rt.h"
 #include "adp.h"
 
@@ -36,6 +37,14 @@ __global__ __launch_bounds__(256) void probe_mfma_kernel(int64_t iters, float* o
 
 __global__ void probe_empty_kernel() {}
 
+// one lane, `steps` dependent loads: i = chain[i]; the chain is a random cycle over cache lines the host built
+__global__ __launch_bounds__(64) void probe_chase_kernel(const int* __restrict__ chain, int64_t steps, int* out) {
+  if (threadIdx.x != 0) return;
+  int i = 0;
+  for (int64_t s = 0; s < steps; ++s) i = chain[i];
+  out[0] = i;
+}
+
 }  // namespace
 
 extern "C" int adp_probe_copy(const float* src, float* dst, int64_t n, void* stream) {
@@ -60,5 +69,12 @@ extern "C" int64_t adp_probe_mfma(int64_t iters, float* out, int64_t out_elems, 
 extern "C" int adp_probe_launch(int64_t workgroups, void* stream) {
   if (workgroups <= 0 || workgroups > 65535) return ADP_ERR_SHAPE;
   ADP_LAUNCH(probe_empty_kernel, dim3((unsigned)workgroups), dim3(64), stream);
+  return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_probe_chase(const int32_t* chain, int64_t steps, int32_t* out, void* stream) {
+  if (!chain || !out) return ADP_ERR_NULL;
+  if (steps <= 0) return ADP_ERR_SHAPE;
+  ADP_LAUNCH(probe_chase_kernel, dim3(1), dim3(64), stream, chain, steps, out);
   return ADP_LAUNCH_OK();
 }

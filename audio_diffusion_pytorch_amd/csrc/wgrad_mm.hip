@@ -453,7 +453,12 @@ static int64_t wg_split(int64_t tiles, int64_t total, int64_t target) {
   return ns;
 }
 
-WgPlan wg_plan(const adp_wgrad_desc& d) {
+// `n` > 1: the plan of a BATCHED launch (adp_conv1d_wgrad_batch: n same-shape items, blockIdx.x = item * nsplit + split).  The
+// items fill the chip together, so each needs 1/n of the position split a lone launch takes: fewer (or no) partial tiles written
+// and read back, longer K loops per workgroup, and for the 512-channel layers (64 tiles x 4 items) no second stage at all.  The tile
+// edge is the lone launch's (the scratch was sized for that plan; a batched plan never needs more).  ADP_WGRAD_BATCH_SPLIT=0: every
+// item keeps the lone split (A/B; then batched and lone calls are bit-identical, otherwise they differ in summation order).
+WgPlan wg_plan(const adp_wgrad_desc& d, int n = 1) {
   WgPlan p;
   p.nkg = 4;
   p.cpb = adp_cdiv(d.N, WG_BKN);
@@ -465,7 +470,11 @@ WgPlan wg_plan(const adp_wgrad_desc& d) {
   // 64x64 tiles unless they leave most CUs idle while 32x32 tiles (4x as many, half the staging per workgroup) do not
   p.bm = (can64 && (t64 * ns64 >= 200 || t32 * ns32 <= 3 * t64 * ns64)) ? 64 : 32;
   // (32 x 32 tiles WITHOUT the position split were measured for the 512-channel layers: batch 4 +0.13 ms, batch 1 -0.08 ms)
-  const int64_t ns = p.bm == 64 ? ns64 : ns32;
+  int64_t ns = p.bm == 64 ? ns64 : ns32;
+  if (n > 1) {
+    const char* e = getenv("ADP_WGRAD_BATCH_SPLIT");
+    if (!e || e[0] != '0') ns = p.bm == 64 ? wg_split(t64 * n, total, 256) : wg_split(t32 * n, total, 768);
+  }
   p.cps = adp_cdiv(total, ns);
   p.nsplit = adp_cdiv(total, p.cps);
   return p;
@@ -602,7 +611,7 @@ bool wg_winograd4(const adp_wgrad_desc& d);
 
 template <int KT, int S, int UP, int PRO, bool WN = false>
 int pick_wg(const adp_wgrad_desc* ds, int n, void* stream) {
-  const WgPlan p = wg_plan(ds[0]);
+  const WgPlan p = wg_plan(ds[0], n);
   if constexpr (WN) {  // the F(4,3) form of the kernel-3 weight gradients (wg_winograd4)
     if (wg_winograd4(ds[0])) {
       if (p.bm == 64) return launch_wg<64, KT, S, UP, PRO, true, true>(ds, n, p, stream);

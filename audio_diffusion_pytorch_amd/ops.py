@@ -91,7 +91,10 @@ class WgradPark:
 
     # whole weight-gradient CALLS are collected too (`calls`): small problems, where the inputs of a block side's gradients stay
     # in the Infinity Cache until the side is done, run as one launch per shape (adp_conv1d_wgrad_batch)
-    BATCH_BYTES = 24 << 20  # x + dy of one call; above it only the second stage is parked
+    # x + dy of one call; above it only the second stage is parked.  (Round 4: 24 MB, 40 / 80 within noise.  Round 5, with the
+    # batch-aware position split of adp_conv1d_wgrad_batch -- an item of a batched launch takes 1/n of the lone split: 24 -> 40 ->
+    # 80 MB 12.77 -> 12.72 -> 12.68 ms per step; 80 MB covers every layer of the README configuration)
+    BATCH_BYTES = 80 << 20
 
     def __init__(self):
         self.items = []  # (key = (partials, cnt, M, accumulate, has_bias), ws, dw, dbias)

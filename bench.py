@@ -388,6 +388,37 @@ def calibration(dev, busy=None):
                 _C.call("adp_probe_launch", 1, _C.stream())
         out["graph_launch_gap_us"] = round(ev_ms(g.replay, 10) * 10.0, 3)  # ms per 100 launches -> us per launch
         del g
+        # small dependent kernels (what two thirds of a step's launches are): 4 MB and 16 MB float4 copies, a -> b -> a ..., 50
+        # per hipGraph: launch gap + first-load latency + drain per kernel, the working set resident in the Infinity Cache
+        small = {}
+        for mb in (4, 16):
+            nn = mb << 18
+            pa, pb = torch.randn(nn, device=dev), torch.empty(nn, device=dev)
+            _C.call("adp_probe_copy", ptr(pa), ptr(pb), nn, _C.stream())
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for i in range(50):
+                    s_, d_ = (pa, pb) if i % 2 == 0 else (pb, pa)
+                    _C.call("adp_probe_copy", ptr(s_), ptr(d_), nn, _C.stream())
+            small[f"{mb}MB"] = round(ev_ms(g.replay, 5) * 1e3 / 50, 3)
+            del g, pa, pb
+        out["small_copy_us_per_launch"] = small
+        # load-to-use latency: one lane chasing a random cycle of 64-byte lines over working sets that sit in the L2 (1 MB),
+        # the Infinity Cache (64 MB) and HBM (2 GB)
+        lat = {}
+        for label, mbytes in (("1MB", 1), ("64MB", 64), ("2GB", 2048)):
+            lines = mbytes << 14  # 64-byte lines
+            perm = torch.randperm(lines, device=dev, dtype=torch.int32)
+            chain = torch.zeros(lines * 16, dtype=torch.int32, device=dev)
+            chain[perm.long() * 16] = torch.roll(perm, -1) * 16
+            # (line 0 is on the cycle like every line: the walk starts there)
+            o = torch.zeros(1, dtype=torch.int32, device=dev)
+            steps = 40000  # (the first few thousand hops of a freshly written chain still hit the caches)
+            fn = lambda: _C.call("adp_probe_chase", ptr(chain, torch.int32), steps, ptr(o, torch.int32), _C.stream())  # noqa: E731
+            lat[label] = round(ev_ms(fn, 3) * 1e6 / steps, 1)
+            del perm, chain
+        out["load_latency_ns"] = lat
     except Exception as e:
         out["error"] = f"{type(e).__name__}: {e}"
     out["clocks_idle"] = _read_clocks()
@@ -401,7 +432,8 @@ def calibration(dev, busy=None):
             out["clocks_under_load"] = {"error": f"{type(e).__name__}: {e}"}
     out["what"] = ("probes of csrc/probe.hip timed with HIP events in this process before the timed window: 256 MB float4 copy "
                    "(read + write bytes / time; 6290 GB/s is the best copy this pool has shown), register-only v_mfma_f32_32x32x2 "
-                   f"loop against the {PEAK_F32_MFMA_TFLOPS} TF peak, hipGraph of 100 dependent empty kernels")
+                   f"loop against the {PEAK_F32_MFMA_TFLOPS} TF peak, hipGraph of 100 dependent empty kernels, hipGraphs of 50 dependent small "
+                   "copies (per launch), one lane chasing a random cycle of cache lines (ns per dependent load)")
     return out
 
 

@@ -351,8 +351,12 @@ int adp_pool_sum(const float* x, int64_t rows, int64_t Lout, int64_t f, const fl
  *                      register operands; out receives one float per thread (out_elems >= 512 * 256); returns the
  *                      launch's flops (negative: error code)                                        -> f32 matrix TFLOP/s
  *   adp_probe_launch : an empty kernel of `workgroups` single-wave workgroups                       -> launch gap
+ *   adp_probe_chase  : ONE lane follows `steps` dependent loads i = chain[i] from i = 0 (chain: int32 indices forming a cycle
+ *                      the host laid out over the working set it wants to probe), out[0] = the final index
+ *                                                                                       -> load-to-use latency (L2 / MALL / HBM)
  * ------------------------------------------------------------------------------------------ */
 int adp_probe_copy(const float* src, float* dst, int64_t n, void* stream);
+int adp_probe_chase(const int32_t* chain, int64_t steps, int32_t* out, void* stream);
 int64_t adp_probe_mfma(int64_t iters, float* out, int64_t out_elems, void* stream);
 int adp_probe_launch(int64_t workgroups, void* stream);
 

@@ -881,13 +881,15 @@ def test_wgrad_direct_family(dev, B, R, M, L, KT, stride, pad, up):
         assert rel_err(dw2, dw_ref) < TOL
 
 
-@pytest.mark.parametrize("whole", [False, True])
+@pytest.mark.parametrize("whole,split", [(False, "1"), (True, "0"), (True, "1")])
 @pytest.mark.parametrize("C,L,n,bias,acc", [(32, 4096, 3, True, False), (64, 2048, 10, True, True), (32, 2048, 2, False, False)])
-def test_wgrad_parked_second_stage(dev, C, L, n, bias, acc, whole):
+def test_wgrad_parked_second_stage(dev, C, L, n, bias, acc, whole, split, monkeypatch):
     """Parked weight gradients (ops.WgradPark).  whole = False: adp_wgrad_desc.accumulate bit 1 + adp_wgrad_reduce_batch -- n
     same-shape split weight gradients leave their partial slices in their own scratch and are summed by one launch per 8.
     whole = True: the calls themselves wait and run as one launch per 8 (adp_conv1d_wgrad_batch: blockIdx.x = item * splits +
-    split) + one batched second stage.  Same result as the plain calls either way (bitwise: same arithmetic, same order)."""
+    split) + one batched second stage.  Same result as the plain calls (bitwise: same arithmetic, same order) -- except that a
+    batched launch, whose items fill the chip together, splits each item's positions n times less (ADP_WGRAD_BATCH_SPLIT=0 keeps
+    the lone split): then the partial sums group differently and the results agree to rounding."""
     B = 2
     park = ops.WgradPark()
     if not whole:
@@ -903,12 +905,18 @@ def test_wgrad_parked_second_stage(dev, C, L, n, bias, acc, whole):
         outs.append((dw, db))
         refs.append((dw_ref, db_ref))
     assert len(park.calls if whole else park.items) == n, "these shapes must take the split matrix-core path"
+    monkeypatch.setenv("ADP_WGRAD_BATCH_SPLIT", split)
     park.flush()
     assert not park.items and not park.calls
     for (dw, db), (dw_ref, db_ref) in zip(outs, refs):
-        assert torch.equal(dw.cpu(), dw_ref.cpu())
-        if bias:
-            assert torch.equal(db.cpu(), db_ref.cpu())
+        if split == "0" or not whole:  # the items keep the lone launch's position split: same arithmetic, same order
+            assert torch.equal(dw.cpu(), dw_ref.cpu())
+            if bias:
+                assert torch.equal(db.cpu(), db_ref.cpu())
+        else:  # a batched launch splits every item's positions n times less (round 5): another summation order
+            assert rel_err(dw, dw_ref) < 1e-5
+            if bias:
+                assert rel_err(db, db_ref) < 1e-5
 
 
 # ------------------------------------------------------------------ GroupNorm+SiLU backward
@@ -1190,5 +1198,13 @@ def test_calibration_probes(dev):
     tile = torch.einsum("ki,kj->ij", a, b) * iters                  # one accumulator tile after `iters` MFMAs
     assert abs(out.cpu().double().sum().item() / (512 * 4 * 4) - tile.sum().item()) < 1e-3 * tile.sum().item()
     _C.call("adp_probe_launch", 3, _C.stream())
+    # the latency probe walks the cycle the host laid out: 7 lines of 16 ints, 0 -> 3 -> 5 -> 1 -> 6 -> 2 -> 4 -> 0
+    order = [0, 3, 5, 1, 6, 2, 4]
+    chain = torch.zeros(7 * 16, dtype=torch.int32)
+    for a, b in zip(order, order[1:] + order[:1]):
+        chain[a * 16] = b * 16
+    o = torch.zeros(1, dtype=torch.int32).to(dev)
+    _C.call("adp_probe_chase", _C.ptr(chain.to(dev), torch.int32), 10, _C.ptr(o, torch.int32), _C.stream())
+    assert int(o.cpu()) == order[10 % 7] * 16
     assert _C.lib().adp_probe_copy(None, None, 4, 0) == -5 and _C.lib().adp_probe_launch(0, 0) == -1
     assert _C.lib().adp_probe_mfma(1, _C.ptr(out), 16, 0) == -1
