@@ -11,6 +11,7 @@ Linear over channels is a 1x1 conv on the MFMA conv kernel; the attention core i
 projections exactly as the convs produce them (k and v are the two channel halves of one to_kv output) and
 never materialises the [n, m] score matrix; the residual add is the out-projection's epilogue.
 """
+import os
 from typing import Optional
 
 import torch
@@ -37,6 +38,10 @@ class CtxBank:
                  for t, p in zip(net.item_types[d], mods) if t == "cross_attention"]
         if len(items) < 2:
             return None
+        # the folded weights and their gradient live for the whole step (2 x I * 2HD * E floats: ~200 MB in config 4): a cap
+        M2_, E_ = items[0].to_kv.weight.shape
+        if 8 * len(items) * M2_ * E_ > (int(os.environ.get("ADP_CTX_BANK_MAX_MB", "4096")) << 20):
+            return None  # (per-item path: nothing is kept beyond an item's own backward)
         dev = context.device
         ptrs = tuple(t.data_ptr() for p in items for t in (p.to_kv.weight, p.norm_context.weight, p.norm_context.bias))
         cache = getattr(net, "_ctx_tables", None)
