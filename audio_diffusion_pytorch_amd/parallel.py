@@ -32,6 +32,27 @@ def graph_safe_rccl_env() -> None:
     os.environ.setdefault("TORCH_NCCL_DUMP_ON_TIMEOUT", "0")
 
 
+def capture_step(step, warmup: int = 2):
+    """Captures `step()` -- a whole training step through a DataParallel wrapper, collectives included -- in a hipGraph and
+    returns (graph, replay).  `warmup` eager steps run first on a side stream (RCCL communicators, allocator pools and lazily
+    built tables must exist before the capture).  The capture uses capture_error_mode="thread_local": ProcessGroupNCCL's
+    watchdog thread may still be polling the events of the EAGER warm-up collectives while the capture is open, and in the
+    default "global" mode an event query from ANY thread aborts the process (seen once in five runs of the `dp1` leg); works
+    issued under capture are not handed to the watchdog at all.  Call with gradients set to None (the captured AccumulateGrad
+    then adopts views of the flat gradient buffer, as in the eager step)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        step()
+    return graph, graph.replay
+
+
 def init_process_group_from_env(backend: Optional[str] = None, graph_safe: bool = True) -> int:
     """Initialises torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).  `graph_safe`
     (default): with the settings of graph_safe_rccl_env, so that the data-parallel step can be replayed from a hipGraph."""

@@ -484,7 +484,7 @@ def _dp1_worker() -> None:
             ov = {"error": f"{type(e).__name__}: {e}"}
         # the same two steps replayed from hipGraphs: the wrapped one holds its RCCL all-reduces (what bench.py times at N > 1)
         try:
-            t_dp_graph = _time(_graphed(step, zero), 20)
+            t_dp_graph = _time(_graphed(step, zero, mode="thread_local"), 20)
         except Exception as e:
             t_dp_graph = None
             graph_err = f"{type(e).__name__}: {e}"
@@ -492,7 +492,7 @@ def _dp1_worker() -> None:
         dp.unet._grad_ready_hook = None
         t_plain2 = _time(plain, reps, warmup=2)  # (again after the wrapped steps: same clocks / allocator state)
         t_ref = min(t_plain, t_plain2)
-        t_plain_graph = _time(_graphed(plain, zero), 20)
+        t_plain_graph = _time(_graphed(plain, zero, mode="thread_local"), 20)
         graphs = ({"ms_per_step": round(t_dp_graph * 1e3, 3), "ms_per_step_without_wrapper": round(t_plain_graph * 1e3, 3),
                    "dp_over_plain": round(t_dp_graph / t_plain_graph, 4)} if t_dp_graph is not None
                   else {"error": graph_err, "ms_per_step_without_wrapper": round(t_plain_graph * 1e3, 3)})
@@ -541,8 +541,9 @@ def dp1_leg(timeout: float = 240.0):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def _graphed(step, zero):
-    """Captures `step` in a hipGraph (after two eager warm-ups on a side stream); returns the replay callable."""
+def _graphed(step, zero, mode="global"):
+    """Captures `step` in a hipGraph (after two eager warm-ups on a side stream); returns the replay callable.
+    mode = "thread_local" for steps that hold RCCL collectives (see parallel.capture_step)."""
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -552,7 +553,7 @@ def _graphed(step, zero):
     torch.cuda.synchronize()
     zero()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, capture_error_mode=mode):
         step()
     return graph.replay
 
@@ -746,7 +747,8 @@ def main():
             torch.cuda.synchronize()
             zero()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # (with RCCL: thread_local -- the watchdog thread may still poll the warm-up collectives' events: parallel.capture_step)
+            with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
                 static_loss = model(x)
                 static_loss.backward()
         except Exception as e:  # capture is a launch-overhead optimisation only; the kernels are identical

@@ -67,21 +67,15 @@ def main():
     eager = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
     args = (x[sl].to(dev),)
     kw = dict(noise=noise[sl].to(dev), embedding=emb[sl].to(dev), embedding_mask_proba=0.5, batch_mask=mask[sl].to(dev))
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
+    from audio_diffusion_pytorch_amd.parallel import capture_step
+
+    def one_step():
         for p in model.parameters():
             p.grad = None
         dp(*args, **kw).backward()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    for p in model.parameters():
-        p.grad = None
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        dp(*args, **kw).backward()
+    g, replay = capture_step(one_step, warmup=1)
     for _ in range(2):
-        g.replay()
+        replay()
     torch.cuda.synchronize()
     for (name, p), e in zip(model.named_parameters(), eager):
         assert (p.grad is None) == (e is None), name

@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from audio_diffusion_pytorch_amd import parallel  # noqa: E402
 
-mode = sys.argv[1] if len(sys.argv) > 1 else "thread_local"
+mode = sys.argv[1] if len(sys.argv) > 1 else "thread_local"  # ("global" can abort: the watchdog polls the warm-up collectives)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 torch.cuda.set_device(0)
 dist.init_process_group(backend="nccl", rank=0, world_size=1)
