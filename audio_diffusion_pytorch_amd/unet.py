@@ -349,9 +349,11 @@ class UNetV0Net(nn.Module):
         1-2 ms of host time -- four of them per step were a tenth of an eager step (the data-parallel path at N > 1 is eager).
         The Parameter objects of a built net never change (`.to()` swaps their storage, not the objects)."""
         cached = getattr(self, "_named_cache", None)
-        if cached is None:
+        if cached is None or getattr(self, "_named_cache_of", None) != id(self):
+            # (a copy.deepcopy of the net -- an EMA copy -- carries the original's cache, whose id() keys name other objects)
             cached = self._named_cache = list(self.named_parameters())
             self._pname_cache = {id(p): n for n, p in cached}
+            self._named_cache_of = id(self)
         return cached
 
     def _param_offsets(self):

@@ -403,3 +403,21 @@ def test_parked_weight_gradients_are_final_at_the_block_hook(dev):
     assert seen["parked"] > 0, "the test shape must take the split matrix-core weight gradient"
     assert seen["calls"] > 0
 
+
+
+def test_deepcopy_of_a_net_keeps_working(emul):
+    """An EMA-style copy.deepcopy of a net that has already run (its per-net caches -- parameter list, id() -> name map, flat
+    gradient offsets -- are built) must not reuse the original's caches: the copy's step gives the original's gradients."""
+    import copy
+    torch.manual_seed(0)
+    net = adp.UNetV0(dim=1, **TINY)
+    x, t = torch.randn(2, 2, 64), torch.tensor([0.3, 0.7])
+    net(x, t).square().mean().backward()
+    ref = {n: p.grad.clone() for n, p in net.named_parameters()}
+    twin = copy.deepcopy(net)
+    for p in twin.parameters():
+        p.grad = None
+    twin(x, t).square().mean().backward()
+    for n, p in twin.named_parameters():
+        assert torch.equal(p.grad, ref[n]), n
+    assert all(a is not b for a, b in zip(net.parameters(), twin.parameters()))
