@@ -33,11 +33,26 @@ constexpr int M4_NPG = 2, M4_NLD = 4;
 constexpr int M4_NLT = M4_NLD * 64;
 constexpr int M4_XSP = M4_BN + 8, M4_XQ = M4_XSP / 4;         // X row: positions n0-4 .. n0+131
 
+// four consecutive virtual positions u0..u0+3 (u0 % 4 == 0) of a row upsampled by UP: 4 / 2 / 1 source floats (UpsampleItem:
+// the [B, C, L*UP] intermediate is never materialised; the LDS tile holds virtual positions, so the MMA waves see a plain conv)
+template <int UP>
+__device__ __forceinline__ f32x4 m4_load_xquad(const float* p) {
+  if (UP == 1) return *reinterpret_cast<const f32x4*>(p);
+  if (UP == 2) {
+    const f32x2 t = *reinterpret_cast<const f32x2*>(p);
+    return f32x4{t[0], t[0], t[1], t[1]};
+  }
+  const float t = *p;
+  return f32x4{t, t, t, t};
+}
+
 // BKT: channels per staged chunk (32, or 64: half the barriers per K, 16 channels per K group and chunk)
 // NKG: K groups (MMA waves per plane group): 4 = the 12-wave block of the long-K layers (one per CU: 96 KB of partial tiles);
 //      2 = an 8-wave block with 60 KB of LDS for the short-K layers -- two of them share a CU, one's loads / exchange / stores
 //      under the other's MFMAs (a 4-chunk K loop is all ramp and drain otherwise)
-template <bool TR, int PD, int BKT, int M4_NKG>
+// UP: nearest-upsample factor folded into the X loader (the UpsampleItem convs); store mode 2 (runtime: the pooled store of
+//     their data gradients -- sums of sp = 2 / 4 adjacent outputs of the lane's quad, 8- / 4-byte stores, + residual)
+template <bool TR, int PD, int BKT, int M4_NKG, int UP = 1>
 __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64) void conv_mm4_kernel(adp_conv_desc d) {
   constexpr int M4_NMMA = M4_NKG * M4_NPG, RPW = 16 / M4_NMMA;  // accumulator rows finished per wave (2 or 4)
   constexpr int M4_RED = M4_NKG * 6 * 1024;                     // parked partial tiles
@@ -93,10 +108,10 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64) void conv_mm4_kern
     for (int i = 0; i < M4_NX4; ++i) {
       const int e = (lt + i * M4_NLT) % (BKT * M4_XQ);
       const int rl = e / M4_XQ, pq = e - rl * M4_XQ;
-      const int u = n0 - 4 + 4 * pq;
+      const int u = n0 - 4 + 4 * pq;  // (virtual position on the upsampled row)
       x_dst[i] = rl * XSP + 4 * pq;
-      x_ok[i] = (u >= 0 && u < L);  // L % 4 == 0: a quad is entirely inside or outside the row
-      x_src[i] = rl * L + (x_ok[i] ? u : 0);
+      x_ok[i] = (u >= 0 && u < L * UP);  // (L * UP) % 4 == 0: a quad is entirely inside or outside the row
+      x_src[i] = rl * L + (x_ok[i] ? u / UP : 0);  // nearest upsample: source index = floor(u / UP), exact
     }
     f32x4 ra[PD][M4_NA4], rx[PD][M4_NX4];
     auto load_chunk = [&](f32x4 (&a)[M4_NA4], f32x4 (&x)[M4_NX4], int chunk) {
@@ -106,7 +121,7 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64) void conv_mm4_kern
       for (int i = 0; i < M4_NA4; ++i) a[i] = *reinterpret_cast<const f32x4*>(wp + a_src[i]);
       const float* xp = xb + (int64_t)rn * L;
 #pragma unroll
-      for (int i = 0; i < M4_NX4; ++i) x[i] = *reinterpret_cast<const f32x4*>(xp + x_src[i]);
+      for (int i = 0; i < M4_NX4; ++i) x[i] = m4_load_xquad<UP>(xp + x_src[i]);
     };
     auto store_chunk = [&](const f32x4 (&a)[M4_NA4], const f32x4 (&x)[M4_NX4], int chunk) {
       float* Ab = smem + (chunk & 1) * (M4_A_ELEMS + M4_X_ELEMS);
@@ -158,7 +173,7 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64) void conv_mm4_kern
     pre_bias[rr] = d.bias ? d.bias[mc] : 0.0f;
     pre_scale[rr] = d.e_scale ? d.e_scale[b * (d.e_bstride ? d.e_bstride : M) + mc] : 1.0f;
     pre_res[rr] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (d.res && m < M && nq < N && KS == 1) pre_res[rr] = *reinterpret_cast<const f32x4*>(d.res + ((int64_t)b * M + m) * N + nq);
+    if (d.res && m < M && nq < N && KS == 1 && d.store == 0) pre_res[rr] = *reinterpret_cast<const f32x4*>(d.res + ((int64_t)b * M + m) * N + nq);
   }
 
   const int xfrag = 4 * hi * XSP + 4 * l31 + 4;                         // + (ci + cc) * XSP: the lane's input quad d1..d4
@@ -264,6 +279,23 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64) void conv_mm4_kern
 #pragma unroll
     for (int k = 0; k < 4; ++k) vfin[rr][k] = 0.0f;
     if (!ok) continue;
+    if (d.store == 2) {  // pooled store (gradient of the nearest upsample): sums of sp adjacent positions, no bias
+      if (d.sp == 2) {
+        const int64_t o = ((int64_t)b * M + m) * (N / 2) + nq / 2;
+        f32x2 v{y[0] + y[1], y[2] + y[3]};
+        if (d.res) {
+          const f32x2 r2 = *reinterpret_cast<const f32x2*>(d.res + o);
+          v[0] += r2[0], v[1] += r2[1];
+        }
+        *reinterpret_cast<f32x2*>(d.out + o) = v;
+      } else {
+        const int64_t o = ((int64_t)b * M + m) * (N / 4) + nq / 4;
+        float v = (y[0] + y[1]) + (y[2] + y[3]);
+        if (d.res) v += d.res[o];
+        d.out[o] = v;
+      }
+      continue;
+    }
     if (KS > 1) {  // raw partial tile; the epilogue runs in the reduce kernel
       *reinterpret_cast<f32x4*>(d.ws + (((int64_t)ks * d.B + b) * M + m) * N + nq) = y;
       continue;
@@ -281,7 +313,7 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64) void conv_mm4_kern
 
   // ---- GroupNorm partial statistics of the tile just stored: one (mean, M2, count) entry per (the RPW rows of a row quad this
   // wave finished: half a quad or all of it) x (128-position tile); the consumer Chan-combines the entries whatever their counts
-  if (d.gn_part != nullptr && n0 < N && KS == 1) {
+  if (d.gn_part != nullptr && n0 < N && KS == 1 && d.store == 0) {
     const int cntv = (N - n0) < M4_BN ? (N - n0) : M4_BN;
     const float fcnt = (float)RPW * (float)cntv;
     float sv = 0.0f;
@@ -328,9 +360,16 @@ bool adp_conv_mm4_eligible(const adp_conv_desc& d) {
   if (!adp_winograd_enabled()) return false;
   const char* e = getenv("ADP_CONV_WINO4");
   if (e && e[0] == '0') return false;
-  if (d.KT != 3 || d.stride != 1 || d.dil != 1 || d.pad != 1 || d.up != 1 || d.R1 != d.R || d.x2) return false;
-  if (d.prologue != 0 || d.store != 0) return false;
-  if (d.N != d.Lin || d.N % 4 != 0) return false;
+  if (d.KT != 3 || d.stride != 1 || d.dil != 1 || d.pad != 1 || d.R1 != d.R || d.x2) return false;
+  if (d.up != 1 && !((d.up == 2 || d.up == 4) && !d.transposed && d.store == 0)) return false;   // UpsampleItem conv (forward)
+  if (d.prologue != 0) return false;
+  if (d.store != 0 && !(d.store == 2 && (d.sp == 2 || d.sp == 4) && d.up == 1 && !d.bias && !d.e_scale && !d.out_pre))
+    return false;  // plain store, or the pooled store of the UpsampleItem convs' data gradients
+  if (d.N != d.Lin * d.up || d.N % 4 != 0) return false;
+  {
+    const char* eu = getenv("ADP_MM4_UP");  // (A/B: "0" keeps the UpsampleItem convs and their data gradients on conv_mm)
+    if (eu && eu[0] == '0' && (d.up != 1 || d.store != 0)) return false;
+  }
   const char* mr = getenv("ADP_WINO4_MIN_R");
   // (from 128 channels: the materialised-activation layers; with the 12-wave block only, the short-K layers of depths 3-4 lost
   //  to conv_mm's wide-N F(2,3) blocks -- 12.22 vs 12.15 ms per step -- the light block wins them back: m4_nkg)
@@ -351,6 +390,7 @@ int64_t adp_conv_mm4_ksplit(const adp_conv_desc& d) {
   const char* e = getenv("ADP_MM4_KS_MAX");
   const int64_t ksmax = e ? atoll(e) : 1;
   const int64_t blocks = (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B, nchunks = d.R / 64;
+  if (d.store != 0) return 1;  // (the pooled store keeps its in-kernel epilogue)
   int64_t ks = 1;
   // (every slice keeps >= 8 chunks of 64 channels: at batch 1 the 512-channel layers would qualify with 4 and lose to conv_mm's
   //  64-position blocks -- batch-1 step 6.46 -> 6.53 ms; depth 8 at batch 4: step 12.16 -> 12.11 ms)
@@ -373,6 +413,7 @@ static int m4_nkg(const adp_conv_desc& d) {
 }
 
 int64_t adp_conv_mm4_gn_entries(const adp_conv_desc& d) {
+  if (d.store != 0) return 0;
   if (d.ws && adp_conv_mm4_ksplit(d) > 1) return adp_conv_splitk_gn_entries(d);
   return (m4_nkg(d) == 2 ? 1 : 2) * adp_cdiv(d.N, M4_BN);
 }
@@ -381,6 +422,20 @@ int adp_conv_mm4(const adp_conv_desc& d, void* stream) {
   const int64_t blocks = (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B;
   const int64_t ks = d.ws ? adp_conv_mm4_ksplit(d) : 1;  // (without the caller's scratch: the unsplit path, still correct)
   const dim3 grid((unsigned)blocks, (unsigned)ks);
+  if (d.up != 1) {  // UpsampleItem convs: the light block for grids of two blocks per CU, else 64-channel chunks (32 when R % 64)
+    const bool light = m4_nkg(d) == 2, c64 = d.R % 64 == 0;
+    const dim3 block(((light ? 2 : 4) * M4_NPG + M4_NLD) * 64);
+    if (d.up == 2) {
+      if (light) ADP_LAUNCH((conv_mm4_kernel<false, 1, 32, 2, 2>), grid, block, stream, d);
+      else if (c64) ADP_LAUNCH((conv_mm4_kernel<false, 1, 64, 4, 2>), grid, block, stream, d);
+      else ADP_LAUNCH((conv_mm4_kernel<false, 1, 32, 4, 2>), grid, block, stream, d);
+    } else {
+      if (light) ADP_LAUNCH((conv_mm4_kernel<false, 1, 32, 2, 4>), grid, block, stream, d);
+      else if (c64) ADP_LAUNCH((conv_mm4_kernel<false, 1, 64, 4, 4>), grid, block, stream, d);
+      else ADP_LAUNCH((conv_mm4_kernel<false, 1, 32, 4, 4>), grid, block, stream, d);
+    }
+    return ADP_LAUNCH_OK();
+  }
   if (m4_nkg(d) == 2) {  // light block: 32-channel chunks (60 KB of LDS: two blocks per CU)
     const dim3 block((2 * M4_NPG + M4_NLD) * 64);
     if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 32, 2>), grid, block, stream, d);
