@@ -64,6 +64,7 @@ SIGNATURES = {
     "adp_gn_silu_bwd_apply": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, I, P]),
     "adp_gn_param_grad": (c_int, [P, I, I, I, P, P, I, P]),
     "adp_modulation_fwd": (c_int, [P, P, I, I, I, I, F, P, P, P]),
+    "adp_modulation_ln_fwd": (c_int, [P, P, I, I, I, I, F, P, P, F, P, P, P, P, P, P, P, P]),
     "adp_chan_ln_bwd_ws_bytes": (I, [I, I, I]),
     "adp_modulation_bwd": (c_int, [P, P, P, I, P, I, I, I, P, P, I, P, P]),
     "adp_modulation_bwd_partial": (I, [P, P, P, I, P, I, I, I, P, P, P]),

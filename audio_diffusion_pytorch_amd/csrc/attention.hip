@@ -18,6 +18,7 @@
 // n = 1024).  Without LDS and barriers the waves free-run, several per SIMD, and hide each other's L2 latency.
 // The dk/dv pass splits the QUERY range over several waves when there are few key tiles (cross attention: m = 64
 // keys x n = 4096 queries) and sums the partial tiles in a second, deterministic stage.  D <= 64, multiple of 2.
+#include <stdlib.h>
 #include "adp_rt.h"
 #include "adp.h"
 
@@ -284,16 +285,18 @@ __global__ __launch_bounds__(256) void attn_sum_splits_kernel(const float* part,
 // grid.x = ceil(key tiles x nsplit / 4); split sp covers query tiles [sp * tps, (sp + 1) * tps).  With nsplit > 1 the
 // partial [D, 32] tiles go to part[sp] (addressed like dk / dv) and attn_kv_reduce_kernel sums them in split order.
 // ---------------------------------------------------------------------------------------------------
-template <bool D64>
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* q, const float* k, const float* v,
-                                                          const float* dout, const float* lse, const float* delta,
-                                                          int H, int D, int n, int m, int64_t qbs, int64_t kvbs,
-                                                          float scale, int nsplit, int tps, int64_t pstride,
-                                                          float* dk, float* dv) {
+// OWN_DELTA (the merged launch, attn_bwd_merged_kernel): delta_i = sum_d dO[d][i] O[d][i] is formed HERE from the dO columns the
+// wave holds anyway and 32 more loads of O per tile, and enters the dP tile as one more MFMA step (A = -delta_i in the kk = 0
+// slot, B = 1): the key-major pass then needs nothing from the query-major pass and both run in ONE launch.
+template <bool D64, bool OWN_DELTA>
+__device__ __forceinline__ void attn_bwd_kv_body(const float* q, const float* k, const float* v, const float* o,
+                                                 const float* dout, const float* lse, const float* delta, int H, int D,
+                                                 int n, int m, int64_t qbs, int64_t kvbs, float scale, int nsplit, int tps,
+                                                 int64_t pstride, float* dk, float* dv, int bx) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int64_t b = blockIdx.z, h = blockIdx.y;
   const int ktiles = (m + 31) / 32;
-  const int wid = blockIdx.x * 4 + wave;  // wave id within (b, h): key tile fastest
+  const int wid = bx * 4 + wave;  // wave id within (b, h): key tile fastest
   const int kt = wid % ktiles, sp = wid / ktiles;
   if (sp >= nsplit) return;
   const int j0 = kt * 32;
@@ -302,7 +305,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* q, const 
   const float* vh = v + b * kvbs + h * (int64_t)D * m;
   const float* doh = dout + (b * H + h) * (int64_t)D * n;
   const float* lh = lse + (b * H + h) * (int64_t)n;
-  const float* dlh = delta + (b * H + h) * (int64_t)n;
+  const float* dlh = OWN_DELTA ? lh : delta + (b * H + h) * (int64_t)n;
+  const float* oh = o + (b * H + h) * (int64_t)D * n;
   const int jk = j0 + l31;
   const bool kok = jk < m;
   const bool vec = ((n & 3) == 0) && aligned16(qh) && aligned16(doh) && aligned16(lh) && aligned16(dlh);
@@ -336,7 +340,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* q, const 
     ld_row16<D64>(doh, n, l31, D, i0, hi, full && vec, dor);
     ld_row16<D64>(qh, n, l31, D, i0, hi, full && vec, qr);
     ld_vec16(lh, i0, hi, n, full && vec, ls);
-    ld_vec16(dlh, i0, hi, n, full && vec, dl);
+    float di = 0.0f;
+    if (OWN_DELTA) {
+      float oc[DMAX / 2];
+      ld_cols<D64>(oh, n, hi, l31, D, i0, full, oc);
+#pragma unroll
+      for (int s = 0; s < DMAX / 2; ++s)
+        if (D64 || 2 * s < D) di = fmaf(dc[s], oc[s], di);
+      di += __shfl_xor(di, 32, 64);  // query i0 + l31, both half-waves
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dl[r] = 0.0f;
+    } else {
+      ld_vec16(dlh, i0, hi, n, full && vec, dl);
+    }
     if (i0 + 32 < i_end) load_q(qn, i0 + 32);
 #ifndef ADP_EMULATE
     __builtin_amdgcn_sched_barrier(0);
@@ -351,6 +367,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* q, const 
 #pragma unroll
     for (int s = 0; s < DMAX / 2; ++s)
       if (D64 || 2 * s < D) dpa = adp_mfma32(dc[s], vf[s], dpa);
+    if (OWN_DELTA) dpa = adp_mfma32(hi == 0 ? -di : 0.0f, 1.0f, dpa);  // dP[i][j] - delta_i for every key column j
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const bool ok = (full || i0 + acc_row(r, hi) < n) && kok;
@@ -399,6 +416,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* q, const 
     }
 }
 
+template <bool D64>
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* q, const float* k, const float* v,
+                                                          const float* dout, const float* lse, const float* delta,
+                                                          int H, int D, int n, int m, int64_t qbs, int64_t kvbs,
+                                                          float scale, int nsplit, int tps, int64_t pstride,
+                                                          float* dk, float* dv) {
+  attn_bwd_kv_body<D64, false>(q, k, v, dout, dout, lse, delta, H, D, n, m, qbs, kvbs, scale, nsplit, tps, pstride, dk, dv,
+                               (int)blockIdx.x);
+}
+
 // dk / dv [b][e] = sum_{sp < nsplit} part_{k,v}[sp * pstride + b * kvbs + e], e < cnt   (fixed order: deterministic);
 // blockIdx.y = 2 * b + (0: k, 1: v)
 __global__ __launch_bounds__(256) void attn_kv_reduce_kernel(const float* pk, const float* pv, int nsplit,
@@ -424,21 +451,59 @@ __global__ __launch_bounds__(256) void attn_kv_reduce_kernel(const float* pk, co
   }
 }
 
+// The split sums of both backward passes in ONE launch (self attention at batch 1 has both): blockIdx.y < nbq sums the nq partial
+// copies of dq (batch element blockIdx.y), the other rows are attn_kv_reduce_kernel's (2 * b + (0: k, 1: v)).  Same fixed orders.
+__global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(const float* pq, int nq, int64_t qstride, int64_t qbs, int64_t qcnt,
+                                                              float* dq, int nbq, const float* pk, const float* pv, int ns,
+                                                              int64_t pstride, int64_t kvbs, int64_t kcnt, float* dk,
+                                                              float* dv) {
+  if ((int)blockIdx.y < nbq) {
+    const float* p = pq + blockIdx.y * qbs;
+    float* o = dq + blockIdx.y * qbs;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < qcnt; e += (int64_t)gridDim.x * 256) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(u < nq ? u : 0) * qstride + e];
+      float a = 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += u < nq ? v[u] : 0.0f;
+      o[e] = a;
+    }
+    return;
+  }
+  const int y = (int)blockIdx.y - nbq;
+  const int64_t b = y >> 1;
+  const float* part = ((y & 1) ? pv : pk) + b * kvbs;
+  float* out = ((y & 1) ? dv : dk) + b * kvbs;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < kcnt; e += (int64_t)gridDim.x * 256) {
+    float s = 0.0f;
+    int sp = 0;
+    for (; sp + 8 <= ns; sp += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(sp + u) * pstride + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; sp < ns; ++sp) s += part[sp * pstride + e];
+    out[e] = s;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // backward, query-major pass: one wave owns 32 queries and loops over key tiles (transposed tiles, as forward):
 //   dS^T[j][i] -> dq[d][i] = sum_j k[d][j] dS^T[j][i]
 // ---------------------------------------------------------------------------------------------------
 template <bool D64>
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* q, const float* k, const float* v,
-                                                         const float* o, const float* dout, const float* lse,
-                                                         float* delta, int H, int D, int n, int m, int64_t qbs,
-                                                         int64_t kvbs, float scale, float* dq, int tps,
-                                                         int64_t pstride) {
+__device__ __forceinline__ void attn_bwd_q_body(const float* q, const float* k, const float* v, const float* o,
+                                                const float* dout, const float* lse, float* delta, int H, int D, int n,
+                                                int m, int64_t qbs, int64_t kvbs, float scale, float* dq, int tps,
+                                                int64_t pstride, int bx) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
   const int64_t b = blockIdx.z, h = blockIdx.y;
   const int qblocks = (n + 127) / 128;
-  const int sp = blockIdx.x / qblocks;  // key split (partial dq tiles go to dq + sp * pstride, summed afterwards)
-  const int i0 = (blockIdx.x - sp * qblocks) * 128 + wave * 32;
+  const int sp = bx / qblocks;  // key split (partial dq tiles go to dq + sp * pstride, summed afterwards)
+  const int i0 = (bx - sp * qblocks) * 128 + wave * 32;
   if (i0 >= n) return;
   const int j_lo = sp * tps * 32, j_hi = (j_lo + tps * 32 < m) ? j_lo + tps * 32 : m;
   const float* qh = q + b * qbs + h * (int64_t)D * n;
@@ -470,7 +535,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* q, const f
     for (int s = 0; s < DMAX / 2; ++s)
       if (D64 || 2 * s < D) part = fmaf(df[s], ld_col<D64>(oh, n, s, hi, D, qcol, qok), part);
     di = part + __shfl_xor(part, 32, 64);
-    if (sp == 0 && hi == 0 && qok) delta[(b * H + h) * (int64_t)n + iq] = di;
+    if (delta && sp == 0 && hi == 0 && qok) delta[(b * H + h) * (int64_t)n + iq] = di;
   }
   f32x16 dqa[2];
 #pragma unroll
@@ -531,6 +596,41 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* q, const f
       const int dd = 32 * t + acc_row(r, hi);
       if (dd < D && qok) dqh[dd * n + iq] = dqa[t][r];
     }
+}
+
+template <bool D64>
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* q, const float* k, const float* v,
+                                                         const float* o, const float* dout, const float* lse,
+                                                         float* delta, int H, int D, int n, int m, int64_t qbs,
+                                                         int64_t kvbs, float scale, float* dq, int tps,
+                                                         int64_t pstride) {
+  attn_bwd_q_body<D64>(q, k, v, o, dout, lse, delta, H, D, n, m, qbs, kvbs, scale, dq, tps, pstride, (int)blockIdx.x);
+}
+
+// Both passes of the backward in ONE launch: blocks [0, gq) run the query-major pass (dq), blocks [gq, gq + gkv) the key-major
+// pass (dk / dv) with its own delta.  At batch 1 each pass alone leaves most of the chip idle (cross attention over 64 keys at
+// n = 128: 8 + 16 workgroups), and a dependent launch costs its boundary plus a cold first load.
+struct attn_bwd_args {
+  const float *q, *k, *v, *o, *dout, *lse;
+  int H, D, n, m;
+  int64_t qbs, kvbs;
+  float scale;
+  float* dq;       // query-major pass: destination (or its partial copies), key tiles per split, stride between the copies
+  int qtps;
+  int64_t qstride;
+  float *dk, *dv;  // key-major pass: destination (or partial copies), query split, query tiles per split, stride
+  int ns, tps;
+  int64_t pstride;
+  int gq;
+};
+template <bool D64>
+__global__ __launch_bounds__(256) void attn_bwd_merged_kernel(attn_bwd_args a) {
+  if ((int)blockIdx.x < a.gq)
+    attn_bwd_q_body<D64>(a.q, a.k, a.v, a.o, a.dout, a.lse, nullptr, a.H, a.D, a.n, a.m, a.qbs, a.kvbs, a.scale, a.dq, a.qtps,
+                         a.qstride, (int)blockIdx.x);
+  else
+    attn_bwd_kv_body<D64, true>(a.q, a.k, a.v, a.o, a.dout, a.lse, nullptr, a.H, a.D, a.n, a.m, a.qbs, a.kvbs, a.scale, a.ns,
+                                a.tps, a.pstride, a.dk, a.dv, (int)blockIdx.x - a.gq);
 }
 
 // query split of the key-major pass: enough waves to cover the chip when there are few key tiles
@@ -635,6 +735,30 @@ extern "C" int adp_attn_bwd(const float* q, const float* k, const float* v, cons
     qstride = B * q_bstride;
   }
   const dim3 gq2((unsigned)(adp_cdiv(n, 128) * nq), (unsigned)H, (unsigned)B);
+  const dim3 gkv((unsigned)adp_cdiv(ktiles * ns, 4), (unsigned)H, (unsigned)B);
+  // One launch for both passes while together they are at most one wave per SIMD (batch 1; hipGraph microbench, us per backward,
+  // separate -> merged: cross attention over 64 keys n = 128 27.6 -> 16.6, n = 1024 32.3 -> 20.7, n = 4096 (1536 waves) 52.3 ->
+  // 53.1; self attention n = 256 35.1 -> 21.7, n = 1024 (2048 waves: the chip is full either way and the key-major pass pays
+  // for its O columns) 107 -> 127).  ADP_ATTN_MERGE=0 / 1 forces either form (tests, A/B).
+  const char* em = getenv("ADP_ATTN_MERGE");
+  const bool merge = em ? em[0] != '0' : (int64_t)(gq2.x + gkv.x) * H * B * 4 <= 1024;
+  if (merge) {
+    attn_bwd_args a;
+    a.q = q, a.k = k, a.v = v, a.o = o, a.dout = dout, a.lse = lse;
+    a.H = (int)H, a.D = (int)D, a.n = (int)n, a.m = (int)m, a.qbs = q_bstride, a.kvbs = kv_bstride, a.scale = scale;
+    a.dq = pq, a.qtps = (int)qtps, a.qstride = qstride;
+    a.dk = pk, a.dv = pv, a.ns = (int)ns, a.tps = (int)tps, a.pstride = pstride, a.gq = (int)gq2.x;
+    const dim3 grid(gq2.x + gkv.x, (unsigned)H, (unsigned)B);
+    if (D == 64) ADP_LAUNCH(attn_bwd_merged_kernel<true>, grid, dim3(256), stream, a);
+    else ADP_LAUNCH(attn_bwd_merged_kernel<false>, grid, dim3(256), stream, a);
+    if (nq > 1 || ns > 1) {
+      const int64_t gx = nq > 1 ? adp_cdiv(H * D * n, 256) : adp_cdiv(H * D * m, 256);
+      const dim3 gr((unsigned)(gx < 2048 ? gx : 2048), (unsigned)((nq > 1 ? B : 0) + (ns > 1 ? 2 * B : 0)));
+      ADP_LAUNCH(attn_bwd_reduce_kernel, gr, dim3(256), stream, (const float*)pq, (int)nq, qstride, q_bstride, H * D * n, dq,
+                 (int)(nq > 1 ? B : 0), (const float*)pk, (const float*)pv, (int)ns, pstride, kv_bstride, H * D * m, dk, dv);
+    }
+    return ADP_LAUNCH_OK();
+  }
   if (D == 64)
     ADP_LAUNCH(attn_bwd_q_kernel<true>, gq2, dim3(256), stream, q, k, v, o, dout, lse, ws, (int)H, (int)D, (int)n, (int)m,
                q_bstride, kv_bstride, scale, pq, (int)qtps, qstride);
@@ -644,7 +768,6 @@ extern "C" int adp_attn_bwd(const float* q, const float* k, const float* v, cons
   if (nq > 1)
     ADP_LAUNCH(attn_sum_splits_kernel, dim3((unsigned)adp_cdiv(H * D * n, 256), (unsigned)B), dim3(256), stream,
                (const float*)pq, (int)nq, qstride, q_bstride, H * D * n, dq);
-  const dim3 gkv((unsigned)adp_cdiv(ktiles * ns, 4), (unsigned)H, (unsigned)B);
   if (D == 64)
     ADP_LAUNCH(attn_bwd_kv_kernel<true>, gkv, dim3(256), stream, q, k, v, dout, lse, (const float*)ws, (int)H, (int)D,
                (int)n, (int)m, q_bstride, kv_bstride, scale, (int)ns, (int)tps, pstride, pk, pv);

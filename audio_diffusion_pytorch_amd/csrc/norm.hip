@@ -718,13 +718,18 @@ template <int LPR, int NT, int VPT>
 __global__ __launch_bounds__(NT) void chan_lnv_fwd_kernel(const float* x, const float* ss, int64_t bstride, int C, int L,
                                                           float eps, float* y, float* stats, const float* gam,
                                                           const float* bet, const float* gam2, const float* bet2,
-                                                          float* y2) {
+                                                          float* y2, float eps2, float* cy, float* cstats) {
+  // CHAIN (cy != nullptr; ModulationItem followed by an AttentionItem / CrossAttentionItem): y = LN(x) * (1 + scale) + shift
+  // from `ss` as usual, then -- the tile still in registers -- the attention's own LayerNorm of y: cy = LN(y) * gam + bet,
+  // y2 = LN(y) * gam2 + bet2 (norm_context of a self-attention item), statistics of y to cstats.  One launch and one pass over
+  // x instead of two launches and a re-read of y.
   constexpr int TL = 4 * LPR, RPP = NT / LPR, NW = NT / 64;
   __shared__ float red2[2][NW][TL];  // one array per reduction round: no barrier before a round's writes
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = tid % LPR, rg = tid / LPR;
   const int l0 = blockIdx.x * TL + 4 * lr, b = blockIdx.y;
   const bool valid = l0 < L;  // L % 4 == 0: a quad is inside or outside
+  const bool chain = cy != nullptr, aff = gam != nullptr && !chain;
   const float* xb = x + (int64_t)b * C * L + l0;
   const float* sb = ss ? ss + b * bstride : nullptr;
   f32x4 v[VPT];
@@ -735,8 +740,8 @@ __global__ __launch_bounds__(NT) void chan_lnv_fwd_kernel(const float* x, const 
     const int c = rg + i * RPP;
     mulv[i] = addv[i] = 0.0f;
     if (y != nullptr && c < C) {
-      mulv[i] = gam ? gam[c] : 1.0f + sb[c];
-      addv[i] = gam ? bet[c] : sb[C + c];
+      mulv[i] = aff ? gam[c] : 1.0f + sb[c];
+      addv[i] = aff ? bet[c] : sb[C + c];
     }
     if (valid && c < C) {
       v[i] = *reinterpret_cast<const f32x4*>(xb + (int64_t)c * L);
@@ -789,22 +794,76 @@ __global__ __launch_bounds__(NT) void chan_lnv_fwd_kernel(const float* x, const 
     *reinterpret_cast<f32x4*>(sp) = f32x4{mean[0], rstd[0], mean[1], rstd[1]};
     *reinterpret_cast<f32x4*>(sp + 4) = f32x4{mean[2], rstd[2], mean[3], rstd[3]};
   }
-  if (y == nullptr || !valid) return;
+  if (y == nullptr || (!valid && !chain)) return;  // (chain: every thread stays for the second LayerNorm's barriers)
   float* yb = y + (int64_t)b * C * L + l0;
   float* yb2 = y2 ? y2 + (int64_t)b * C * L + l0 : nullptr;
+  float g1[VPT], b1[VPT], g2[VPT], b2[VPT];  // the second LayerNorm's affine maps, requested ahead of its reductions
+  float s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int c = rg + i * RPP;
-    if (c >= C) continue;
+    g1[i] = b1[i] = g2[i] = b2[i] = 0.0f;
+    if (chain && c < C) {
+      g1[i] = gam[c], b1[i] = bet[c];
+      if (yb2) g2[i] = gam2[c], b2[i] = bet2[c];
+    }
+    if (c >= C || !valid) {
+      if (chain) v[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      continue;
+    }
     const float mul = mulv[i], add = addv[i];
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = fmaf((v[i][k] - mean[k]) * rstd[k], mul, add);
     *reinterpret_cast<f32x4*>(yb + (int64_t)c * L) = o;
-    if (yb2) {
+    if (chain) {
+      v[i] = o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s2[k] += o[k];
+    } else if (yb2) {
       const float m2 = gam2[c], a2 = bet2[c];
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = fmaf((v[i][k] - mean[k]) * rstd[k], m2, a2);
+      *reinterpret_cast<f32x4*>(yb2 + (int64_t)c * L) = o;
+    }
+  }
+  if (!chain) return;
+  // ---- second LayerNorm over the channels of y (rounds 2 and 3 reuse the two LDS arrays: a barrier lies between a round's
+  // reads and the next use of its array)
+  over_channels(s2, 0);
+  float q2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) mean[k] = s2[k] / (float)C;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const bool in = rg + i * RPP < C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float dlt = in ? v[i][k] - mean[k] : 0.0f;
+      q2[k] = fmaf(dlt, dlt, q2[k]);
+    }
+  }
+  over_channels(q2, 1);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rstd[k] = 1.0f / sqrtf(q2[k] / (float)C + eps2);
+  if (!valid) return;
+  if (tid < LPR) {
+    float* sp = cstats + ((int64_t)b * L + l0) * 2;
+    *reinterpret_cast<f32x4*>(sp) = f32x4{mean[0], rstd[0], mean[1], rstd[1]};
+    *reinterpret_cast<f32x4*>(sp + 4) = f32x4{mean[2], rstd[2], mean[3], rstd[3]};
+  }
+  float* cb = cy + (int64_t)b * C * L + l0;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = rg + i * RPP;
+    if (c >= C) continue;
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = fmaf((v[i][k] - mean[k]) * rstd[k], g1[i], b1[i]);
+    *reinterpret_cast<f32x4*>(cb + (int64_t)c * L) = o;
+    if (yb2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = fmaf((v[i][k] - mean[k]) * rstd[k], g2[i], b2[i]);
       *reinterpret_cast<f32x4*>(yb2 + (int64_t)c * L) = o;
     }
   }
@@ -968,14 +1027,21 @@ constexpr int64_t LN_CMAX = 1024;
 
 int launch_ln_fwd(const float* x, const float* ss, int64_t bstride, int64_t B, int64_t C, int64_t L, float eps, float* y,
                   float* stats, void* stream, const float* gam = nullptr, const float* bet = nullptr,
-                  const float* gam2 = nullptr, const float* bet2 = nullptr, float* y2 = nullptr) {
+                  const float* gam2 = nullptr, const float* bet2 = nullptr, float* y2 = nullptr, float eps2 = 0.0f,
+                  float* cy = nullptr, float* cstats = nullptr) {
+  if (cy && !(lnv_ok(L, x, y, y2, stats, cy) && lnv_ok(L, cstats, nullptr, nullptr, nullptr, nullptr))) {
+    // chained Modulation -> LayerNorm without the 16-byte form: the two launches it stands for
+    const int rc = launch_ln_fwd(x, ss, bstride, B, C, L, eps, y, stats, stream);
+    if (rc != ADP_OK) return rc;
+    return launch_ln_fwd(y, nullptr, 0, B, C, L, eps2, cy, cstats, stream, gam, bet, gam2, bet2, y2);
+  }
   if (lnv_ok(L, x, y, y2, stats, nullptr)) {
     const LnvCfg v = lnv_cfg(C, B, L);
     dim3 vgrid((unsigned)adp_cdiv(L, 4 * v.lpr), (unsigned)B);
 #define ADP_LNV_FWD(LPR, NT, VPT)                                                                                     \
   if (v.lpr == LPR && v.nt == NT && v.vpt == VPT) {                                                                   \
     ADP_LAUNCH((chan_lnv_fwd_kernel<LPR, NT, VPT>), vgrid, dim3(NT), stream, x, ss, bstride, (int)C, (int)L, eps, y, \
-               stats, gam, bet, gam2, bet2, y2);                                                                      \
+               stats, gam, bet, gam2, bet2, y2, eps2, cy, cstats);                                                    \
     return ADP_LAUNCH_OK();                                                                                           \
   }
     ADP_LNV_FWD(64, 256, 2) ADP_LNV_FWD(32, 256, 4) ADP_LNV_FWD(16, 256, 4) ADP_LNV_FWD(8, 256, 4) ADP_LNV_FWD(8, 1024, 2)
@@ -1339,6 +1405,18 @@ extern "C" int adp_modulation_fwd(const float* x, const float* ss, int64_t ss_bs
   if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
   if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
   return launch_ln_fwd(x, ss, ss_bstride, B, C, L, eps, y, stats, stream);
+}
+
+extern "C" int adp_modulation_ln_fwd(const float* x, const float* ss, int64_t ss_bstride, int64_t B, int64_t C, int64_t L,
+                                     float eps, float* y, float* stats, float eps_ln, const float* gamma, const float* beta,
+                                     float* xn, const float* gamma2, const float* beta2, float* xn2, float* ln_stats,
+                                     void* stream) {
+  if (!x || !ss || !y || !stats || !gamma || !beta || !xn || !ln_stats) return ADP_ERR_NULL;
+  if (xn2 && (!gamma2 || !beta2)) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
+  if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
+  return launch_ln_fwd(x, ss, ss_bstride, B, C, L, eps, y, stats, stream, gamma, beta, gamma2, beta2, xn2, eps_ln, xn,
+                       ln_stats);
 }
 
 extern "C" int adp_gn_finalize(const float* part, int64_t B, int64_t C, int64_t E, int64_t G, float eps, float* stats,

@@ -273,6 +273,21 @@ def modulation_fwd(x: Tensor, ss: Tensor, ss_bstride: int, eps: float = MODULATI
     return y, stats
 
 
+def modulation_ln_fwd(x: Tensor, ss: Tensor, ss_bstride: int, gamma: Tensor, beta: Tensor, gamma2: Optional[Tensor] = None,
+                      beta2: Optional[Tensor] = None, eps: float = MODULATION_LN_EPS, eps_ln: float = ATTENTION_LN_EPS):
+    """ModulationItem + the LayerNorm(s) of the attention item behind it in one launch (adp_modulation_ln_fwd):
+    (y, stats) as modulation_fwd, (xn, xn2 or None, ln_stats) as ln_affine_fwd(y, gamma, beta, gamma2, beta2)."""
+    B, C, L = x.shape
+    y, xn = torch.empty_like(x), torch.empty_like(x)
+    xn2 = torch.empty_like(x) if gamma2 is not None else None
+    stats = torch.empty((B, L, 2), dtype=torch.float32, device=x.device)
+    ln_stats = torch.empty((B, L, 2), dtype=torch.float32, device=x.device)
+    _C.tag(bytes=4 * x.numel() * (4 if xn2 is not None else 3), shape=f"B{B} C{C} L{L}")
+    _C.call("adp_modulation_ln_fwd", ptr(x), ptr(ss), ss_bstride, B, C, L, eps, ptr(y), ptr(stats), eps_ln, ptr(gamma),
+            ptr(beta), ptr(xn), ptr(gamma2), ptr(beta2), ptr(xn2), ptr(ln_stats), _C.stream())
+    return y, stats, xn, xn2, ln_stats
+
+
 def modulation_bwd(x: Tensor, dy: Tensor, ss: Tensor, ss_bstride: int, stats: Tensor, dss: Tensor, dss_bstride: int,
                    dx: Optional[Tensor] = None) -> Tensor:
     B, C, L = x.shape

@@ -453,6 +453,9 @@ def _grad_buffer(shape, device) -> Tensor:
     return buf
 
 
+# ModulationItem + the LayerNorm of the attention item behind it as one launch (adp_modulation_ln_fwd); "0": two launches (A/B)
+MOD_LN_FUSE = os.environ.get("ADP_MOD_LN_FUSE", "1") != "0"
+
 # channel count from which SiLU(GroupNorm(x)) is materialised instead of recomputed in the conv loaders
 # (round 3, with the Winograd variants: 128 -> 14.14, 256 -> 14.15, 512 -> 14.20, 64 -> 14.21, 1024 -> 14.37 ms per step)
 ACT_MATERIALIZE_MIN_C = int(os.environ.get("ADP_ACT_MATERIALIZE_MIN_C", "128"))
@@ -469,6 +472,7 @@ class _Run:
         net._named_params()
         self.pnames = net._pname_cache
         self.gn: Optional[ops.GnPart] = None  # GroupNorm partial statistics of the tensor produced last (if any)
+        self.ln_ready = None  # (y, xn, cn, stats): LayerNorm(s) of y already formed by the ModulationItem that produced y
         self.mod_sums = ops.ModulationSums()  # parked second stages of the Modulation backwards
         # parked second stages of the split ConvBlock weight gradients: summed per side of a block in one launch per shape
         # (ADP_WGRAD_PARK=0: every weight gradient finishes itself, A/B)
@@ -638,13 +642,23 @@ class _Run:
             self.tape.append((bwd, None))
         return y
 
-    def modulation(self, key, x: Tensor) -> Tensor:
+    def modulation(self, key, x: Tensor, attn_next=None) -> Tensor:
+        """`attn_next`: the parameters of an AttentionItem / CrossAttentionItem that follows immediately (and whether it is a
+        self-attention item): its LayerNorm(s) of this item's output come out of the same launch (adp_modulation_ln_fwd) and
+        wait in self.ln_ready for attention.attention_item."""
         ss, dss = self.ss(key)
         NT = self.net.bank_total
         # (Modulation-side GroupNorm partials were measured and rejected: the per-channel lane reductions cost the
         # kernel more than the statistics launch they save -- tools/rejected/README.md)
         self.gn = None
-        y, stats = ops.modulation_fwd(x, ss, NT)
+        if attn_next is not None and MOD_LN_FUSE:
+            p, dual = attn_next
+            y, stats, xn, cn, st = ops.modulation_ln_fwd(x, ss, NT, p.norm.weight, p.norm.bias,
+                                                         p.norm_context.weight if dual else None,
+                                                         p.norm_context.bias if dual else None)
+            self.ln_ready = (y, xn, cn, st)
+        else:
+            y, stats = ops.modulation_fwd(x, ss, NT)
         if self.need_grad:
             off = self.net.bank_slices[key][0]
             # (second stage parked: the depth's Modulation items are summed together when its bank rows are formed)
@@ -682,7 +696,10 @@ class _Run:
             if t == ITEM_RESNET:
                 x = self.resnet(p, x)
             elif t == ITEM_MODULATION:
-                x = self.modulation((d, which, i), x)
+                nxt = self.net.item_types[d][i + 1] if i + 1 < len(mods) else None
+                # (a cross-attention item without the context bank normalises its context itself: only `norm` is taken along)
+                attn_next = (mods[i + 1], nxt == ITEM_ATTENTION) if nxt in (ITEM_ATTENTION, ITEM_CROSS_ATTENTION) else None
+                x = self.modulation((d, which, i), x, attn_next)
             elif t == ITEM_INJECT:
                 assert channels is not None and channels[d] is not None, f"Missing context `channels` at depth {d}"
                 x = self.inject(p, x, channels[d], self.ctx_index[d])

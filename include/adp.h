@@ -195,6 +195,13 @@ int adp_gn_param_grad(const float* ab, int64_t B, int64_t C, int64_t NS, float* 
  * ------------------------------------------------------------------------------------------ */
 int adp_modulation_fwd(const float* x, const float* ss, int64_t ss_bstride, int64_t B, int64_t C, int64_t L,
                        float eps, float* y, float* stats, void* stream);
+/* ModulationItem followed by an AttentionItem / CrossAttentionItem (components.py:90-93) in one launch: y and stats as
+ * adp_modulation_fwd, then the attention's LayerNorm of y while the tile is still in registers: xn = LN(y) * gamma + beta,
+ * xn2 = LN(y) * gamma2 + beta2 (norm_context of a self-attention item; may be NULL), ln_stats[b, l, {mean, rstd}] of y
+ * (what adp_ln_affine_fwd(y, ...) would return). */
+int adp_modulation_ln_fwd(const float* x, const float* ss, int64_t ss_bstride, int64_t B, int64_t C, int64_t L, float eps,
+                          float* y, float* stats, float eps_ln, const float* gamma, const float* beta, float* xn,
+                          const float* gamma2, const float* beta2, float* xn2, float* ln_stats, void* stream);
 /* dx, and dss[b*dss_bstride + {c | C + c}] = {sum_l dy*xhat | sum_l dy} (overwritten).
  * ws: adp_chan_ln_bwd_ws_bytes(B, C, L). */
 int64_t adp_chan_ln_bwd_ws_bytes(int64_t B, int64_t C, int64_t L);

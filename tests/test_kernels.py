@@ -1020,6 +1020,37 @@ def test_modulation_fwd_bwd(dev, B, C, L):
     assert rel_err(dbank, dbank_ref) < TOL
 
 
+@pytest.mark.parametrize("B,C,L,dual", [(2, 8, 300, False), (2, 32, 72, True), (1, 130, 64, False), (2, 300, 40, True),
+                                        (1, 1024, 24, False), (4, 512, 784, True), (2, 1024, 128, False),
+                                        (2, 100, 50, True)])   # (L % 4 != 0: the two launches it stands for)
+def test_modulation_ln_fwd(dev, B, C, L, dual):
+    """adp_modulation_ln_fwd (norm.hip, chained mode of chan_lnv_fwd): ModulationItem + the LayerNorm(s) of the attention item
+    behind it in one launch = adp_modulation_fwd followed by adp_ln_affine_fwd on its output (every output, both statistics),
+    and both against torch."""
+    x = (rnd(B, C, L, seed=1) * 1.5 + 0.4)
+    NT = 2 * C + 7
+    bank = rnd(B, NT, seed=2) * 0.5
+    off = 3
+    scale, shift = bank[:, off:off + C], bank[:, off + C:off + 2 * C]
+    g1, b1, g2, b2 = (rnd(C, seed=10 + i) * 0.5 + (1.0 if i % 2 == 0 else 0.0) for i in range(4))
+    y_ref = (F.layer_norm(x.transpose(1, 2), (C,), eps=ops.MODULATION_LN_EPS) * (1 + scale[:, None, :])
+             + shift[:, None, :])
+    xn_ref = F.layer_norm(y_ref, (C,), g1, b1, eps=ops.ATTENTION_LN_EPS).transpose(1, 2)
+    cn_ref = F.layer_norm(y_ref, (C,), g2, b2, eps=ops.ATTENTION_LN_EPS).transpose(1, 2)
+    xd, bank_d = x.to(dev), bank.to(dev)
+    gd = [t.to(dev) for t in (g1, b1, g2, b2)]
+    y, st, xn, cn, lst = ops.modulation_ln_fwd(xd, bank_d.view(-1)[off:], NT, gd[0], gd[1], gd[2] if dual else None,
+                                               gd[3] if dual else None)
+    y0, st0 = ops.modulation_fwd(xd, bank_d.view(-1)[off:], NT)
+    xn0, cn0, lst0 = ops.ln_affine_fwd(y0, gd[0], gd[1], gd[2] if dual else None, gd[3] if dual else None)
+    assert torch.equal(y, y0) and torch.equal(st, st0)
+    assert rel_err(y, y_ref.transpose(1, 2)) < TOL and rel_err(xn, xn_ref) < TOL
+    assert rel_err(xn, xn0) < 1e-5 and rel_err(lst, lst0) < 1e-5
+    assert (cn is None) == (not dual)
+    if dual:
+        assert rel_err(cn, cn_ref) < TOL and rel_err(cn, cn0) < 1e-5
+
+
 @pytest.mark.parametrize("B,C,L,n", [(2, 64, 200, 3), (1, 32, 9000, 2), (2, 1024, 12, 9)])
 def test_modulation_bwd_parked_sums(dev, B, C, L, n):
     """adp_modulation_bwd_partial + adp_modulation_bwd_reduce: n Modulation backwards of one shape, second stages summed by
@@ -1147,7 +1178,9 @@ def test_v_noise_mse_step(dev):
                                        (1, 2, 64, 512, 64),    # few key tiles: the dk/dv pass splits the queries
                                        (2, 1, 16, 203, 37),    # ragged both ways, query split with a short last slice
                                        (1, 2, 64, 96, 256)])
-def test_attention_fwd_bwd(dev, B, H, D, n, m):
+@pytest.mark.parametrize("merge", ["1", "0"])  # backward: both passes in one launch (own delta) / two launches, delta through ws
+def test_attention_fwd_bwd(dev, B, H, D, n, m, merge, monkeypatch):
+    monkeypatch.setenv("ADP_ATTN_MERGE", merge)
     mid = H * D
     q = rnd(B, mid, n, seed=1).requires_grad_()
     kv = rnd(B, 2 * mid, m, seed=2).requires_grad_()

@@ -202,12 +202,15 @@ ATTN = dict(in_channels=2, channels=[8, 16, 32], factors=[1, 2, 2], items=[1, 1,
             embedding_features=12)
 
 
-@pytest.mark.parametrize("batch,bank", [(2, "1"), (1, "1"), (2, "0")])
-def test_unet_attention_self_and_cross(dev, batch, bank, monkeypatch):
+@pytest.mark.parametrize("batch,bank,fuse", [(2, "1", True), (1, "1", True), (2, "0", True), (2, "1", False)])
+def test_unet_attention_self_and_cross(dev, batch, bank, fuse, monkeypatch):
     """README attention layout at tiny size (self attention + cross attention over an injected embedding:
     BASELINE config 4 feeds `embedding=` directly).  bank = the context side of the four cross-attention
-    items as one folded weight bank (attention.CtxBank: slice views at batch 1, row copies otherwise) or item by item."""
+    items as one folded weight bank (attention.CtxBank: slice views at batch 1, row copies otherwise) or item by item;
+    fuse = the ModulationItem in front of an attention item forms that item's LayerNorm(s) in its own launch."""
+    from audio_diffusion_pytorch_amd import unet as unet_mod
     monkeypatch.setenv("ADP_CTX_BANK", bank)
+    monkeypatch.setattr(unet_mod, "MOD_LN_FUSE", fuse)
     oracle, net = build_pair(ATTN, dev)
     g = torch.Generator().manual_seed(4)
     x = torch.randn(batch, 2, 96, generator=g)
