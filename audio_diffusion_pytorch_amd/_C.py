@@ -69,6 +69,7 @@ SIGNATURES = {
     "adp_modulation_bwd": (c_int, [P, P, P, I, P, I, I, I, P, P, I, P, P]),
     "adp_modulation_bwd_partial": (I, [P, P, P, I, P, I, I, I, P, P, P]),
     "adp_modulation_bwd_reduce": (c_int, [P, P, I, I, I, I, I, P]),
+    "adp_modulation_ln_bwd_partial": (I, [P, P, I, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P]),
     "adp_ln_stats": (c_int, [P, I, I, I, F, P, P]),
     "adp_ln_affine_fwd": (c_int, [P, I, I, I, F, P, P, P, P, P, P, P, P]),
     "adp_ln_bwd": (c_int, [P, P, P, P, P, I, I, I, I, P, P, P, P]),

@@ -103,6 +103,14 @@ class CtxBank:
             run.emb_grad, _ = ops.ln_bwd(self.ctx, dxhat, self.st, c["ones"])
 
 
+class PendingLN:
+    """Gradient handed from a cross-attention item's backward to the backward of the ModulationItem in front of it: the
+    LayerNorm backward of d(xn) (+ the residual gradient) has not run yet."""
+
+    def __init__(self, y, dxn, gamma, ln_stats, dres, dgb):
+        self.y, self.dxn, self.gamma, self.ln_stats, self.dres, self.dgb = y, dxn, gamma, ln_stats, dres, dgb
+
+
 def attention_item(run, p, x: Tensor, context: Optional[Tensor]) -> Tensor:
     net = run.net
     H, D = net.heads, net.head_features
@@ -156,6 +164,9 @@ def attention_item(run, p, x: Tensor, context: Optional[Tensor]) -> Tensor:
     y = ops.conv1d(o, wo, None, res=x)
 
     if run.need_grad:
+        from . import unet as unet_mod
+        defer_ln = ready is not None and is_cross and unet_mod.MOD_LN_BWD_FUSE
+
         def bwd(gy):
             ops.conv1d_wgrad(o, gy, 1, dw=run.g(p.to_out.weight).view(C, mid, 1), want_bias=False, park=run.wpark)
             do = ops.conv1d(gy, wo, None, transposed=True)
@@ -164,7 +175,13 @@ def attention_item(run, p, x: Tensor, context: Optional[Tensor]) -> Tensor:
             ops.conv1d_wgrad(xn, dq, 1, dw=run.g(p.to_q.weight).view(mid, C, 1), want_bias=False, park=run.wpark)
             dxn = ops.conv1d(dq, wq, None, transposed=True)
             # [dgamma | dbeta] land directly in the flat gradient buffer (weight and bias are adjacent parameters)
-            dx, _ = ops.ln_bwd(x, dxn, st_x, p.norm.weight, dres=gy, dgb=run.gspan(p.norm.weight, 2 * C))
+            if defer_ln:
+                # cross attention behind a ModulationItem that formed `xn`: the LayerNorm's backward runs inside that item's
+                # backward -- the next tape entry -- as one pass (ops.ModulationSums.partial_ln)
+                dx = PendingLN(x, dxn, p.norm.weight, st_x, gy, run.gspan(p.norm.weight, 2 * C))
+                net._ln_deferred = getattr(net, "_ln_deferred", 0) + 1  # (visible to tests: which path a step took)
+            else:
+                dx, _ = ops.ln_bwd(x, dxn, st_x, p.norm.weight, dres=gy, dgb=run.gspan(p.norm.weight, 2 * C))
             if bank is not None:  # k/v path: the bank's backward runs once, after the last item (CtxBank.backward)
                 bank.put_dkv(p, dkv)
                 return dx

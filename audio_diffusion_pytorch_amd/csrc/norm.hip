@@ -974,6 +974,155 @@ __global__ __launch_bounds__(NT) void chan_lnv_bwd_kernel(const float* x, const 
   }
 }
 
+// Backward of "ModulationItem -> LayerNorm of an attention item" as ONE pass (the backward of chan_lnv_fwd's chained mode):
+//   stage A   d(xn) -> d(y): LayerNorm-with-affine backward over the channels of y (+ the residual gradient dres), y itself
+//             rebuilt from x (y = xhat1 * (1 + scale) + shift: x is needed by stage B anyway, y is not read);
+//   stage B   d(y) -> d(x): the Modulation's own backward.
+// Per-channel sums over the tile's positions for both stages: ws2 (sum d(xn) * xhat2 | sum d(xn): dgamma / dbeta of the
+// LayerNorm) and ws1 (sum d(y) * xhat1 | sum d(y): dscale / dshift), both [b][2][tile][c] like chan_lnv_bwd_kernel's.
+// Three tensor reads + one write where the two launches read five and write two; the intermediate d(y) stays in registers.
+template <int LPR, int NT, int VPT>
+__global__ __launch_bounds__(NT) void chan_lnv_bwd_chain_kernel(const float* x, const float* ss, int64_t bstride,
+                                                                const float* stats1, const float* dxn, const float* gamma,
+                                                                const float* stats2, const float* dres, int C, int L,
+                                                                int NTL, float* dx, float* ws1, float* ws2) {
+  constexpr int TL = 4 * LPR, RPP = NT / LPR, NW = NT / 64;
+  __shared__ float red[4][NW][TL];  // two arrays per stage: no barrier between a stage's reads and the next stage's writes
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = tid % LPR, rg = tid / LPR;
+  const int tile = blockIdx.x, l0 = tile * TL + 4 * lr, b = blockIdx.y;
+  const bool valid = l0 < L;
+  const int64_t boff = (int64_t)b * C * L + l0;
+  float mean1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, rstd1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float mean2[4] = {0.0f, 0.0f, 0.0f, 0.0f}, rstd2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (valid) {
+    const float* sp = stats1 + ((int64_t)b * L + l0) * 2;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(sp), c4 = *reinterpret_cast<const f32x4*>(sp + 4);
+    mean1[0] = a[0], rstd1[0] = a[1], mean1[1] = a[2], rstd1[1] = a[3];
+    mean1[2] = c4[0], rstd1[2] = c4[1], mean1[3] = c4[2], rstd1[3] = c4[3];
+    const float* sq = stats2 + ((int64_t)b * L + l0) * 2;
+    const f32x4 e = *reinterpret_cast<const f32x4*>(sq), f4 = *reinterpret_cast<const f32x4*>(sq + 4);
+    mean2[0] = e[0], rstd2[0] = e[1], mean2[1] = e[2], rstd2[1] = e[3];
+    mean2[2] = f4[0], rstd2[2] = f4[1], mean2[3] = f4[2], rstd2[3] = f4[3];
+  }
+  const float* sb = ss + b * bstride;
+  f32x4 xh[VPT], g[VPT];
+  float mulv[VPT], addv[VPT];
+  float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  auto xhat2 = [&](int i, int k) {  // normalised y of the LayerNorm at (channel pass i, position k), from xhat1
+    return (fmaf(xh[i][k], mulv[i], addv[i]) - mean2[k]) * rstd2[k];
+  };
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = rg + i * RPP;
+    const bool ok = valid && c < C;
+    f32x4 d;
+    if (ok) {
+      d = *reinterpret_cast<const f32x4*>(dxn + boff + (int64_t)c * L);
+      xh[i] = *reinterpret_cast<const f32x4*>(x + boff + (int64_t)c * L);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] = xh[i][k] = 0.0f;
+    }
+    mulv[i] = (c < C) ? 1.0f + sb[c] : 0.0f;
+    addv[i] = (c < C) ? sb[C + c] : 0.0f;
+    const float gm = (c < C) ? gamma[c] : 0.0f;
+    float pa = 0.0f, pb = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      xh[i][k] = ok ? (xh[i][k] - mean1[k]) * rstd1[k] : 0.0f;
+      const float x2 = ok ? xhat2(i, k) : 0.0f;
+      g[i][k] = d[k] * gm;
+      s1[k] += g[i][k];
+      s2[k] = fmaf(g[i][k], x2, s2[k]);
+      pa = fmaf(d[k], x2, pa);
+      pb += d[k];
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) {
+      pa += __shfl_xor(pa, o, 64);
+      pb += __shfl_xor(pb, o, 64);
+    }
+    if (lr == 0 && c < C) {
+      ws2[(((int64_t)b * 2 + 0) * NTL + tile) * C + c] = pa;
+      ws2[(((int64_t)b * 2 + 1) * NTL + tile) * C + c] = pb;
+    }
+  }
+  auto over_channels = [&](float (&a)[4], float (&c2)[4], int stage) {  // channel means of two sums, in every thread
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        a[k] += __shfl_xor(a[k], o, 64);
+        c2[k] += __shfl_xor(c2[k], o, 64);
+      }
+    if (NW > 1) {
+      if (lane < LPR)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          red[2 * stage][wave][4 * lr + k] = a[k];
+          red[2 * stage + 1][wave][4 * lr + k] = c2[k];
+        }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float u = 0.0f, w2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          u += red[2 * stage][w][4 * lr + k];
+          w2 += red[2 * stage + 1][w][4 * lr + k];
+        }
+        a[k] = u, c2[k] = w2;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a[k] /= (float)C;
+      c2[k] /= (float)C;
+    }
+  };
+  over_channels(s1, s2, 0);
+  // ---- stage A output d(y) (kept in g) and stage B's sums
+  float t1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, t2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = rg + i * RPP;
+    const bool ok = valid && c < C;
+    f32x4 r = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (ok && dres) r = *reinterpret_cast<const f32x4*>(dres + boff + (int64_t)c * L);
+    float pa = 0.0f, pb = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float o = ok ? rstd2[k] * (g[i][k] - s1[k] - xhat2(i, k) * s2[k]) + r[k] : 0.0f;  // d(y)
+      pa = fmaf(o, xh[i][k], pa);
+      pb += o;
+      g[i][k] = o * mulv[i];
+      t1[k] += g[i][k];
+      t2[k] = fmaf(g[i][k], xh[i][k], t2[k]);
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) {
+      pa += __shfl_xor(pa, o, 64);
+      pb += __shfl_xor(pb, o, 64);
+    }
+    if (lr == 0 && c < C) {
+      ws1[(((int64_t)b * 2 + 0) * NTL + tile) * C + c] = pa;
+      ws1[(((int64_t)b * 2 + 1) * NTL + tile) * C + c] = pb;
+    }
+  }
+  over_channels(t1, t2, 1);
+  if (!valid) return;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = rg + i * RPP;
+    if (c >= C) continue;
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = rstd1[k] * (g[i][k] - t1[k] - xh[i][k] * t2[k]);
+    *reinterpret_cast<f32x4*>(dx + boff + (int64_t)c * L) = o;
+  }
+}
+
 // vector-form tile by channel count: (lanes per row segment, threads, passes); RPP * VPT >= C
 struct LnvCfg {
   int lpr, nt, vpt;
@@ -1530,6 +1679,40 @@ extern "C" int adp_ln_bwd(const float* x, const float* dxn, const float* stats, 
   // dgamma_dbeta = [dgamma (C) | dbeta (C)]
   launch_reduce_tiles((const float*)ws, B, C, NT, (int64_t)0, 1, (int)accumulate, dgamma_dbeta, stream);
   return ADP_LAUNCH_OK();
+}
+
+extern "C" int64_t adp_modulation_ln_bwd_partial(const float* x, const float* ss, int64_t ss_bstride, const float* stats,
+                                                 const float* y, const float* dxn, const float* gamma, const float* ln_stats,
+                                                 const float* dres, int64_t B, int64_t C, int64_t L, int64_t accumulate,
+                                                 float* dx, float* ws, float* dgamma_dbeta, float* ws_ln, void* stream) {
+  if (!x || !ss || !stats || !y || !dxn || !gamma || !ln_stats || !dx || !ws || !dgamma_dbeta || !ws_ln) return ADP_ERR_NULL;
+  if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || L >= (int64_t)1 << 31) return ADP_ERR_SHAPE;
+  if (C > LN_CMAX) return ADP_ERR_UNSUPPORTED;
+  int64_t NT = -1;
+  if (lnv_ok(L, x, dxn, dres, dx, stats) && lnv_ok(L, ln_stats, nullptr, nullptr, nullptr, nullptr)) {
+    const LnvCfg v = lnv_cfg(C, B, L, true);
+    const int VNTL = (int)adp_cdiv(L, 4 * v.lpr);
+    dim3 vgrid((unsigned)VNTL, (unsigned)B);
+#define ADP_LNV_CHAIN(LPR, NT_, VPT)                                                                                    \
+  if (NT < 0 && v.lpr == LPR && v.nt == NT_ && v.vpt == VPT) {                                                          \
+    ADP_LAUNCH((chan_lnv_bwd_chain_kernel<LPR, NT_, VPT>), vgrid, dim3(NT_), stream, x, ss, ss_bstride, stats, dxn,    \
+               gamma, ln_stats, dres, (int)C, (int)L, VNTL, dx, ws, ws_ln);                                             \
+    NT = VNTL;                                                                                                          \
+  }
+    ADP_LNV_CHAIN(64, 256, 2) ADP_LNV_CHAIN(32, 256, 4) ADP_LNV_CHAIN(16, 256, 4) ADP_LNV_CHAIN(8, 256, 4) ADP_LNV_CHAIN(8, 1024, 2)
+    ADP_LNV_CHAIN(4, 1024, 2) ADP_LNV_CHAIN(2, 1024, 1) ADP_LNV_CHAIN(4, 1024, 4) ADP_LNV_CHAIN(2, 1024, 2) ADP_LNV_CHAIN(1, 1024, 1)
+    ADP_LNV_CHAIN(4, 512, 4) ADP_LNV_CHAIN(4, 512, 8) ADP_LNV_CHAIN(2, 512, 2) ADP_LNV_CHAIN(2, 512, 4) ADP_LNV_CHAIN(1, 512, 2) ADP_LNV_CHAIN(8, 512, 4)
+#undef ADP_LNV_CHAIN
+    if (NT > 0) launch_reduce_tiles((const float*)ws_ln, B, C, NT, (int64_t)0, 1, (int)accumulate, dgamma_dbeta, stream);
+  }
+  if (NT < 0) {
+    // without the 16-byte form: the two launches it stands for (d(y) passes through dx: every thread reads its own elements of
+    // the incoming gradient before it writes them)
+    const int64_t NA = launch_ln_bwd(y, dxn, (const float*)nullptr, (int64_t)0, gamma, ln_stats, dres, B, C, L, dx, ws_ln, stream);
+    launch_reduce_tiles((const float*)ws_ln, B, C, NA, (int64_t)0, 1, (int)accumulate, dgamma_dbeta, stream);
+    NT = launch_ln_bwd(x, dx, ss, ss_bstride, (const float*)nullptr, stats, (const float*)nullptr, B, C, L, dx, ws, stream);
+  }
+  return ADP_LAUNCH_OK() == ADP_OK ? NT : (int64_t)ADP_ERR_LAUNCH;
 }
 
 extern "C" int64_t adp_skipmod_bwd_ws_bytes(int64_t B, int64_t C, int64_t L) {

@@ -320,6 +320,22 @@ class ModulationSums:
         self.items.append((off, ws, dss, B, C, NT, dss_bstride))
         return dx
 
+    def partial_ln(self, off: int, x: Tensor, ss: Tensor, ss_bstride: int, stats: Tensor, dss: Tensor, dss_bstride: int,
+                   y: Tensor, dxn: Tensor, gamma: Tensor, ln_stats: Tensor, dres: Optional[Tensor], dgb: Tensor) -> Tensor:
+        """`partial` for a ModulationItem whose output y went through an attention item's LayerNorm (gamma, ln_stats): the
+        LayerNorm's backward of d(xn) (+ dres) and this item's backward in one pass (adp_modulation_ln_bwd_partial);
+        dgb = the LayerNorm's [dgamma | dbeta] destination."""
+        B, C, L = x.shape
+        dx = torch.empty_like(x)
+        nbytes = _C.query("adp_chan_ln_bwd_ws_bytes", B, C, L)
+        ws, ws_ln = _ws(nbytes, x), _ws(nbytes, x)
+        _C.tag(bytes=16 * x.numel(), shape=f"B{B} C{C} L{L}")
+        NT = _C.call_value("adp_modulation_ln_bwd_partial", ptr(x), ptr(ss), ss_bstride, ptr(stats), ptr(y), ptr(dxn),
+                           ptr(gamma), ptr(ln_stats), ptr(dres), B, C, L, 0, ptr(dx), ptr(ws), ptr(dgb), ptr(ws_ln),
+                           _C.stream())
+        self.items.append((off, ws, dss, B, C, NT, dss_bstride))
+        return dx
+
     def flush(self, lo: Optional[int] = None, hi: Optional[int] = None) -> None:
         take = [it for it in self.items if lo is None or lo <= it[0] < hi]
         if not take:

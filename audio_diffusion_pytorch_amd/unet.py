@@ -29,6 +29,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import ops
+from .attention import PendingLN
 
 ITEM_RESNET = "resnet"
 ITEM_MODULATION = "modulation"
@@ -456,6 +457,9 @@ def _grad_buffer(shape, device) -> Tensor:
 # ModulationItem + the LayerNorm of the attention item behind it as one launch (adp_modulation_ln_fwd); "0": two launches (A/B)
 MOD_LN_FUSE = os.environ.get("ADP_MOD_LN_FUSE", "1") != "0"
 
+# ... and the backward of that pair as one pass (adp_modulation_ln_bwd_partial; cross-attention items); "0": A/B
+MOD_LN_BWD_FUSE = os.environ.get("ADP_MOD_LN_BWD_FUSE", "1") != "0"
+
 # channel count from which SiLU(GroupNorm(x)) is materialised instead of recomputed in the conv loaders
 # (round 3, with the Winograd variants: 128 -> 14.14, 256 -> 14.15, 512 -> 14.20, 64 -> 14.21, 1024 -> 14.37 ms per step)
 ACT_MATERIALIZE_MIN_C = int(os.environ.get("ADP_ACT_MATERIALIZE_MIN_C", "128"))
@@ -661,8 +665,14 @@ class _Run:
             y, stats = ops.modulation_fwd(x, ss, NT)
         if self.need_grad:
             off = self.net.bank_slices[key][0]
+
             # (second stage parked: the depth's Modulation items are summed together when its bank rows are formed)
-            self.tape.append((lambda gy: self.mod_sums.partial(off, x, gy, ss, NT, stats, dss, NT), None))
+            def bwd(gy):
+                if isinstance(gy, PendingLN):  # the attention item behind this one left its LayerNorm's backward to us
+                    return self.mod_sums.partial_ln(off, x, ss, NT, stats, dss, NT, gy.y, gy.dxn, gy.gamma, gy.ln_stats,
+                                                    gy.dres, gy.dgb)
+                return self.mod_sums.partial(off, x, gy, ss, NT, stats, dss, NT)
+            self.tape.append((bwd, None))
         return y
 
     def inject(self, p, x: Tensor, ctx: Tensor, ctx_index: int) -> Tensor:

@@ -541,6 +541,9 @@ def dp1_leg(timeout: float = 240.0):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+LEG_WARM_S = 0.3  # untimed replay in front of every leg outside the headline (which has the calibration's 1 s)
+
+
 def _graphed(step, zero, mode="global"):
     """Captures `step` in a hipGraph (after two eager warm-ups on a side stream); returns the replay callable.
     mode = "thread_local" for steps that hold RCCL collectives (see parallel.capture_step)."""
@@ -558,10 +561,17 @@ def _graphed(step, zero, mode="global"):
     return graph.replay
 
 
-def _time(fn, n, warmup=3):
+def _time(fn, n, warmup=3, warm_s=0.0):
+    """Seconds per call over n calls after `warmup` untimed ones; warm_s > 0 keeps calling for at least that long first (the
+    legs outside the headline start on a GPU that idled through a model build: clocks come back within a few hundred ms)."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    t_w = time.perf_counter()
+    while warm_s > 0.0 and time.perf_counter() - t_w < warm_s:
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
         fn()
@@ -613,7 +623,7 @@ def extra_legs(model, x, dev):
         def step1():
             zero(model)
             model(x1).backward()
-        dt = _time(_graphed(step1, lambda: zero(model)), 20)
+        dt = _time(_graphed(step1, lambda: zero(model)), 20, warm_s=LEG_WARM_S)
         out["batch1"] = {"workload": "BASELINE configs[0] shape on the GPU: fwd+bwd, audio [1,2,2**18]",
                          "steps_per_s": round(1.0 / dt, 2), "ms_per_step": round(dt * 1e3, 3), "launch": "hipGraph replay"}
     except Exception as e:
@@ -621,7 +631,7 @@ def extra_legs(model, x, dev):
     try:
         noise = torch.randn(1, 2, LENGTH, device=dev)
         model.sample(noise, num_steps=2)  # captures the step
-        dt = _time(lambda: model.sample(noise, num_steps=50), 2, warmup=1)
+        dt = _time(lambda: model.sample(noise, num_steps=50), 2, warmup=1, warm_s=LEG_WARM_S)
         out["sampler"] = {"workload": "BASELINE configs[2]: VSampler.sample num_steps=50, noise [1,2,2**18], "
                                       "hipGraph-captured step", "sampler_steps_per_s": round(50.0 / dt, 2),
                           "ms_per_step": round(dt / 50 * 1e3, 3), "ms_per_50_step_sample": round(dt * 1e3, 2)}
@@ -638,7 +648,7 @@ def extra_legs(model, x, dev):
             def stepb():
                 zero(model)
                 model(x).backward()
-            dt = _time(_graphed(stepb, lambda: zero(model)), 20)
+            dt = _time(_graphed(stepb, lambda: zero(model)), 20, warm_s=LEG_WARM_S)
             out[key] = {"workload": f"headline step ([{x.shape[0]},2,2**18] fwd+bwd) with {env}={val}: kernel-3 convs and "
                                     f"weight gradients {what}",
                         "steps_per_s": round(1.0 / dt, 2), "ms_per_step": round(dt * 1e3, 3)}
@@ -664,7 +674,7 @@ def extra_legs(model, x, dev):
             def stepa():
                 zero(m)
                 m(x1, **kw).backward()
-            dt = _time(_graphed(stepa, lambda: zero(m)), 10)
+            dt = _time(_graphed(stepa, lambda: zero(m)), 10, warm_s=LEG_WARM_S)
             recs = profiled_step(m, lambda: m(x1, **kw).backward())
             out[name] = {"workload": f"UNetV0 README channels + {extra}, fwd+bwd at [1,2,2**18]"
                                      + (", embedding [1,64,768]" if use_emb else ""),

@@ -218,6 +218,15 @@ int64_t adp_modulation_bwd_partial(const float* x, const float* dy, const float*
                                    void* stream);
 int adp_modulation_bwd_reduce(const float* const* ws, float* const* dss, int64_t n, int64_t B, int64_t C, int64_t NT,
                               int64_t dss_bstride, void* stream);
+/* Backward of adp_modulation_ln_fwd's pair for the `xn` output in one pass: d(xn) -> d(y) (LayerNorm backward with affine
+ * `gamma`, statistics ln_stats, + the residual gradient dres, may be NULL) -> d(x) (the Modulation's backward as
+ * adp_modulation_bwd_partial: per-tile channel sums to ws, tile count returned, summed later by adp_modulation_bwd_reduce).
+ * [dgamma | dbeta] of the LayerNorm to dgamma_dbeta (accumulate != 0: added).  y = the Modulation's output (read only when the
+ * tensors do not allow the 16-byte form); ws and ws_ln: adp_chan_ln_bwd_ws_bytes(B, C, L) each. */
+int64_t adp_modulation_ln_bwd_partial(const float* x, const float* ss, int64_t ss_bstride, const float* stats,
+                                      const float* y, const float* dxn, const float* gamma, const float* ln_stats,
+                                      const float* dres, int64_t B, int64_t C, int64_t L, int64_t accumulate, float* dx,
+                                      float* ws, float* dgamma_dbeta, float* ws_ln, void* stream);
 
 /* LayerNorm-over-channels statistics only (LayerNorm prologue of the attention projections, components.py:92-93) */
 int adp_ln_stats(const float* x, int64_t B, int64_t C, int64_t L, float eps, float* stats, void* stream);

@@ -1051,6 +1051,44 @@ def test_modulation_ln_fwd(dev, B, C, L, dual):
         assert rel_err(cn, cn_ref) < TOL and rel_err(cn, cn0) < 1e-5
 
 
+@pytest.mark.parametrize("B,C,L,res", [(2, 8, 300, True), (2, 32, 72, False), (1, 130, 64, True), (2, 300, 40, True),
+                                       (1, 1024, 24, True), (4, 512, 784, True), (2, 1024, 128, False),
+                                       (2, 100, 50, True)])   # (L % 4 != 0: the two launches it stands for)
+def test_modulation_ln_bwd(dev, B, C, L, res):
+    """adp_modulation_ln_bwd_partial (norm.hip, chan_lnv_bwd_chain_kernel): d(xn) -> d(y) -> d(x) through the attention item's
+    LayerNorm and the ModulationItem in front of it in one pass, against torch autograd and against the two separate calls
+    (adp_ln_bwd, adp_modulation_bwd_partial): dx, the LayerNorm's [dgamma | dbeta], the Modulation's scale / shift gradient."""
+    x = (rnd(B, C, L, seed=1) * 1.5 + 0.4).requires_grad_()
+    NT = 2 * C + 7
+    bank = (rnd(B, NT, seed=2) * 0.5).requires_grad_()
+    off = 3
+    scale, shift = bank[:, off:off + C], bank[:, off + C:off + 2 * C]
+    g1 = (rnd(C, seed=10) * 0.5 + 1.0).requires_grad_()
+    b1 = (rnd(C, seed=11) * 0.5).requires_grad_()
+    y = F.layer_norm(x.transpose(1, 2), (C,), eps=ops.MODULATION_LN_EPS) * (1 + scale[:, None, :]) + shift[:, None, :]
+    xn = F.layer_norm(y, (C,), g1, b1, eps=ops.ATTENTION_LN_EPS).transpose(1, 2)
+    dxn, dres = rnd(B, C, L, seed=3), rnd(B, C, L, seed=4)
+    out = (xn * dxn).sum() + ((y.transpose(1, 2) * dres).sum() if res else 0.0)
+    dx_ref, dbank_ref, dg_ref, db_ref = torch.autograd.grad(out, (x, bank, g1, b1))
+    xd, bank_d, g1d, b1d = x.detach().to(dev), bank.detach().to(dev), g1.detach().to(dev), b1.detach().to(dev)
+    ssv = bank_d.view(-1)[off:]
+    yd, st, xnd, _, lst = ops.modulation_ln_fwd(xd, ssv, NT, g1d, b1d)
+    dxn_d, dres_d = dxn.to(dev), (dres.to(dev) if res else None)
+    # one pass
+    sums, dbank = ops.ModulationSums(), torch.zeros(B, NT, device=dev)
+    dgb = torch.full((2 * C,), float("nan"), device=dev)
+    dx = sums.partial_ln(off, xd, ssv, NT, st, dbank.view(-1)[off:], NT, yd, dxn_d, g1d, lst, dres_d, dgb)
+    sums.flush()
+    assert rel_err(dx, dx_ref) < TOL and rel_err(dbank, dbank_ref) < TOL
+    assert rel_err(dgb[:C], dg_ref) < TOL and rel_err(dgb[C:], db_ref) < TOL
+    # the two calls it replaces
+    dy0, dgb0 = ops.ln_bwd(yd, dxn_d, lst, g1d, dres=dres_d)
+    sums0, dbank0 = ops.ModulationSums(), torch.zeros(B, NT, device=dev)
+    dx0 = sums0.partial(off, xd, dy0, ssv, NT, st, dbank0.view(-1)[off:], NT)
+    sums0.flush()
+    assert rel_err(dx, dx0) < 2e-5 and rel_err(dbank, dbank0) < 2e-5 and rel_err(dgb, dgb0) < 2e-5
+
+
 @pytest.mark.parametrize("B,C,L,n", [(2, 64, 200, 3), (1, 32, 9000, 2), (2, 1024, 12, 9)])
 def test_modulation_bwd_parked_sums(dev, B, C, L, n):
     """adp_modulation_bwd_partial + adp_modulation_bwd_reduce: n Modulation backwards of one shape, second stages summed by

@@ -211,6 +211,7 @@ def test_unet_attention_self_and_cross(dev, batch, bank, fuse, monkeypatch):
     from audio_diffusion_pytorch_amd import unet as unet_mod
     monkeypatch.setenv("ADP_CTX_BANK", bank)
     monkeypatch.setattr(unet_mod, "MOD_LN_FUSE", fuse)
+    monkeypatch.setattr(unet_mod, "MOD_LN_BWD_FUSE", batch == 2)  # (the batch-1 case keeps the separate backward launches)
     oracle, net = build_pair(ATTN, dev)
     g = torch.Generator().manual_seed(4)
     x = torch.randn(batch, 2, 96, generator=g)
@@ -226,6 +227,32 @@ def test_unet_attention_self_and_cross(dev, batch, bank, fuse, monkeypatch):
     compare_grads(net, oracle)
     assert rel_err(emb_d.grad, emb.grad) < TOL
     assert (getattr(net.net if hasattr(net, "net") else net, "_ctx_tables", None) is not None) == (bank == "1")
+
+
+@pytest.mark.parametrize("batch,fuse_bwd", [(1, True), (2, True), (2, False)])
+def test_unet_cross_attention_behind_modulation(dev, batch, fuse_bwd, monkeypatch):
+    """BASELINE config 4's layout at tiny size: CrossAttentionItems directly behind the ModulationItems (no self attention in
+    between).  The Modulation forms the item's LayerNorm in its own launch and, with fuse_bwd, runs that LayerNorm's backward
+    inside its own (adp_modulation_ln_fwd / adp_modulation_ln_bwd_partial); both settings against the oracle."""
+    from audio_diffusion_pytorch_amd import unet as unet_mod
+    monkeypatch.setattr(unet_mod, "MOD_LN_BWD_FUSE", fuse_bwd)
+    cfg = dict(ATTN, attentions=[0, 0, 0], cross_attentions=[0, 1, 1])
+    oracle, net = build_pair(cfg, dev)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(batch, 2, 96, generator=g)
+    t = torch.tensor([0.15, 0.65][:batch])
+    emb = torch.randn(batch, 5, 12, generator=g).requires_grad_()
+    y_ref = oracle(x, t, embedding=emb)
+    emb_d = emb.detach().to(dev).requires_grad_()
+    y = net(x.to(dev), t.to(dev), embedding=emb_d)
+    assert rel_err(y, y_ref) < TOL
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    y.backward(gy.to(dev))
+    compare_grads(net, oracle)
+    assert rel_err(emb_d.grad, emb.grad) < TOL
+    inner = net.net if hasattr(net, "net") else net
+    assert getattr(inner, "_ln_deferred", 0) == (6 if fuse_bwd else 0)  # 2 sides x (1 + 2) cross-attention items
 
 
 def test_classifier_free_guidance(dev):
