@@ -14,6 +14,8 @@ from contextlib import nullcontext
 from math import pi
 from typing import Any, List, Optional, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -193,6 +195,23 @@ class VSampler(Sampler):
         ab = torch.stack([alphas[:-1], betas[:-1], alphas[1:], betas[1:]], dim=1).contiguous()
         return sigmas[:, None].expand(num_steps + 1, b).contiguous(), ab
 
+    HOIST_MAX_BYTES = 512 << 20  # cap of the hoisted conditioning table (README net: 360 KB per step and batch element)
+
+    def _conditioning_table(self, sig: Tensor, num_steps: int, b: int, kwargs) -> Optional[Tensor]:
+        """[num_steps, B, bank_total] or None.  The time values of ALL steps are known before the loop starts, and what the
+        U-Net derives from them (time MLP, then the conditioning bank: one row of 90 K scale / shift values per call in the
+        README configuration, 184 MB of weights streamed per call) does not depend on x: one batched pass in front of the
+        loop replaces eight launches per step.  Only for a bare UNetV0 (the plugin wrappers re-shape their arguments) without
+        `features`; ADP_SAMPLER_HOIST=0 keeps the per-step conditioning (A/B)."""
+        table_fn = getattr(self.net, "conditioning_table", None)
+        if table_fn is None or kwargs.get("features") is not None or os.environ.get("ADP_SAMPLER_HOIST", "1") == "0":
+            return None
+        total = getattr(self.net, "bank_total", 0)
+        if total <= 0 or 4 * num_steps * b * total > self.HOIST_MAX_BYTES:
+            return None
+        table = table_fn(sig[:num_steps])
+        return None if table is None else table.view(num_steps, b, total)
+
     @torch.no_grad()
     def forward(self, x_noisy: Tensor, num_steps: int, show_progress: bool = False, **kwargs) -> Tensor:
         with _on_device_of(x_noisy):
@@ -202,21 +221,23 @@ class VSampler(Sampler):
             prepare = getattr(self.net, "prepare_sampling_kwargs", None)
             if prepare is not None:  # e.g. text -> embedding tensor, once per sampling run
                 kwargs = prepare(x, kwargs)
+            cond = self._conditioning_table(sig, num_steps, b, kwargs)
             if self.use_graph and x.is_cuda and not show_progress:
-                out = self._forward_graph(x, sig, ab, num_steps, kwargs)
+                out = self._forward_graph(x, sig, ab, num_steps, kwargs, cond)
                 if out is not None:
                     return out
             bar = tqdm(range(num_steps), disable=not show_progress)
             host_sigmas = torch.linspace(self.schedule.start, self.schedule.end, num_steps + 1).tolist() \
                 if (show_progress and isinstance(self.schedule, LinearSchedule)) else None
             for i in bar:
-                v = self.net(x, sig[i], **kwargs)
+                v = self.net(x, sig[i], **kwargs) if cond is None else self.net(x, sig[i], conditioning=cond[i], **kwargs)
                 x = ops.v_step(x, v.contiguous(), ab[i])
                 if host_sigmas is not None:
                     bar.set_description(f"Sampling (noise={host_sigmas[i + 1]:.2f})")
             return x
 
-    def _forward_graph(self, x: Tensor, sig: Tensor, ab: Tensor, num_steps: int, kwargs) -> Optional[Tensor]:
+    def _forward_graph(self, x: Tensor, sig: Tensor, ab: Tensor, num_steps: int, kwargs,
+                       cond: Optional[Tensor] = None) -> Optional[Tensor]:
         """One step = U-Net forward + rotation kernel, captured once per call STRUCTURE and replayed.  The cache key
         is (x shape, kwarg names, tensor shapes/dtypes, python scalar values); the entry owns static copies of every
         tensor kwarg (also those nested in `channels`) and the caller's tensors are copied into them before the
@@ -228,10 +249,11 @@ class VSampler(Sampler):
         specs = tuple((k, _kw_spec(kwargs[k], live)) for k in names)
         if any(sp is None for _, sp in specs) or any(not t.is_cuda for t in live):
             return None
-        key = (tuple(x.shape), x.device, specs)
+        key = (tuple(x.shape), x.device, specs, cond is not None)
         entry = self._graph_cache.get(key)
         if entry is None:
             sx, ssig, sab = torch.empty_like(x), torch.empty_like(sig[0]), torch.empty_like(ab[0])
+            scond = torch.empty_like(cond[0]) if cond is not None else None  # this step's rows of the hoisted conditioning
             statics = [torch.empty_like(t, memory_format=torch.contiguous_format) for t in live]
             sx.copy_(x)
             ssig.copy_(sig[0])
@@ -240,6 +262,9 @@ class VSampler(Sampler):
                 st.copy_(t)
             it = iter(statics)
             skw = {k: _kw_rebuild(kwargs[k], it) for k in names}
+            if scond is not None:
+                scond.copy_(cond[0])
+                skw["conditioning"] = scond
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):  # warm-up outside capture
@@ -250,18 +275,21 @@ class VSampler(Sampler):
             with torch.cuda.graph(graph):
                 v = self.net(sx, ssig, **skw)
                 ops.v_step(sx, v.contiguous(), sab, out=sx)  # in place: each element is read then written
-            entry = (graph, sx, ssig, sab, statics)
+            entry = (graph, sx, ssig, sab, statics, scond)
             self._graph_cache[key] = entry
             while len(self._graph_cache) > self.GRAPH_CACHE_ENTRIES:
                 self._graph_cache.popitem(last=False)  # least recently used graph + its buffers
         else:
             self._graph_cache.move_to_end(key)
-        graph, sx, ssig, sab, statics = entry
+        graph, sx, ssig, sab, statics, scond = entry
         sx.copy_(x)
         for st, t in zip(statics, live):
             st.copy_(t)
         for i in range(num_steps):
-            ssig.copy_(sig[i])
+            if scond is not None:
+                scond.copy_(cond[i])  # (the captured step no longer reads the sigma row)
+            else:
+                ssig.copy_(sig[i])
             sab.copy_(ab[i])
             graph.replay()
         return sx.clone()

@@ -417,7 +417,14 @@ class UNetV0Net(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, x: Tensor, time: Optional[Tensor] = None, *, features: Optional[Tensor] = None,
                 embedding: Optional[Tensor] = None, channels: Optional[Sequence[Optional[Tensor]]] = None,
-                x_append: Optional[Tensor] = None) -> Tensor:
+                x_append: Optional[Tensor] = None, conditioning: Optional[Tensor] = None) -> Tensor:
+        """`conditioning` (inference only): the rows `conditioning_table` returned for this call's `time` values -- the time
+        MLP and the conditioning bank's projection are then skipped (VSampler hoists them out of its loop)."""
+        if conditioning is not None:
+            if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for _, p in self._named_params())):
+                raise RuntimeError("UNetV0.forward(conditioning=...) is an inference-only path (torch.no_grad())")
+            assert features is None and conditioning.shape == (x.shape[0], self.bank_total), \
+                "conditioning: [B, bank_total] rows of conditioning_table, without `features`"
         if self.use_time:
             assert time is not None, "TimeConditioningPlugin requires time in forward"
         elif time is not None:  # the reference's bare XUNet.forward takes x only (keyword conditioning)
@@ -427,15 +434,29 @@ class UNetV0Net(nn.Module):
             assert features is not None, "ModulationItem requires `features` when use_time_conditioning=False"
         params = [p for _, p in self._named_params()]
         ctx_list = [c for c in (channels or []) if c is not None]
+        # (inside an autograd Function's forward grad mode is always off and needs_input_grad only mirrors requires_grad: whether
+        #  anybody can ask for a backward pass has to be read HERE -- under torch.no_grad() nothing is recorded)
+        grad_on = torch.is_grad_enabled()
         if not x.is_cuda:  # CPU tensors only reach the kernels through the test-suite's SIMT emulator build
-            return _UNetFn.apply(self, x, time, features, embedding, x_append, channels, len(ctx_list), *ctx_list,
-                                 *params)
-        for t in (time, features, embedding, x_append, *ctx_list, params[0]):
+            return _UNetFn.apply(self, x, time, features, embedding, x_append, channels, len(ctx_list), conditioning,
+                                 grad_on, *ctx_list, *params)
+        for t in (time, features, embedding, x_append, conditioning, *ctx_list, params[0]):
             if t is not None and t.device != x.device:
                 raise RuntimeError(f"UNetV0: every tensor must live on the input's device {x.device}; got {t.device}")
         with torch.cuda.device(x.device):  # launches go to the current device's stream
-            return _UNetFn.apply(self, x, time, features, embedding, x_append, channels, len(ctx_list), *ctx_list,
-                                 *params)
+            return _UNetFn.apply(self, x, time, features, embedding, x_append, channels, len(ctx_list), conditioning,
+                                 grad_on, *ctx_list, *params)
+
+    @torch.no_grad()
+    def conditioning_table(self, times: Tensor) -> Optional[Tensor]:
+        """[T, bank_total]: what every Modulation / SkipModulate item reads (SiLU(time MLP) through the conditioning bank) for
+        each of the T time values, in one batched pass -- the bank's weights (the largest tensor of the net: 184 MB in the
+        README configuration) are streamed once per 16 rows instead of once per U-Net call.  None when this net has no time
+        conditioning (nothing to hoist).  Row b of a later call: forward(x, time, conditioning=table[rows of that call])."""
+        if not (self.use_time and self.bank_total > 0):
+            return None
+        run = _Run(self, False)
+        return run.conditioning(times.reshape(-1), None)
 
 
 NATIVE_FACTORS = (1, 2, 4)      # down/upsample factors with dedicated conv kernel variants
@@ -492,9 +513,14 @@ class _Run:
         return self.flat[a:a + numel]
 
     # -- conditioning ---------------------------------------------------------------------
-    def conditioning(self, time: Tensor, features: Optional[Tensor]):
+    def conditioning(self, time: Tensor, features: Optional[Tensor], ss_pre: Optional[Tensor] = None):
         n = self.net
         self.ss_all = self.dss_all = None
+        if ss_pre is not None:  # rows of UNetV0Net.conditioning_table (inference)
+            assert not self.need_grad
+            self.feats = None
+            self.ss_all = ss_pre.contiguous()
+            return self.ss_all
         if n.use_time:
             t = time.reshape(-1).to(torch.float32).contiguous()
             four = ops.time_fourier_fwd(t, n.time_weights)
@@ -817,9 +843,9 @@ class _Run:
 
 class _UNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, net: UNetV0Net, x, time, features, embedding, x_append, channels, n_ctx, *rest):
+    def forward(ctx, net: UNetV0Net, x, time, features, embedding, x_append, channels, n_ctx, cond_pre, grad_on, *rest):
         ctx_list, params = rest[:n_ctx], rest[n_ctx:]
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = bool(grad_on) and any(ctx.needs_input_grad)
         run = _Run(net, need_grad)
         run.skip_grads = []
         run.ctx_index = {}
@@ -832,7 +858,7 @@ class _UNetFn(torch.autograd.Function):
         run.ctx_needs = [bool(c.requires_grad) for c in ctx_list]
         x = x.contiguous()
         x2 = x_append.contiguous() if x_append is not None else None
-        run.conditioning(time, features)
+        run.conditioning(time, features, cond_pre if not need_grad else None)
         run.emb_grad = None
         run.want_emb_grad = bool(embedding is not None and ctx.needs_input_grad[4])
         run.ctx_bank = None
@@ -920,6 +946,6 @@ class _UNetFn(torch.autograd.Function):
         run.grads.clear()
         run.flat = None
         ctx.run = None
-        out = (None, gx, None, gfeat, gemb, None, None, None) + gctx + tuple(views)
+        out = (None, gx, None, gfeat, gemb, None, None, None, None, None) + gctx + tuple(views)
         del views, flat, v
         return out

@@ -854,6 +854,12 @@ def main():
             rf, hbm, extra, eager_ms = roofline_leg(model.module if world > 1 else model, x)
             line["roofline"] = rf
             if hbm:
+                copy = (calib or {}).get("copy_256MB_gbps")
+                if copy:  # the same launches against what a plain 16-byte copy reaches on THIS box (calibration probe)
+                    hbm["copy_ceiling_gbps"] = copy
+                    hbm["frac_of_copy_ceiling"] = round(hbm["achieved"] / copy, 4)
+                    if "replay_achieved" in hbm:
+                        hbm["replay_frac_of_copy_ceiling"] = round(hbm["replay_achieved"] / copy, 4)
                 line["roofline_hbm_convblock"] = hbm
             line["kernels"] = extra
             line["instrumented_kernel_ms_per_step"] = eager_ms

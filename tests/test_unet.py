@@ -151,6 +151,36 @@ def test_vsampler_matches_oracle(dev):
     assert rel_err(out, ref) < TOL
 
 
+@pytest.mark.parametrize("batch,steps", [(1, 4), (3, 7)])   # (3 x 7 = 21 table rows: more than one 16-row pass of the bank)
+def test_vsampler_hoisted_conditioning(dev, batch, steps, monkeypatch):
+    """VSampler forms the conditioning rows of ALL steps in one batched pass in front of its loop (UNetV0Net.conditioning_table)
+    and hands each call its rows: the table equals the per-call conditioning, and so does the sample
+    (ADP_SAMPLER_HOIST=0 = the per-step path); with `features` the per-step path is kept."""
+    from audio_diffusion_pytorch_amd import unet as unet_mod
+    # (bit for bit on the emulator; on the GPU a 16-row pass of the bank and a 1-row pass may round differently)
+    same = torch.equal if torch.device(dev).type == "cpu" else (lambda a, b: rel_err(a, b) < 1e-5)
+    torch.manual_seed(0)
+    model = adp.DiffusionModel(net_t=adp.UNetV0, sampler_use_graph=False, **TINY).to(dev)
+    net = model.net
+    noise = torch.randn(batch, 2, 128).to(dev)
+    sig, _ = model.sampler._tables(steps, batch, noise.device)
+    table = net.conditioning_table(sig[:steps])
+    assert table.shape == (steps * batch, net.bank_total)
+    for i in (0, steps - 1):
+        run = unet_mod._Run(net, False)
+        assert same(run.conditioning(sig[i], None), table[i * batch:(i + 1) * batch])
+    calls = []
+    orig = type(net).conditioning_table
+    monkeypatch.setattr(type(net), "conditioning_table", lambda self, t: (calls.append(1), orig(self, t))[1])
+    out = model.sample(noise, num_steps=steps)
+    assert len(calls) == 1
+    monkeypatch.setenv("ADP_SAMPLER_HOIST", "0")
+    ref = model.sample(noise, num_steps=steps)
+    assert len(calls) == 1 and same(out, ref)
+    with pytest.raises(RuntimeError):  # the precomputed rows are an inference-only input
+        net(noise.requires_grad_(), sig[0], conditioning=table[:batch])
+
+
 def test_upsampler_append_channels(dev):
     """DiffusionUpsampler: AppendChannelsPlugin input concat read through two base pointers (config 5 shape)."""
     from oracle.a_unet_restatement import AppendChannelsOracle
