@@ -23,8 +23,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_b1" -o trace --
 find "$O/prof_b1" -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$O/${TAG}_batch1_kernel_stats.csv"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_s" -o trace -- python "$ROOT/tools/sample_bench.py" --steps 10 --graph 0 > "$O/prof_s.log" 2>&1
 find "$O/prof_s" -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$O/${TAG}_sampler_b1_kernel_stats.csv"
-rm -rf "$O/prof_b4" "$O/prof_b1" "$O/prof_s"
+ADP_CFG_PROF_REPLAY=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c4" -o trace -- python "$ROOT/tools/cfg_prof.py" config4 3 > "$O/prof_c4.log" 2>&1
+find "$O/prof_c4" -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$O/${TAG}_config4_kernel_stats.csv"
+rm -rf "$O/prof_b4" "$O/prof_b1" "$O/prof_s" "$O/prof_c4"
 cd "$ROOT"
+if [ "${ADP_FINAL_MICRO:-0}" = "1" ]; then  # kernel-work microbenches (unchanged code: taken once per round)
 (timeout 120 python tools/mm4_micro.py 4) 2>&1 | grep -v "Warn\|amdgpu.ids" > "$O/${TAG}_mm4_micro.txt"
 (timeout 200 python tools/dp_capture_probe.py thread_local 4; timeout 200 python tools/dp_capture_probe.py thread_local 1) 2>&1 | grep "^\[" > "$O/${TAG}_dp_capture_probe.txt"
+fi
 ls -la "$O" | grep "$TAG"
