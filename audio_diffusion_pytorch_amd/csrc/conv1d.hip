@@ -852,6 +852,7 @@ extern "C" int adp_conv1d(const adp_conv_desc* dp, void* stream) {
   if (d.store == 2 && ((d.sp != 2 && d.sp != 4) || d.N % d.sp != 0 || d.bias)) return ADP_ERR_UNSUPPORTED;
   if (d.B > 65535 || adp_cdiv(d.M, 32) > 65535) return ADP_ERR_SHAPE;
   if (adp_conv_tile_eligible(d)) return adp_conv_tile(d, stream);
+  if (adp_conv_tilek_eligible(d)) return adp_conv_tilek(d, stream);
   if (adp_conv_mm4_eligible(d)) return adp_conv_mm4(d, stream);
   if (adp_conv_mm_eligible(d)) return adp_conv_mm(d, stream);
   if (adp_conv_direct_eligible(d)) return adp_conv_direct(d, stream);
@@ -865,7 +866,7 @@ extern "C" int64_t adp_conv1d_ws_bytes(const adp_conv_desc* dp) {
   if (!dp) return ADP_ERR_NULL;
   const adp_conv_desc& d = *dp;
   if (d.B <= 0 || d.R <= 0 || d.M <= 0 || d.N <= 0 || d.Lin <= 0) return ADP_ERR_SHAPE;
-  if (adp_conv_tile_eligible(d)) return 0;
+  if (adp_conv_tile_eligible(d) || adp_conv_tilek_eligible(d)) return 0;  // (tilek: the K split stays inside the workgroup)
   if (adp_conv_mm4_eligible(d)) {
     const int64_t ks4 = adp_conv_mm4_ksplit(d);
     return ks4 > 1 ? ks4 * d.B * d.M * d.N * (int64_t)sizeof(float) : 0;
@@ -881,6 +882,7 @@ extern "C" int64_t adp_conv1d_gn_entries(const adp_conv_desc* dp) {
   if (d.B <= 0 || d.R <= 0 || d.M <= 0 || d.N <= 0 || d.Lin <= 0) return ADP_ERR_SHAPE;
   if (d.store != 0 || d.M % 4 != 0) return 0;
   if (adp_conv_tile_eligible(d)) return adp_conv_tile_gn_entries(d);
+  if (adp_conv_tilek_eligible(d)) return adp_conv_tilek_gn_entries(d);
   if (adp_conv_mm4_eligible(d)) return adp_conv_mm4_gn_entries(d);
   // (the K split only happens when the caller passed its scratch: set d.ws before asking)
   if (adp_conv_mm_eligible(d))  // one slice per 64-position tile, or the K-split reduce kernel's slices
@@ -892,6 +894,7 @@ extern "C" int64_t adp_conv1d_gn_entries(const adp_conv_desc* dp) {
 extern "C" int64_t adp_conv1d_tile(const adp_conv_desc* dp) {
   if (!dp) return ADP_ERR_NULL;
   if (adp_conv_tile_eligible(*dp)) return 32 * 1000 + 64;   // wave-tile 32-channel kernel: 32 outputs x 64 positions per wave
+  if (adp_conv_tilek_eligible(*dp)) return 48000000 + 64;   // deep-layer wave tiles: 16 / 32 rows x 64 positions, 8 K slices per workgroup
   if (adp_conv_mm4_eligible(*dp)) return 64000000 + 32 * 1000 + 128;  // F(4,3) block: 6 planes x 4 K groups, 32 rows x 128 positions
   if (adp_conv_mm_eligible(*dp)) return adp_conv_mm_tile(*dp);
   if (adp_conv_direct_eligible(*dp)) return 8 * 1000 + 999;  // direct VALU kernel: 8 output channels x 1024 positions

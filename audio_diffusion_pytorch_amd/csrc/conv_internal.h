@@ -40,6 +40,12 @@ bool adp_conv_tile_eligible(const adp_conv_desc& d);
 int adp_conv_tile(const adp_conv_desc& d, void* stream);
 int64_t adp_conv_tile_gn_entries(const adp_conv_desc& d);  // GroupNorm partial slices per output row quad (gn_part)
 
+// conv_tilek.hip: the same wave tile for the deep layers whose tiles alone cannot fill the chip (>= 512 channels, <= 320 tiles):
+// eight waves of a workgroup split the input channels, 16- or 32-row tiles, no cross-workgroup K split / reduce launch
+bool adp_conv_tilek_eligible(const adp_conv_desc& d);
+int adp_conv_tilek(const adp_conv_desc& d, void* stream);
+int64_t adp_conv_tilek_gn_entries(const adp_conv_desc& d);  // one GroupNorm partial entry per row quad and 64-position tile
+
 // conv_direct.hip: VALU direct convolution for the narrow (2-8 channel) ends of the U-Net
 bool adp_conv_direct_eligible(const adp_conv_desc& d);
 int adp_conv_direct(const adp_conv_desc& d, void* stream);

@@ -113,7 +113,7 @@ def winograd_fraction(kernel: str) -> float:
     f32 MFMA peak; `frac_executed` = frac x this share is what the matrix pipes actually sustain."""
     head, _, rest = kernel.partition("<")
     args = [a.strip() for a in rest.rsplit(">", 1)[0].split(",")] if rest else []
-    if head.endswith("conv_mm4_kernel") or head.endswith("conv_tile32_kernel"):
+    if head.endswith("conv_mm4_kernel") or head.endswith("conv_tile32_kernel") or head.endswith("conv_tilek_kernel"):
         return 0.5
     if head.endswith("wgrad_mm_kernel") and len(args) >= 7:
         return 0.5 if (len(args) >= 8 and args[7] == "true") else (2.0 / 3.0 if args[6] == "true" else 1.0)

@@ -381,6 +381,56 @@ def test_conv_tile32(dev, nw, B, L, pro, res, shift, monkeypatch):
     assert rel_err(dx, F.conv_transpose1d(x, w, None, padding=1)) < TOL
 
 
+@pytest.mark.parametrize("rb", [1, 2])
+@pytest.mark.parametrize("B,R,M,L,res,shift", [(1, 256, 32, 128, 0, 0.0), (2, 512, 64, 192, 1, 0.0), (1, 256, 96, 64, 1, 100.0)])
+def test_conv_tilek(dev, rb, B, R, M, L, res, shift, monkeypatch):
+    """conv_tilek.hip: the wave tile of conv_tile.hip for the deep layers -- eight waves of a workgroup split the input
+    channels (16-channel chunks parked in wave-private LDS, U = G g built by the wave), partial tiles summed in LDS in wave
+    order, 16- or 32-row tiles (rb): forward with bias / residual and the GroupNorm partial statistics of the output, data
+    gradient (transposed weight view, taps flipped), non-square channel counts; against F.conv1d and the statistics of the
+    fp64 result (`shift`: output mean at 100 sigma)."""
+    from ctypes import byref
+    monkeypatch.setenv("ADP_TILEK_MIN_R", "256")
+    monkeypatch.setenv("ADP_TILEK_MIN_TILES", "1")
+    monkeypatch.setenv("ADP_TILEK_RB", str(rb))
+    G = 8
+    x = rnd(B, R, L, seed=1) * 1.3 + 0.2
+    w, b = rnd(M, R, 3, seed=2, scale=0.05), rnd(M, seed=3) + shift
+    r = rnd(B, M, L, seed=6) if res else None
+    xd, wd = x.to(dev), w.to(dev)
+    d = _C.ConvDesc(_C.ptr(xd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(xd), None, B, R, R, L, M, L,
+                    3, 1, 1, 1, 1, 0, 0, 1, 0, 1, 0)
+    assert _C.query("adp_conv1d_tile", byref(d)) == 48000064, "case must dispatch to the deep-layer wave-tile kernel"
+    assert _C.query("adp_conv1d_ws_bytes", byref(d)) == 0
+    gn = ops.GnPart()
+    ref = F.conv1d(x, w, b, padding=1)
+    out = ops.conv1d(xd, wd, b.to(dev), pad=1, res=r.to(dev) if res else None, gn=gn)
+    if res:
+        ref = ref + r
+    assert rel_err(out, ref) < TOL
+    assert gn.part is not None and gn.part.shape == (B, M // 4, L // 64, 3) and gn.part[..., 2].eq(256).all()
+    st = ops.gn_finalize(gn.part, G)
+    g64 = ref.double().view(B, G, -1)
+    assert rel_err(st[..., 0], g64.mean(-1)) < 2e-6
+    assert rel_err(st[..., 1], (g64.var(-1, unbiased=False) + 1e-5).rsqrt()) < 2e-5
+    # data gradient of the same conv: input = a [B, M, L] gradient, weight viewed transposed
+    gy = rnd(B, M, L, seed=7)
+    dx = ops.conv1d(gy.to(dev), wd, None, pad=1, transposed=True) if M >= 128 else None
+    if dx is not None:
+        assert rel_err(dx, F.conv_transpose1d(gy, w, None, padding=1)) < TOL
+    # ... and a gradient-shaped call that does dispatch here whatever M is: R and M swapped
+    w2 = rnd(R, M, 3, seed=8, scale=0.05)   # forward weight of a conv M -> R; its data gradient maps [B, R, L] -> [B, M, L]
+    gy2 = rnd(B, R, L, seed=9)
+    d2 = _C.ConvDesc(_C.ptr(xd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(xd), None, B, R, R, L, M, L,
+                     3, 1, 1, 1, 1, 1, 0, 1, 0, 1, 0)
+    assert _C.query("adp_conv1d_tile", byref(d2)) == 48000064
+    dx2 = ops.conv1d(gy2.to(dev), w2.to(dev), None, pad=1, transposed=True)
+    assert rel_err(dx2, F.conv_transpose1d(gy2, w2, None, padding=1)) < TOL
+    monkeypatch.setenv("ADP_CONV_TILEK", "0")  # the kernel family it replaces agrees
+    out0 = ops.conv1d(xd, wd, b.to(dev), pad=1, res=r.to(dev) if res else None)
+    assert rel_err(out, out0) < 1e-5
+
+
 def test_conv_tile32_trained_weight_dynamic_range(dev):
     """F(4,3)'s transform constants (1/24 ... 8) amplify fp32 rounding more than F(2,3) / the direct form: bound the wave-tile
     kernel's error against an fp64 reference at a TRAINED-weight-like dynamic range -- |w| log-uniform over 1e-3 ... 10 with

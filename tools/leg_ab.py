@@ -28,10 +28,14 @@ def apply(name, value):
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 2
-    leg = args[0]
-    B = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else (4 if leg == "headline" else 1)
     args = [a for a in args if not a.isdigit()]
     switches = [(a.split("=")[0], a.split("=")[1].split(",")) for a in args[1:]]
+    for leg in args[0].split(","):  # several layouts in one process: headline,batch1,config4
+        B = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else (4 if leg == "headline" else 1)
+        run_leg(leg, B, switches, rounds)
+
+
+def run_leg(leg, B, switches, rounds):
     extra, use_emb = LAYOUTS["batch1" if leg == "headline" else leg]
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
