@@ -1,0 +1,365 @@
+// Wave-tile Winograd F(4,3) convolution for the DEEP ConvBlock layers when their output tiles alone cannot fill the chip:
+// kernel 3, stride 1, 'same', 512-1024 channels over 128-1024 positions (ResnetItem ConvBlocks of depths 5-8 at batch 1, depth 8
+// at batch 4; /root/reference/audio_diffusion_pytorch/components.py:89; BASELINE configs 1, 3, 4).
+//
+// conv_mm / conv_mm4 give such a layer 64-128 blocks of 32 rows x 64-128 positions and fill the other CUs with a cross-workgroup
+// K split: partial tiles through HBM and a second launch that sums them (45 reduce launches per U-Net forward at batch 1).  Here
+// the K split stays INSIDE the workgroup and the tile can be 16 rows:
+//   * a workgroup owns one (16 RB) x 64 output tile; its 8 waves split the input channels (R / 8 each) and every wave runs
+//     conv_tile.hip's barrier-free wave tile on its own channels: 16-channel chunks fetched with coalesced 16-byte loads one
+//     chunk ahead; the x tile [16][66] is parked in a wave-PRIVATE LDS region, the weights never touch LDS: in the MFMA's A
+//     layout lane (j, kq) multiplies row j by channel 4 ks + kq, so each lane fetches exactly the 4 RB tap triples it will
+//     multiply (12-byte loads) and forms its six planes of U = G g in registers; F(4,3) on v_mfma_f32_16x16x4_f32 with V = B^T d
+//     formed in registers -- no workgroup barrier anywhere in the K loop, the SIMD's other waves cover one wave's load phases
+//     (first version: raw weights and U through LDS, 28-46 KB of LDS traffic per chunk and wave against 10 KB now -- the LDS, one
+//     per CU, was the bound: [1, 1024, 256] 18.3 us, [4, 1024, 128] 28.0 us);
+//   * the eight partial tiles meet in LDS once (after A^T: four values per lane and output row instead of six planes), summed in
+//     wave order by the 4 RB waves that also add bias / residual, store 16 bytes per lane and form the GroupNorm partial
+//     statistics of the output (shifted sums per row, Chan-combined per 4-channel row quad: conv_tile.hip's entry format);
+//   * 16-row tiles (RB = 1) double the tile count where 32-row tiles are fewer than ~200: [1, 1024, 256] is 256 workgroups of
+//     8 waves instead of 128 blocks x 2 K slices + a reduce launch.
+// Matrix work: half of the direct form's, three quarters of conv_mm's F(2,3).  fp32 throughout (error against fp64 ~1e-6 of the
+// output's max norm, tests/test_kernels.py).  Algorithmic bytes per launch: 4 * (B * R * L + B * M * L (+ residual) + 3 * M * R).
+#include <stdlib.h>
+#include "adp_rt.h"
+#include "adp.h"
+#include "conv_internal.h"
+
+namespace {
+
+constexpr int TK_KT = 3;
+constexpr int TK_TN = 64;            // positions per tile (16 output quads)
+constexpr int TK_CH = 16;            // channels per chunk (four K steps of v_mfma_f32_16x16x4_f32)
+constexpr int TK_NKW = 8;            // waves per workgroup = K slices
+
+// NCH: 16-channel chunks per wave, unrolled (4: 512 input channels, 8: 1024) -- in a rolled loop the chunk-ahead registers are
+// loop-carried values and the compiler parks them through register copies behind s_waitcnt vmcnt(0) at the back edge, which
+// turns the prefetch into a wait for what was just requested; 0 = rolled loop (any other channel count).
+// Tile = (16 RB) rows x (64 NB) positions, RB * NB <= 2: two ROW blocks share the lane's V = B^T d, two POSITION blocks share its
+// U = G g (and the weight loads, and one pair of halo columns per 128 positions: 96 cache lines of x per chunk and 128 positions
+// instead of 128 -- the kernel is bound by the CU's L1 fill rate).
+template <bool TR, int RB, int NB, int NCH>
+__global__ __launch_bounds__(64 * TK_NKW) void conv_tilek_kernel(adp_conv_desc d, int ntn) {
+  constexpr int PF = 2;                            // chunks in flight per wave (register sets)
+  const bool RES = d.res != nullptr, GN = d.gn_part != nullptr;  // (workgroup-uniform)
+  constexpr int ROWS = 16 * RB, TN = TK_TN * NB, NBLK = RB * NB;
+  constexpr int RSX = TN + 2;                      // LDS row of the x tile: index i <-> position n0 - 1 + i
+  constexpr int XF = TK_CH * RSX;
+  constexpr int YF = NBLK * 4 * 64 * 4;            // a wave's partial tile after A^T: [block][r][lane] float4
+  constexpr int WF = XF > YF ? XF : YF;            // one wave's region: x tile, later its partial tile
+  constexpr int XQ = 16 * NB, NXL = 4 * NB;        // float4 per x row, x loads per lane and chunk
+  __shared__ __attribute__((aligned(16))) float lds[TK_NKW * WF + TK_NKW * 8];
+  float* const gsh = lds + TK_NKW * WF;            // statistics scratch [wave][kq][2]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = adp_uniform(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;         // MFMA 16x16x4: lane = (row / quad column j, K index kq)
+  const int M = (int)d.M, R = (int)d.R, L = (int)d.Lin;
+
+  // ---- XCD-aware decode of the 1-D grid: an XCD gets a contiguous range of row tiles (its L2 keeps their weight slabs)
+  int id = blockIdx.x;
+  const int total = gridDim.x;
+  if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+  const int per_m = ntn * (int)d.B;
+  const int mt = id / per_m, rem = id - mt * per_m;
+  const int b = rem / ntn, nt = rem - b * ntn;
+  const int m0 = mt * ROWS, n0 = nt * TN;
+
+  const int kc = R / TK_NKW;                       // this wave's channels [c_lo, c_lo + kc)
+  const int c_lo = wave * kc, nchunks = NCH > 0 ? NCH : kc / TK_CH;
+  float* const X = lds + wave * WF;
+
+  // ---- chunk loads (registers, PF chunks ahead): x tile 16 rows x 16 NB quads = 4 NB float4 per lane + halo; weights 4 RB triples
+  const float* xb = d.x + ((int64_t)b * R + c_lo) * L + n0;
+  int xsrc[NXL], xdst[NXL];
+#pragma unroll
+  for (int i = 0; i < NXL; ++i) {
+    const int idx = lane + 64 * i, row = idx / XQ, quad = idx - row * XQ;
+    xsrc[i] = row * L + 4 * quad;
+    xdst[i] = row * RSX + 4 * quad + 1;
+  }
+  // halo: lanes 0-31 = (row, side); lanes 32-63 request the SAME addresses (no further cache lines) and do not write
+  const int hrow = lane & 15, hside = (lane >> 4) & 1;
+  const int hpos = hside ? TN : -1;
+  const bool hok = n0 + hpos >= 0 && n0 + hpos < L;
+  const int hoff = hrow * L + (hok ? hpos : 0);
+  // weights: lane (j, kq) needs w[m0 + 16 rb + j][c0 + 4 ks + kq][0..2] (TR: w[c0 + 4 ks + kq][m0 + 16 rb + j][.]), ks = 0..3
+  const float* wb = TR ? d.w + ((int64_t)(c_lo + kq) * M + m0 + j) * TK_KT : d.w + ((int64_t)(m0 + j) * R + c_lo + kq) * TK_KT;
+  const int w_ks = TR ? 4 * M * TK_KT : 4 * TK_KT;            // + 4 channels
+  const int w_rb = TR ? 16 * TK_KT : 16 * R * TK_KT;          // + 16 rows
+  // register sets: a chunk's loads are requested PF chunks ahead (a 16-channel chunk is 24-48 MFMAs = 0.4-0.7 us of matrix
+  // work, an L2 / HBM round trip 1-2 us)
+  struct ChunkRegs {
+    f32x4 x[NXL];
+    float w[RB][4][3];
+    float h;
+  };
+  auto load_chunk = [&](ChunkRegs& c, int chunk) {
+    const float* xp = xb + (int64_t)chunk * TK_CH * L;
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) c.x[i] = *reinterpret_cast<const f32x4*>(xp + xsrc[i]);
+    c.h = xp[hoff];
+    const float* wp = wb + (TR ? (int64_t)chunk * TK_CH * M * TK_KT : (int64_t)chunk * TK_CH * TK_KT);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) c.w[rb][ks][t] = wp[rb * w_rb + ks * w_ks + t];
+  };
+
+  // epilogue operands of the finishing waves (wave = 4 block + r, block = rb * NB + nb): requested before the K loop
+  const bool fin = wave < 4 * NBLK;
+  const int fblk = wave >> 2, fr = wave & 3;
+  const int frb = fblk / NB, fnb = fblk - frb * NB;
+  const int fch = m0 + 16 * frb + 4 * kq + fr;               // this lane's output channel when its wave finishes
+  const int64_t foff = ((int64_t)b * M + fch) * L + n0 + TK_TN * fnb + 4 * j;
+  f32x4 rv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  float bv = 0.0f;
+  if (fin) {
+    if (RES) rv = *reinterpret_cast<const f32x4*>(d.res + foff);
+    if (d.bias) bv = d.bias[fch];
+  }
+
+  f32x4 Macc[RB][NB][6];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int p = 0; p < 6; ++p) Macc[rb][nb][p] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  const float* Xr = X + kq * RSX + 4 * j;          // + 4 ks rows, + 64 nb positions
+
+  auto run_chunk = [&](ChunkRegs& cr, int next) {
+    // ---- park the x tile (index i of a row <-> position n0 - 1 + i)
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+      float* o = X + xdst[i];
+      o[0] = cr.x[i][0];
+      *reinterpret_cast<f32x2*>(o + 1) = f32x2{cr.x[i][1], cr.x[i][2]};  // even index: 8-byte aligned
+      o[3] = cr.x[i][3];
+    }
+    if (lane < 32) X[hrow * RSX + (hside ? RSX - 1 : 0)] = hok ? cr.h : 0.0f;  // zero padding
+    // ---- U = G g in registers; G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+    float uf[RB][4][6];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const float a = cr.w[rb][ks][0], g1 = cr.w[rb][ks][1], e = cr.w[rb][ks][2];
+        const float g0 = TR ? e : a, g2 = TR ? a : e;  // the data gradient runs the taps backwards
+        const float s02 = g0 + g2, q = 0.041666666666666664f * g0 + 0.16666666666666666f * g2;
+        uf[rb][ks][0] = 0.25f * g0;
+        uf[rb][ks][1] = -0.16666666666666666f * (s02 + g1);
+        uf[rb][ks][2] = -0.16666666666666666f * (s02 - g1);
+        uf[rb][ks][3] = q + 0.08333333333333333f * g1;
+        uf[rb][ks][4] = q - 0.08333333333333333f * g1;
+        uf[rb][ks][5] = g2;
+      }
+    adp_wave_sync();
+    // this set's next chunk, in flight under PF chunks of MFMAs.  UNCONDITIONAL (past the end the last chunk is fetched again
+    // and never used): a branch around the loads makes the compiler merge the two paths with register copies behind an
+    // s_waitcnt vmcnt(0) -- every iteration then waits for the loads it has just requested
+    load_chunk(cr, next < nchunks ? next : nchunks - 1);
+    // ---- four K steps: lane (j, kq) reads the six inputs around its quad(s) of channel 4 ks + kq
+    f32x2 dn[NB][3];
+    auto frags = [&](int ks) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dn[nb][q] = *reinterpret_cast<const f32x2*>(Xr + 4 * ks * RSX + TK_TN * nb + 2 * q);
+    };
+    frags(0);
+#pragma unroll
+    for (int ks = 0; ks < TK_CH / 4; ++ks) {
+      f32x2 dc[NB][3];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dc[nb][q] = dn[nb][q];
+      if (ks + 1 < TK_CH / 4) frags(ks + 1);
+      adp_sched_fence();
+      // B^T d: (4 d0 - 5 d2 + d4, -4 d1 - 4 d2 + d3 + d4, 4 d1 - 4 d2 - d3 + d4, -2 d1 - d2 + 2 d3 + d4,
+      //         2 d1 - d2 - 2 d3 + d4, 4 d1 - 5 d3 + d5)
+      float v[NB][6];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const float d0 = dc[nb][0][0], d1 = dc[nb][0][1], d2 = dc[nb][1][0], d3 = dc[nb][1][1], d4 = dc[nb][2][0],
+                    d5 = dc[nb][2][1];
+        const float a = fmaf(-4.0f, d2, d4), bb = fmaf(-4.0f, d1, d3), c = d4 - d2, e = 2.0f * (d3 - d1);
+        v[nb][0] = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));
+        v[nb][1] = a + bb;
+        v[nb][2] = a - bb;
+        v[nb][3] = c + e;
+        v[nb][4] = c - e;
+        v[nb][5] = fmaf(4.0f, d1, fmaf(-5.0f, d3, d5));
+      }
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) Macc[rb][nb][p] = adp_mfma16(uf[rb][ks][p], v[nb][p], Macc[rb][nb][p]);
+      adp_sched_fence();
+    }
+    adp_wave_sync();  // the next chunk overwrites this wave's tile
+  };
+  ChunkRegs cs[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) load_chunk(cs[i], i < nchunks ? i : nchunks - 1);
+  if (NCH > 0) {
+#pragma unroll
+    for (int chunk = 0; chunk < NCH; chunk += PF)
+#pragma unroll
+      for (int i = 0; i < PF; ++i) run_chunk(cs[i], chunk + i + PF);
+  } else {
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {  // (nchunks is even: eligibility)
+      run_chunk(cs[0], chunk + 2);
+      run_chunk(cs[1], chunk + 3);
+    }
+  }
+
+  // ---- y = A^T m per output row (A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]); the wave's partial tile goes
+  // to the head of its own region: [block][r][lane] float4
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float m0v = Macc[rb][nb][0][r], m1 = Macc[rb][nb][1][r], m2 = Macc[rb][nb][2][r], m3 = Macc[rb][nb][3][r],
+                    m4 = Macc[rb][nb][4][r], m5 = Macc[rb][nb][5][r];
+        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+        *reinterpret_cast<f32x4*>(X + (((rb * NB + nb) * 4 + r) * 64 + lane) * 4) =
+            f32x4{m0v + s12 + s34, fmaf(2.0f, d34, d12), fmaf(4.0f, s34, s12), fmaf(8.0f, d34, d12) + m5};
+      }
+  __syncthreads();
+  if (fin) {
+    // accumulator register r of block (rb, nb) <-> output channel 16 rb + 4 kq + r, column j = output quad of position block nb:
+    // this wave sums row (block, fr) of all K slices in wave order
+    f32x4 y = *reinterpret_cast<const f32x4*>(lds + ((fblk * 4 + fr) * 64 + lane) * 4);
+#pragma unroll
+    for (int w = 1; w < TK_NKW; ++w) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(lds + w * WF + ((fblk * 4 + fr) * 64 + lane) * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] += t[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[k] += bv;
+    if (RES) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] += rv[k];
+    }
+    *reinterpret_cast<f32x4*>(d.out + foff) = y;
+    if (GN) {
+      // (mean, M2) of this wave's 64 positions of channel fch, shifted by the row's first value (|mean| >> sigma costs no digits)
+      const float gk = __shfl(y[0], lane & 48, 64);
+      float s = 0.0f, q = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float e = y[k] - gk;
+        s += e;
+        q = fmaf(e, e, q);
+      }
+      const float sv = adp_row16_sum(s), qv = adp_row16_sum(q);
+      if (j == 0) {
+        gsh[(wave * 4 + kq) * 2] = gk + sv / (float)TK_TN;
+        gsh[(wave * 4 + kq) * 2 + 1] = fmaxf(qv - sv * (sv / (float)TK_TN), 0.0f);
+      }
+    }
+  }
+  if (GN) {
+    __syncthreads();
+    if (tid < 4 * NBLK) {
+      // row quad (rb, kq) over the 64 positions of block nb: its four channels were finished by waves 4 block + r, r = 0..3
+      // (Chan's pairwise update); one entry per row quad and 64-position slice
+      const int blk = tid >> 2, qk = tid & 3, rb = blk / NB, nb = blk - rb * NB;
+      constexpr float cnt = (float)TK_TN;
+      float mean = gsh[((4 * blk) * 4 + qk) * 2], m2 = gsh[((4 * blk) * 4 + qk) * 2 + 1], n = cnt;
+      for (int r = 1; r < 4; ++r) {
+        const float mw = gsh[((4 * blk + r) * 4 + qk) * 2], dl = mw - mean, nn = n + cnt;
+        mean += dl * (cnt / nn);
+        m2 += gsh[((4 * blk + r) * 4 + qk) * 2 + 1] + dl * dl * (n * cnt / nn);
+        n = nn;
+      }
+      float* e = d.gn_part + (((int64_t)b * (M / 4) + m0 / 4 + 4 * rb + qk) * (ntn * NB) + nt * NB + nb) * 3;
+      e[0] = mean;
+      e[1] = m2;
+      e[2] = n;
+    }
+  }
+}
+
+static int64_t tilek_tiles32(const adp_conv_desc& d) { return (d.M / 32) * d.B * (d.N / TK_TN); }
+
+// Tile shape (RB row blocks x NB position blocks of 16 x 64): 16 x 128 when those tiles alone give every CU a workgroup (the
+// position blocks share the weights and a pair of halo columns: fewest cache lines per MFMA), else 32 x 64 under the same
+// condition, else 16 x 64 (twice the workgroups).  ADP_TILEK_RB / ADP_TILEK_NB force a shape (tests, A/B).
+static void tilek_shape(const adp_conv_desc& d, int* rb, int* nb) {
+  const char* er = getenv("ADP_TILEK_RB");
+  const char* en = getenv("ADP_TILEK_NB");
+  const bool nb_ok = d.N % (2 * TK_TN) == 0;
+  *rb = 1, *nb = 1;
+  if (er && (er[0] == '1' || er[0] == '2')) {  // forced row blocks (position blocks only when asked for, with 16 rows)
+    *rb = er[0] - '0';
+    if (*rb == 1 && en && en[0] == '2' && nb_ok) *nb = 2;
+    return;
+  }
+  if (en && en[0] == '2' && nb_ok) {
+    *nb = 2;
+    return;
+  }
+  if (!(en && en[0] == '1') && nb_ok && (d.M / 16) * d.B * (d.N / (2 * TK_TN)) >= 200) *nb = 2;
+  else if (tilek_tiles32(d) >= 200) *rb = 2;
+}
+
+template <bool TR, int RB, int NB>
+int launch_tilek(const adp_conv_desc& d, void* stream) {
+  const int ntn = (int)(d.N / (TK_TN * NB));
+  const unsigned grid = (unsigned)((d.M / (16 * RB)) * d.B * ntn);
+  const int64_t nch = d.R / TK_NKW / TK_CH;
+  // (chunks in flight per wave: 2.  In-step A/B, hipGraph replay, same box, 2 -> 4: batch-1 step 6.22 -> 6.28 ms, config-4 layout
+  //  10.12 -> 10.19 ms -- the CUs are short of L1 fill rate, not of requests in flight)
+  if (nch == 4) ADP_LAUNCH((conv_tilek_kernel<TR, RB, NB, 4>), dim3(grid), dim3(64 * TK_NKW), stream, d, ntn);
+  else if (nch == 8) ADP_LAUNCH((conv_tilek_kernel<TR, RB, NB, 8>), dim3(grid), dim3(64 * TK_NKW), stream, d, ntn);
+  else ADP_LAUNCH((conv_tilek_kernel<TR, RB, NB, 0>), dim3(grid), dim3(64 * TK_NKW), stream, d, ntn);
+  return ADP_LAUNCH_OK();
+}
+
+}  // namespace
+
+// Taken where the output tiles alone leave the chip short of work (ADP_TILEK_MIN_TILES .. ADP_TILEK_MAX_TILES 32-row tiles,
+// default 100 .. 320: depths 5-7 at batch 1, depth 8 at batch 2-4) and the K loop is long enough to split eight ways in 16-channel chunks (ADP_TILEK_MIN_R, 512).
+// ADP_CONV_TILEK=0: those layers stay on conv_mm / conv_mm4 with their cross-workgroup K split (A/B).
+bool adp_conv_tilek_eligible(const adp_conv_desc& d) {
+  if (!adp_winograd_enabled()) return false;
+  const char* e = getenv("ADP_CONV_TILEK");
+  if (e && e[0] == '0') return false;
+  if (d.KT != TK_KT || d.stride != 1 || d.dil != 1 || d.pad != 1 || d.up != 1 || d.store != 0) return false;
+  if (d.prologue != 0 || d.x2 || d.R1 != d.R || d.out_pre || d.e_scale) return false;
+  const char* mr = getenv("ADP_TILEK_MIN_R");
+  if (d.R < (mr ? atoll(mr) : 512) || d.R % (2 * TK_NKW * TK_CH) != 0 || d.M % 32 != 0) return false;  // (chunk pairs)
+  if (d.N != d.Lin || d.N % TK_TN != 0) return false;
+  // hipGraph microbench, us per launch (conv2 + residual; mm = conv_mm / conv_mm4 incl. its reduce launch -> this kernel):
+  //   [1,512,1024] 17.4 -> 16.4 (32-row)   [1,512,512] 12.7 -> 10.0   [1,1024,256] 19.3 -> 16.5   [2,1024,128] 18.8 -> 16.1 (16-row)
+  //   [4,1024,128] 28.4 -> 25.9 (32-row; data gradient 28.0 -> 22.1)    [1,1024,128] 13.6 -> 15.7 and [8,1024,128] 40 -> 38: left out
+  const char* mt = getenv("ADP_TILEK_MAX_TILES");
+  const char* mn = getenv("ADP_TILEK_MIN_TILES");
+  if (tilek_tiles32(d) > (mt ? atoll(mt) : 320) || tilek_tiles32(d) < (mn ? atoll(mn) : 100)) return false;
+  if ((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.w) | reinterpret_cast<uintptr_t>(d.out) |
+       reinterpret_cast<uintptr_t>(d.res)) & 15)
+    return false;
+  if (d.B * d.R * d.Lin >= (int64_t)1 << 31 || d.M * d.R * d.KT >= (int64_t)1 << 31 || d.B * d.M * d.N >= (int64_t)1 << 40)
+    return false;
+  return true;
+}
+
+int64_t adp_conv_tilek_gn_entries(const adp_conv_desc& d) { return d.N / TK_TN; }
+
+int adp_conv_tilek(const adp_conv_desc& d, void* stream) {
+  int rb, nb;
+  tilek_shape(d, &rb, &nb);
+  if (nb == 2) return d.transposed ? launch_tilek<true, 1, 2>(d, stream) : launch_tilek<false, 1, 2>(d, stream);
+  if (rb == 2) return d.transposed ? launch_tilek<true, 2, 1>(d, stream) : launch_tilek<false, 2, 1>(d, stream);
+  return d.transposed ? launch_tilek<true, 1, 1>(d, stream) : launch_tilek<false, 1, 1>(d, stream);
+}
