@@ -341,6 +341,42 @@ def _read_clocks():
     return info
 
 
+def _mixed_kernel_probe(dev, ev_ms):
+    """us per launch of a hipGraph that cycles through eight different single-kernel library calls on tiny tensors."""
+    from audio_diffusion_pytorch_amd import ops
+    B, C, L, G = 1, 64, 256, 8
+    x, y, z = (torch.randn(B, C, L, device=dev) for _ in range(3))
+    st = ops.gn_stats(x, G)
+    gam, bet = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    ss = torch.randn(B, 2 * C, device=dev) * 0.1
+    x8, w8 = torch.randn(1, 8, 4096, device=dev), torch.randn(8, 8, 3, device=dev) * 0.1
+    o8 = torch.empty_like(x8)
+    ab = torch.tensor([0.3, 0.9, 0.5, 0.8], device=dev)
+    f2 = torch.randn(4, 512, device=dev)
+    lst, mst = torch.empty(B, L, 2, device=dev), torch.empty(B, L, 2, device=dev)
+
+    def round_():
+        ops.add(x, y, out=z)
+        ops.axpby(0.5, z, out=y)
+        ops.act_fwd(f2, 2)
+        ops.gn_act(x, st, G, gam, bet)
+        ops.modulation_fwd(x, ss.view(-1), 2 * C, y=z, stats=mst)
+        ops.ln_affine_fwd(z, gam, bet)
+        ops.conv1d(x8, w8, None, pad=1, out=o8)
+        ops.v_step(x, y, ab, out=z)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        round_()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(12):
+            round_()
+    return round(ev_ms(g.replay, 10) * 1e3 / (12 * 8), 3)
+
+
 def calibration(dev, busy=None):
     """What THIS box does on three kernels whose ideal rates are known (csrc/probe.hip), measured in the benchmarked
     process before the timed window -- so that two bench lines of the same code on two boxes can be told apart from a
@@ -404,6 +440,14 @@ def calibration(dev, busy=None):
             small[f"{mb}MB"] = round(ev_ms(g.replay, 5) * 1e3 / 50, 3)
             del g, pa, pb
         out["small_copy_us_per_launch"] = small
+        # DIFFERENT small kernels back to back (the step's ~470 small launches are ~40 different kernels, not one): eight
+        # single-launch library calls on tiny tensors, 12 rounds per hipGraph.  Boxes whose same-kernel probes above agree to the
+        # percent differ here (and in the step: 11.5 vs 12.6 ms with equal event-timed kernel durations) -- what a slow box adds
+        # is per launch of a kernel that is not the previous one
+        try:
+            out["graph_mixed_kernels_us_per_launch"] = _mixed_kernel_probe(dev, ev_ms)
+        except Exception as e:
+            out["graph_mixed_kernels_us_per_launch"] = {"error": f"{type(e).__name__}: {e}"}
         # load-to-use latency: one lane chasing a random cycle of 64-byte lines over working sets that sit in the L2 (1 MB),
         # the Infinity Cache (64 MB) and HBM (2 GB)
         lat = {}
@@ -433,7 +477,8 @@ def calibration(dev, busy=None):
     out["what"] = ("probes of csrc/probe.hip timed with HIP events in this process before the timed window: 256 MB float4 copy "
                    "(read + write bytes / time; 6290 GB/s is the best copy this pool has shown), register-only v_mfma_f32_32x32x2 "
                    f"loop against the {PEAK_F32_MFMA_TFLOPS} TF peak, hipGraph of 100 dependent empty kernels, hipGraphs of 50 dependent small "
-                   "copies (per launch), one lane chasing a random cycle of cache lines (ns per dependent load)")
+                   "copies (per launch), hipGraph of 96 launches cycling through eight different small library kernels (per launch), "
+                   "one lane chasing a random cycle of cache lines (ns per dependent load)")
     return out
 
 
