@@ -431,6 +431,37 @@ def test_conv_tilek(dev, rb, B, R, M, L, res, shift, monkeypatch):
     assert rel_err(out, out0) < 1e-5
 
 
+def test_conv_dispatch_of_the_readme_layers(emul):
+    """Which kernel family adp_conv1d picks for the ResnetItem ConvBlock convs of the README U-Net (channels
+    [8,32,64,128,256,512,512,1024,1024] at [B,2,2**18]) -- the table DESIGN.md section 4 describes, as a test: depth 1 on the
+    32-channel wave tile, the wide layers on the F(4,3) block, and the deep layers whose tiles cannot fill the chip on
+    conv_tilek (depths 5-7 at batch 1, depth 8 at batch 2-4) with NO split-K scratch, depth 8 at batch 1 / 8 on conv_mm."""
+    from ctypes import byref
+    a = torch.zeros(64)  # (aligned dummy storage: the queries never dereference)
+    p = _C.ptr(a)
+
+    def tile(B, C, L, tr=0):
+        d = _C.ConvDesc(p, None, p, None, None, None, None, None, None, p, None, B, C, C, L, C, L, 3, 1, 1, 1, 1, tr, 0, 1, 0,
+                        1, 0)
+        return _C.query("adp_conv1d_tile", byref(d)), _C.query("adp_conv1d_ws_bytes", byref(d))
+    TILE32, TILEK, MM4 = 32064, 48000064, 64032128
+    deep = {5: (512, 1024), 6: (512, 512), 7: (1024, 256), 8: (1024, 128)}
+    for tr in (0, 1):
+        assert tile(4, 32, 65536, tr)[0] == TILE32 and tile(1, 32, 65536, tr)[0] == TILE32
+        for B in (4, 8):
+            for depth in (3, 4, 5, 6, 7):
+                C, L = {3: (128, 4096), 4: (256, 2048), **deep}[depth]
+                assert tile(B, C, L, tr)[0] == MM4, (B, depth)
+        for depth in (5, 6, 7):
+            assert tile(1, *deep[depth], tr) == (TILEK, 0), depth
+        for B in (2, 4):
+            assert tile(B, *deep[8], tr) == (TILEK, 0), B
+        for B in (1, 8):  # 64 / 512 tiles of 32 x 64: outside conv_tilek's window
+            t, ws = tile(B, *deep[8], tr)
+            assert t != TILEK and t != TILE32, B
+        assert tile(1, *deep[8], tr)[1] > 0   # batch 1: conv_mm with its cross-workgroup K split (scratch for partial tiles)
+
+
 def test_conv_tile32_trained_weight_dynamic_range(dev):
     """F(4,3)'s transform constants (1/24 ... 8) amplify fp32 rounding more than F(2,3) / the direct form: bound the wave-tile
     kernel's error against an fp64 reference at a TRAINED-weight-like dynamic range -- |w| log-uniform over 1e-3 ... 10 with
