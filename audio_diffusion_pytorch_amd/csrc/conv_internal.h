@@ -34,7 +34,7 @@ int adp_conv_mm4(const adp_conv_desc& d, void* stream);
 int64_t adp_conv_mm4_gn_entries(const adp_conv_desc& d);  // two entries (row pairs) per row quad and 128-position tile
 int64_t adp_conv_mm4_ksplit(const adp_conv_desc& d);      // cross-workgroup K split (1 = none)
 
-// conv_tile.hip: barrier-free wave-tile kernel (wave-private LDS tile, Winograd F(2,3)) for the HBM-bound 32 -> 32 channel
+// conv_tile.hip: barrier-free wave-tile kernel (wave-private LDS tile, Winograd F(4,3)) for the HBM-bound 32 -> 32 channel
 // kernel-3 ConvBlock convs and their data gradients (depth 1)
 bool adp_conv_tile_eligible(const adp_conv_desc& d);
 int adp_conv_tile(const adp_conv_desc& d, void* stream);

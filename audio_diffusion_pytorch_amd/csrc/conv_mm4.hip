@@ -390,7 +390,7 @@ int64_t adp_conv_mm4_ksplit(const adp_conv_desc& d) {
   const char* e = getenv("ADP_MM4_KS_MAX");
   const int64_t ksmax = e ? atoll(e) : 1;
   const int64_t blocks = (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B, nchunks = d.R / 64;
-  if (d.store != 0) return 1;  // (the pooled store keeps its in-kernel epilogue)
+  if (d.store != 0 || d.up != 1) return 1;  // (the pooled store and the upsample loader keep their in-kernel epilogue)
   int64_t ks = 1;
   // (every slice keeps >= 8 chunks of 64 channels: at batch 1 the 512-channel layers would qualify with 4 and lose to conv_mm's
   //  64-position blocks -- batch-1 step 6.46 -> 6.53 ms; depth 8 at batch 4: step 12.16 -> 12.11 ms)
@@ -406,21 +406,25 @@ int64_t adp_conv_mm4_ksplit(const adp_conv_desc& d) {
 // default 400) so that two of them share a CU; else the 12-wave block.  Isolated launches at batch 4, us (tools/mm4_micro.py,
 // conv_mm F(2,3) -> 12-wave F(4,3) -> light): C=512 L=1024 45.9 -> 44.9 -> 39.8; C=256 L=2048 29.2 -> 29.0 -> 25.4; C=128 L=4096
 // 18.7 -> 21.3 -> 17.4; with one block per CU the light block loses (C=512 L=512 25.6 -> 22.5 -> 24.9).
+// The K split the launcher will really take: only with the caller's scratch (adp_conv1d_ws_bytes sizes it from the potential
+// split).  Block shape, GroupNorm entry count and the launch all read THIS value, so they cannot disagree.
+static int64_t m4_ks_eff(const adp_conv_desc& d) { return d.ws ? adp_conv_mm4_ksplit(d) : 1; }
+
 static int m4_nkg(const adp_conv_desc& d) {
   const char* e = getenv("ADP_MM4_LIGHT_MIN_BLOCKS");
-  const int64_t blocks = (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B * adp_conv_mm4_ksplit(d);
+  const int64_t blocks = (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B * m4_ks_eff(d);
   return blocks >= (e ? atoll(e) : 400) ? 2 : 4;
 }
 
 int64_t adp_conv_mm4_gn_entries(const adp_conv_desc& d) {
   if (d.store != 0) return 0;
-  if (d.ws && adp_conv_mm4_ksplit(d) > 1) return adp_conv_splitk_gn_entries(d);
+  if (m4_ks_eff(d) > 1) return adp_conv_splitk_gn_entries(d);
   return (m4_nkg(d) == 2 ? 1 : 2) * adp_cdiv(d.N, M4_BN);
 }
 
 int adp_conv_mm4(const adp_conv_desc& d, void* stream) {
   const int64_t blocks = (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B;
-  const int64_t ks = d.ws ? adp_conv_mm4_ksplit(d) : 1;  // (without the caller's scratch: the unsplit path, still correct)
+  const int64_t ks = m4_ks_eff(d);  // (without the caller's scratch: the unsplit path, still correct)
   const dim3 grid((unsigned)blocks, (unsigned)ks);
   if (d.up != 1) {  // UpsampleItem convs: the light block for grids of two blocks per CU, else 64-channel chunks (32 when R % 64)
     const bool light = m4_nkg(d) == 2, c64 = d.R % 64 == 0;

@@ -96,11 +96,15 @@ def fused_mse_loss(v_pred: Tensor, v_target: Tensor) -> Tensor:
 
 class VDiffusion(Diffusion):
     def __init__(self, net: nn.Module, sigma_distribution: Distribution = UniformDistribution(),
-                 loss_fn: Any = F.mse_loss):
+                 loss_fn: Any = F.mse_loss, use_graph: bool = True):
+        """`use_graph` (not in the reference): replay the training step from hipGraphs where that is safe (graphed.py) --
+        the README loop `loss = model(x); loss.backward()` then costs two graph launches instead of ~700 kernel launches
+        issued from Python; False (or ADP_TRAIN_GRAPH=0) = launch every kernel eagerly."""
         super().__init__()
         self.net = net
         self.sigma_distribution = sigma_distribution
         self.loss_fn = loss_fn
+        self.use_graph = use_graph
 
     def get_alpha_beta(self, sigmas: Tensor) -> Tuple[Tensor, Tensor]:
         angle = sigmas * pi / 2
@@ -108,6 +112,38 @@ class VDiffusion(Diffusion):
 
     def forward(self, x: Tensor, noise: Optional[Tensor] = None, **kwargs) -> Tensor:
         """`noise` (optional, default torch.randn_like(x) as at diffusion.py:88) lets a harness inject the draw."""
+        if self._graph_path_ok(x, noise):
+            with _on_device_of(x):
+                loss = self.train_graphs().run(x, noise, kwargs)
+            if loss is not None:
+                return loss
+        return self._forward_eager(x, noise, **kwargs)
+
+    def train_graphs(self):
+        """The captured training steps of this module (kept OFF the module: hipGraphs can be neither deep-copied nor pickled,
+        and an EMA copy.deepcopy(model) / torch.save(model) must keep working after a step has been captured)."""
+        from .graphed import GRAPHS_OF, TrainStepGraphs
+        graphs = GRAPHS_OF.get(self)
+        if graphs is None:
+            graphs = GRAPHS_OF[self] = TrainStepGraphs(self)
+        return graphs
+
+    def _graph_path_ok(self, x: Tensor, noise: Optional[Tensor]) -> bool:
+        """Whether this call may be served by the replayed step (graphed.py lists the conditions)."""
+        if not (self.use_graph and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()) or x.requires_grad:
+            return False
+        if noise is not None and (not noise.is_cuda or noise.requires_grad or noise.shape != x.shape):
+            return False
+        if type(self.sigma_distribution) is not UniformDistribution or os.environ.get("ADP_TRAIN_GRAPH", "1") == "0":
+            return False
+        if torch.cuda.is_current_stream_capturing():  # (a caller's own whole-step capture: bench.py, parallel.capture_step)
+            return False
+        hooked = self.__dict__.get("_hook_sites")
+        if hooked is None:  # the U-Nets whose backward may carry a data-parallel hook (collectives: not captured implicitly)
+            hooked = self.__dict__["_hook_sites"] = [m for m in self.net.modules() if hasattr(m, "_param_offsets")]
+        return all(getattr(m, "_grad_ready_hook", None) is None for m in hooked)
+
+    def _forward_eager(self, x: Tensor, noise: Optional[Tensor] = None, **kwargs) -> Tensor:
         batch_size, device = x.shape[0], x.device
         with _on_device_of(x):
             sigmas = self.sigma_distribution(num_samples=batch_size, device=device)

@@ -53,9 +53,11 @@ def capture_step(step, warmup: int = 2):
     return graph, graph.replay
 
 
-def init_process_group_from_env(backend: Optional[str] = None, graph_safe: bool = True) -> int:
-    """Initialises torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).  `graph_safe`
-    (default): with the settings of graph_safe_rccl_env, so that the data-parallel step can be replayed from a hipGraph."""
+def init_process_group_from_env(backend: Optional[str] = None, graph_safe: bool = False) -> int:
+    """Initialises torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).  `graph_safe=True`
+    (opt-in: only jobs that will call capture_step need it) applies the settings of graph_safe_rccl_env, so that the
+    data-parallel step can be replayed from a hipGraph -- at the price of the RCCL watchdog (a hung collective then hangs
+    until the launcher's timeout); a warning says so when the settings take effect.  Eager jobs keep the watchdog."""
     if dist.is_initialized():
         return dist.get_rank()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -64,6 +66,10 @@ def init_process_group_from_env(backend: Optional[str] = None, graph_safe: bool 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if graph_safe:
+        import warnings
+        warnings.warn("init_process_group_from_env(graph_safe=True): ProcessGroupNCCL's watchdog (async error handling, "
+                      "monitoring, dump on timeout) is switched off so that steps with collectives can be captured in a "
+                      "hipGraph; a failed or hung RCCL collective will not be aborted by torch", RuntimeWarning, stacklevel=2)
         graph_safe_rccl_env()
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":

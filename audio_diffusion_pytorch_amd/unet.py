@@ -348,13 +348,35 @@ class UNetV0Net(nn.Module):
     def _named_params(self):
         """[(name, parameter)] in registration order, walked ONCE: the module tree holds ~600 parameters and a traversal costs
         1-2 ms of host time -- four of them per step were a tenth of an eager step (the data-parallel path at N > 1 is eager).
-        The Parameter objects of a built net never change (`.to()` swaps their storage, not the objects)."""
+        The cache is VALIDATED on every call (one dict lookup + identity test per parameter, ~30 us): `.to()` swaps storages and
+        keeps the Parameter objects, but load_state_dict(assign=True), to_empty(), torch.__future__'s overwrite-on-conversion
+        and copy.deepcopy put NEW objects into the modules' `_parameters` dicts -- the kernels read those through the module
+        attributes, so gradients keyed on the old objects would land on orphans."""
         cached = getattr(self, "_named_cache", None)
-        if cached is None or getattr(self, "_named_cache_of", None) != id(self):
-            # (a copy.deepcopy of the net -- an EMA copy -- carries the original's cache, whose id() keys name other objects)
-            cached = self._named_cache = list(self.named_parameters())
+        holders = getattr(self, "_named_holders", None)
+        # (a copy.deepcopy of the net -- an EMA copy -- carries a structurally valid copy of the cache, but the id() keys of
+        #  _pname_cache name the ORIGINAL's objects)
+        if cached is not None and holders is not None and len(cached) == len(holders) \
+                and getattr(self, "_named_cache_of", None) == id(self):
+            for (_, p), (params, leaf) in zip(cached, holders):
+                if params.get(leaf) is not p:
+                    cached = None
+                    break
+        else:
+            cached = None
+        if cached is None:
+            cached, holders = [], []
+            for prefix, mod in self.named_modules():
+                for leaf, p in mod._parameters.items():
+                    if p is not None:
+                        cached.append((prefix + ("." if prefix else "") + leaf, p))
+                        holders.append((mod._parameters, leaf))
+            assert [n for n, _ in cached] == [n for n, _ in self.named_parameters()], \
+                "UNetV0Net: shared / re-registered parameters are not supported by the flat gradient layout"
+            self._named_cache, self._named_holders = cached, holders
             self._pname_cache = {id(p): n for n, p in cached}
             self._named_cache_of = id(self)
+            self._ctx_tables = None  # (pointer tables of the cross-attention context bank: rebuilt from the new objects)
         return cached
 
     def _param_offsets(self):
@@ -505,7 +527,12 @@ class _Run:
 
     # -- gradient destination views -------------------------------------------------------
     def g(self, p: nn.Parameter) -> Tensor:
-        return self.grads[self.pnames[id(p)]]
+        try:
+            return self.grads[self.pnames[id(p)]]
+        except KeyError:
+            raise RuntimeError("UNetV0: a parameter the kernels read is not one of the net's registered Parameters (replaced "
+                               "between forward and backward, or wrapped by nn.utils.parametrize -- not supported by the "
+                               "one-node U-Net: its gradient would have no slot in the flat gradient buffer)") from None
 
     def gspan(self, p_first: nn.Parameter, numel: int) -> Tensor:
         """Flat gradient slice starting at `p_first` and covering `numel` floats (adjacent parameters)."""

@@ -71,3 +71,26 @@ def test_winograd_fraction_by_kernel_instantiation():
     assert abs(f("conv_mm_kernel<64, 3, 1, 1, true, 0, 32, 2, true, 1>") - 2 / 3) < 1e-9
     assert f("conv_mm_kernel<64, 1, 1, 1, true, 0, 32, 2, false, 1>") == 1.0 and f("gn_bwd_apply_vec_kernel<256>") == 1.0
     assert f("wgrad_mm_kernel<64, 2, 2, 1, 0, 1, false, false>") == 1.0
+
+
+def test_bench_launches_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (how the driver calls --gpus 1) must start its two ranks itself; under a
+    launcher it must not.  GPU-less: the ranks stop after the rendezvous (gloo) -- flags parsed, process group joined from the
+    environment bench.py's own launcher set, one JSON line from rank 0."""
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["ADP_BENCH_RENDEZVOUS_ONLY"] = "1"
+    out = subprocess.run([sys.executable, bench.__file__, "--gpus", "2", "--steps", "7", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines == [{"rendezvous": "ok", "n_gpus": 2, "rank_sum": 3.0, "steps": 7}], out.stdout
+    # the command it builds is the contract's torchrun line with the caller's own flags
+    seen = {}
+    rc = bench._self_launch(4, argv=["--gpus", "4", "--steps", "3"], run=lambda cmd, env: seen.update(cmd=cmd, env=env) or 0)
+    assert rc == 0 and seen["cmd"][1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=4" in seen["cmd"] and seen["cmd"][-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["cmd"][seen["cmd"].index("--master-addr") + 1] == "127.0.0.1"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

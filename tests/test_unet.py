@@ -481,3 +481,27 @@ def test_deepcopy_of_a_net_keeps_working(emul):
     for n, p in twin.named_parameters():
         assert torch.equal(p.grad, ref[n]), n
     assert all(a is not b for a, b in zip(net.parameters(), twin.parameters()))
+
+
+def test_replaced_parameter_objects_are_followed(emul):
+    """load_state_dict(assign=True) (also to_empty / overwrite-on-conversion) puts NEW Parameter objects into the modules after
+    the net's per-net caches were built: the next step must key its gradients on the new objects (the kernels read them through
+    the module attributes), not on the orphaned ones."""
+    torch.manual_seed(0)
+    net = adp.UNetV0(dim=1, **TINY)
+    x, t = torch.randn(2, 2, 64), torch.tensor([0.3, 0.7])
+    net(x, t).square().mean().backward()  # builds the caches
+    torch.manual_seed(1)
+    donor = adp.UNetV0(dim=1, **TINY)
+    donor(x, t).square().mean().backward()
+    ref = {n: p.grad.clone() for n, p in donor.named_parameters()}
+    old = list(net.parameters())
+    net.load_state_dict({k: v.clone() for k, v in donor.state_dict().items()}, assign=True)
+    new = list(net.parameters())
+    assert all(a is not b for a, b in zip(old, new)), "assign=True is expected to replace the Parameter objects"
+    for p in new:
+        p.requires_grad_(True)
+        p.grad = None
+    net(x, t).square().mean().backward()
+    for n, p in net.named_parameters():
+        assert p.grad is not None and torch.equal(p.grad, ref[n]), n
