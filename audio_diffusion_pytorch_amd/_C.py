@@ -63,6 +63,8 @@ SIGNATURES = {
     "adp_gn_silu_bwd_reduce": (c_int, [P, P, P, P, P, I, I, I, I, I, P, P]),
     "adp_gn_silu_bwd_apply": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, I, P]),
     "adp_gn_param_grad": (c_int, [P, I, I, I, P, P, I, P]),
+    "adp_gn_silu_bwd_slab_ok": (I, [I, I, I, I]),
+    "adp_gn_silu_bwd_slab": (c_int, [P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, I, P]),
     "adp_modulation_fwd": (c_int, [P, P, I, I, I, I, F, P, P, P]),
     "adp_modulation_ln_fwd": (c_int, [P, P, I, I, I, I, F, P, P, F, P, P, P, P, P, P, P, P]),
     "adp_chan_ln_bwd_ws_bytes": (I, [I, I, I]),
@@ -107,6 +109,8 @@ SIGNATURES = {
     "adp_probe_mfma": (I, [I, P, I, P]),
     "adp_probe_launch": (c_int, [I, P]),
     "adp_probe_chase": (c_int, [P, I, P, P]),
+    "adp_probe_copy_v": (c_int, [P, P, I, c_int, P]),
+    "adp_probe_mfma_v": (I, [I, P, I, c_int, P]),
 }
 
 

@@ -30,6 +30,29 @@ __device__ __forceinline__ f32x4 adp_mfma16(float a, float b, f32x4 c) {
 // compiler scheduling fence: nothing moves across (keeps prefetch loads ahead of the matrix work that hides them)
 __device__ __forceinline__ void adp_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
+// nontemporal (streaming) global access: the data is not kept in the L2 / Infinity Cache
+template <class T> __device__ __forceinline__ T adp_nt_load(const T* p) { return __builtin_nontemporal_load(p); }
+template <class T> __device__ __forceinline__ void adp_nt_store(T v, T* p) { __builtin_nontemporal_store(v, p); }
+
+// Hand-off of a few words between WORKGROUPS of one launch (per-XCD L2s are not coherent with each other, a CU's L1 is never
+// refreshed by another CU's stores -- MI355X_MICROARCH.md, "inter-workgroup visibility"): the producer writes its payload with
+// write-through (sc1) stores, drains them (adp_drain_stores) and only then takes a ticket with an agent-scope atomic; the consumer
+// -- whoever draws the last ticket -- reads the payload with sc1 loads (L1 bypassed; its L2 cannot hold the lines: nobody on its
+// XCD read them in this launch).  No release / acquire fence (those write back / invalidate whole caches: microseconds).
+__device__ __forceinline__ void adp_agent_store(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float adp_agent_load(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int adp_agent_ticket(int* p) {
+  return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void adp_agent_store_int(int* p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void adp_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // v_rcp_f32 (1 ulp) instead of the IEEE division sequence
 __device__ __forceinline__ float adp_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
@@ -142,6 +165,38 @@ __device__ __forceinline__ void adp_wait_until(long long t) {
   while ((long long)wall_clock64() < t) __builtin_amdgcn_s_sleep(2);
 }
 
+#endif
+
+// Issue priority of the loader waves of the wave-specialised kernels (conv_mm4, wgrad_mm): compile-time A/B knob, default 0 =
+// no instruction (tools/ktrace.py build <tag> -DADP_LOADER_PRIO=2 builds a measurement library with it).
+#if defined(ADP_LOADER_PRIO) && !defined(ADP_EMULATE)
+#define ADP_LOADER_PRIO_SET() __builtin_amdgcn_s_setprio(ADP_LOADER_PRIO)
+#else
+#define ADP_LOADER_PRIO_SET()
+#endif
+
+// In-kernel timeline marks for kernel work (tools/ktrace.py builds a SEPARATE measurement library with -DADP_KTRACE; in the
+// product build every macro below is empty).  A wave's lane 0 drops the shader clock (s_memtime) into a per-wave row of 64
+// LDS slots -- no global traffic inside the loops being measured -- and the rows of the first blocks are dumped at the end.
+#if defined(ADP_KTRACE) && !defined(ADP_EMULATE)
+#define ADP_KT_DECL(buf)                                           \
+  __shared__ unsigned long long adp_kt_lds[16 * 64];               \
+  if (threadIdx.x < 1024) adp_kt_lds[threadIdx.x & 1023] = 0ull;   \
+  unsigned long long* const adp_kt_out = (buf);
+#define ADP_KT(slot)                                                                                          \
+  do {                                                                                                        \
+    if ((threadIdx.x & 63) == 0) adp_kt_lds[(threadIdx.x >> 6) * 64 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#define ADP_KT_DUMP(block_linear)                                                                                   \
+  do {                                                                                                              \
+    if (adp_kt_out && (block_linear) < 64)                                                                          \
+      adp_kt_out[((int64_t)(block_linear) * 16 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63)] =                   \
+          adp_kt_lds[(threadIdx.x >> 6) * 64 + (threadIdx.x & 63)];                                                 \
+  } while (0)
+#else
+#define ADP_KT_DECL(buf)
+#define ADP_KT(slot)
+#define ADP_KT_DUMP(block_linear)
 #endif
 
 // Launch trace (introspection only, see adp_launch_trace / adp_launch_times in adp.h): when tracing is on, every

@@ -26,6 +26,16 @@
 #include "adp.h"
 #include "conv_internal.h"
 
+#ifdef ADP_KTRACE
+static __device__ unsigned long long* m4_kt_buf = nullptr;
+extern "C" int adp_ktrace_set_mm4(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(m4_kt_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define M4_KT_BUF m4_kt_buf
+#else
+#define M4_KT_BUF nullptr
+#endif
+
 namespace {
 
 constexpr int M4_BM = 32, M4_BN = 128, M4_KT = 3;
@@ -53,7 +63,9 @@ __device__ __forceinline__ f32x4 m4_load_xquad(const float* p) {
 // UP: nearest-upsample factor folded into the X loader (the UpsampleItem convs); store mode 2 (runtime: the pooled store of
 //     their data gradients -- sums of sp = 2 / 4 adjacent outputs of the lane's quad, 8- / 4-byte stores, + residual)
 template <bool TR, int PD, int BKT, int M4_NKG, int UP = 1>
-__global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64) void conv_mm4_kernel(adp_conv_desc d) {
+// (second launch bound = waves per SIMD the register allocation has to leave room for: the light 8-wave block lives on TWO
+//  blocks per CU = 4 waves per SIMD = at most 128 registers; the 12-wave block on one = 3 per SIMD)
+__global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BKT == 32) ? 4 : 1) void conv_mm4_kernel(adp_conv_desc d) {
   constexpr int M4_NMMA = M4_NKG * M4_NPG, RPW = 16 / M4_NMMA;  // accumulator rows finished per wave (2 or 4)
   constexpr int M4_RED = M4_NKG * 6 * 1024;                     // parked partial tiles
   constexpr int M4_QK = BKT * M4_KT;                            // floats of a forward weight row per chunk
@@ -70,6 +82,8 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64) void conv_mm4_kern
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
   const int M = (int)d.M, R = (int)d.R, L = (int)d.Lin, N = (int)d.N;
+  ADP_KT_DECL(M4_KT_BUF)
+  ADP_KT(0);
 
   // ---- XCD-aware decode of the 1-D grid (each XCD gets a contiguous range of weight row tiles)
   int id = blockIdx.x;
@@ -91,9 +105,85 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64) void conv_mm4_kern
 
   if (wave >= M4_NMMA) {
     // =========================== loader waves (pure copies: global -> registers -> LDS) ===========================
+    ADP_LOADER_PRIO_SET();
     const int lt = tid - M4_NMMA * 64;
     const float* xb = d.x + (int64_t)b * R * L;
     const float* wbase = TR ? d.w + (int64_t)m0 * KT : d.w + (int64_t)m0 * R * KT;
+    if constexpr (UP == 1) {
+      if (N % M4_BN == 0) {
+        // ---- LEAN loader (round 6; full tiles: every ConvBlock conv of the README net).  tools/ktrace.py: at [4, 1024, 256] the
+        // MMA waves spent 1400-1700 of every chunk's ~5000 cycles in the barrier waiting for the LOADERS -- whose global loads
+        // had landed within 100-400 cycles, and whose ~130 instructions per chunk (four selects per staged quad for zero padding
+        // that only the two halo quads of a row can need, 64-bit address arithmetic and an LDS address per slot) then took
+        // 4000-4700 cycles of issue slots beside two MFMA waves per SIMD.  Here a lane's slots walk rows (X) / quad columns (A) at
+        // constant strides: one 32-bit lane offset per tile on wave-uniform bases, LDS addresses = base + immediates, no select on
+        // the 32 interior quads of an X row; the first 2 * BKT lanes stage the halo quads and are the only ones to test the row's ends.
+        constexpr int LPR = M4_NLT / M4_AROWS;        // lanes per A row (8, or 4 for the 64-row transposed view)
+        constexpr int NA = M4_AQ / LPR;               // A slots per lane (quad columns qq0 + LPR * i)
+        constexpr int NX = BKT / 8;                   // X slots per lane (rows row0 + 8 i of one interior quad column)
+        static_assert(M4_AQ % LPR == 0 && M4_NLT % M4_AROWS == 0, "A tile: whole quad columns per lane");
+        const int arow = lt / LPR, aq0 = lt % LPR;
+        const unsigned a_off = (unsigned)((TR ? arow * M * KT : arow * R * KT) + 4 * aq0);
+        const int a_lds = arow * AS + 4 * aq0;
+        const int xrow0 = lt >> 5, xpq = 1 + (lt & 31);
+        const unsigned x_off = (unsigned)(xrow0 * L + (n0 - 4 + 4 * xpq));
+        const int x_lds = xrow0 * XSP + 4 * xpq;
+        const bool halo_lane = lt < 2 * BKT;          // (wave-uniform: 2 * BKT is a multiple of 64)
+        const int hrow = lt % BKT, hside = lt / BKT;  // side 0: positions n0-4 .. n0-1, side 1: n0+128 .. n0+131
+        const int hu = hside ? n0 + M4_BN : n0 - 4;
+        const bool h_ok = hu >= 0 && hu < L;          // (a property of the tile, not of the chunk)
+        const unsigned h_off = (unsigned)(hrow * L + (h_ok ? hu : 0));
+        const int h_lds = hrow * XSP + (hside ? M4_BN + 4 : 0);
+        f32x4 ra[PD][NA], rx[PD][NX], rh[PD];
+        auto load_chunk = [&](f32x4 (&a)[NA], f32x4 (&x)[NX], f32x4& h, int chunk) {
+          const int rn = (c_lo + (chunk < nchunks ? chunk : nchunks - 1)) * BKT;  // (the tail re-reads the last chunk: never consumed)
+          const float* wp = TR ? wbase + (int64_t)rn * M * KT : wbase + rn * KT;  // wave-uniform
+          const float* xp = xb + (int64_t)rn * L;
+#pragma unroll
+          for (int i = 0; i < NA; ++i) a[i] = *reinterpret_cast<const f32x4*>(wp + (a_off + (unsigned)(4 * LPR * i)));
+#pragma unroll
+          for (int i = 0; i < NX; ++i) x[i] = *reinterpret_cast<const f32x4*>(xp + (x_off + (unsigned)(8 * i * L)));
+          if (halo_lane) h = *reinterpret_cast<const f32x4*>(xp + h_off);
+        };
+        auto store_chunk = [&](const f32x4 (&a)[NA], const f32x4 (&x)[NX], const f32x4& h, int chunk) {
+          float* Ab = smem + (chunk & 1) * (M4_A_ELEMS + M4_X_ELEMS);
+          float* Xb = Ab + M4_A_ELEMS;
+#pragma unroll
+          for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(Ab + a_lds + 4 * LPR * i) = a[i];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) *reinterpret_cast<f32x4*>(Xb + x_lds + 8 * i * XSP) = x[i];
+          if (halo_lane) {
+            f32x4 v = h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = h_ok ? v[j] : 0.0f;  // zero padding
+            *reinterpret_cast<f32x4*>(Xb + h_lds) = v;
+          }
+        };
+#pragma unroll
+        for (int s = 0; s < PD; ++s) load_chunk(ra[s], rx[s], rh[s], s);
+        for (int c0 = 0; c0 < nrounds; c0 += PD) {
+#pragma unroll
+          for (int s = 0; s < PD; ++s) {
+#ifdef ADP_KTRACE
+            if (c0 + s < 16) ADP_KT(1 + 3 * (c0 + s));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (c0 + s < 16) ADP_KT(2 + 3 * (c0 + s));
+#endif
+            store_chunk(ra[s], rx[s], rh[s], c0 + s);
+            load_chunk(ra[s], rx[s], rh[s], c0 + s + PD);
+#ifdef ADP_KTRACE
+            if (c0 + s < 16) ADP_KT(3 + 3 * (c0 + s));
+#endif
+            __syncthreads();  // B_c
+          }
+        }
+        ADP_KT(60);
+        __syncthreads();  // staging buffers free
+        __syncthreads();  // partial tiles parked
+        ADP_KT_DUMP(blockIdx.x);
+        return;
+      }
+    }
     int a_src[M4_NA4], a_dst[M4_NA4];
 #pragma unroll
     for (int i = 0; i < M4_NA4; ++i) {
@@ -143,13 +233,23 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64) void conv_mm4_kern
     for (int c0 = 0; c0 < nrounds; c0 += PD) {
 #pragma unroll
       for (int s = 0; s < PD; ++s) {
+#ifdef ADP_KTRACE
+        if (c0 + s < 16) ADP_KT(1 + 3 * (c0 + s));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (c0 + s < 16) ADP_KT(2 + 3 * (c0 + s));
+#endif
         store_chunk(ra[s], rx[s], c0 + s);
         load_chunk(ra[s], rx[s], c0 + s + PD);
+#ifdef ADP_KTRACE
+        if (c0 + s < 16) ADP_KT(3 + 3 * (c0 + s));
+#endif
         __syncthreads();  // B_c
       }
     }
+    ADP_KT(60);
     __syncthreads();  // staging buffers free
     __syncthreads();  // partial tiles parked
+    ADP_KT_DUMP(blockIdx.x);
     return;
   }
 
@@ -182,66 +282,103 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64) void conv_mm4_kern
   const bool edge = pg == 0 ? (l31 == 0) : (l31 == 31);
 
   for (int c = 0; c < nrounds; ++c) {
+#ifdef ADP_KTRACE
+    if (c < 16) ADP_KT(1 + 3 * c);
+#endif
     __syncthreads();  // B_c: chunk c is in LDS[c & 1]
+#ifdef ADP_KTRACE
+    if (c < 16) ADP_KT(2 + 3 * c);
+#endif
     if (c < nchunks) {
       const float* Ab = smem + (c & 1) * (M4_A_ELEMS + M4_X_ELEMS);
       const float* Xb = Ab + M4_A_ELEMS;
+      // The fragments of channel group sub + 1 are requested BEFORE the twelve MFMAs of group sub (round 6): left to itself the
+      // compiler kept ONE register set per group (ds_read, s_waitcnt lgkmcnt(0), transforms, MFMAs, next ds_read ...), so every
+      // group exposed an LDS round trip to the matrix pipe (tools/ktrace.py: ~4600 cycles per chunk and SIMD for 3072 of MFMAs).
+      auto load_frag = [&](float (&av)[4 * KT], f32x4 (&qx)[4], float (&hx)[4], int sub) {
+        const int ci = kg * CPK + sub * 8;
+        // av[cc * 3 + t] = tap t of channel ci + cc + 4 * hi for this lane's output row
+        if (!TR) {
+          const float* ap = Ab + afrag + ci * KT;
+#pragma unroll
+          for (int j = 0; j < KT; ++j) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(ap + 4 * j);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) av[4 * j + k] = q[k];
+          }
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int t = 0; t < KT; ++t) av[cc * KT + t] = Ab[afrag + (ci + cc) * AS + (KT - 1 - t)];
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          qx[cc] = *reinterpret_cast<const f32x4*>(Xb + xfrag + (ci + cc) * XSP);
+          hx[cc] = Xb[hfrag + (ci + cc) * XSP];  // one address per half-wave: a broadcast read
+        }
+      };
+      // (measured round 6 on the 12-wave block: no gain -- the pipe's idle time is the lock step of the two MMA waves of a SIMD
+      //  after each barrier, not the LDS round trips; -DADP_MM4_PIPE keeps the variant for A/B.  Never in the light block, which
+      //  has to stay within 128 registers to share its CU with a second block.)
+#ifdef ADP_MM4_PIPE
+      constexpr bool PIPE = (M4_NKG == 4);
+#else
+      constexpr bool PIPE = false;
+#endif
+      float avn[4 * KT], hxn[4];
+      f32x4 qxn[4];
+      if (PIPE) load_frag(avn, qxn, hxn, 0);
 #pragma unroll
       for (int sub = 0; sub < CPK / 8; ++sub) {
-      const int ci = kg * CPK + sub * 8;
-      float av[4 * KT];  // av[cc * 3 + t] = tap t of channel ci + cc + 4 * hi for this lane's output row
-      if (!TR) {
-        const float* ap = Ab + afrag + ci * KT;
+        float av[4 * KT], hx[4];
+        f32x4 qx[4];
+        if (PIPE) {
 #pragma unroll
-        for (int j = 0; j < KT; ++j) {
-          const f32x4 q = *reinterpret_cast<const f32x4*>(ap + 4 * j);
+          for (int j = 0; j < 4 * KT; ++j) av[j] = avn[j];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) av[4 * j + k] = q[k];
+          for (int j = 0; j < 4; ++j) qx[j] = qxn[j], hx[j] = hxn[j];
+          if (sub + 1 < CPK / 8) load_frag(avn, qxn, hxn, sub + 1);
+          adp_sched_fence();  // (the requests above stay above the matrix work that hides them)
+        } else {
+          load_frag(av, qx, hx, sub);
         }
-      } else {
+        if (pg == 0) {
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
+          for (int cc = 0; cc < 4; ++cc) {
+            const float d1 = qx[cc][0], d2 = qx[cc][1], d3 = qx[cc][2], d4 = qx[cc][3];
+            const float nb = adp_lane_prev(0.0f, d4);         // the left neighbour quad's last input
+            const float d0 = edge ? hx[cc] : nb;
+            const float g0 = av[cc * KT], g1 = av[cc * KT + 1], g2 = av[cc * KT + 2];
+            const float t1 = fmaf(-4.0f, d2, d4), t2 = fmaf(-4.0f, d1, d3);
+            const float gs = g0 + g2;
+            acc[0] = adp_mfma32(g0, fmaf(4.0f, d0, fmaf(-5.0f, d2, d4)), acc[0]);
+            acc[1] = adp_mfma32(gs + g1, t1 + t2, acc[1]);
+            acc[2] = adp_mfma32(gs - g1, t1 - t2, acc[2]);
+          }
+        } else {
 #pragma unroll
-          for (int t = 0; t < KT; ++t) av[cc * KT + t] = Ab[afrag + (ci + cc) * AS + (KT - 1 - t)];
-      }
-      f32x4 qx[4];
-      float hx[4];
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        qx[cc] = *reinterpret_cast<const f32x4*>(Xb + xfrag + (ci + cc) * XSP);
-        hx[cc] = Xb[hfrag + (ci + cc) * XSP];  // one address per half-wave: a broadcast read
-      }
-      if (pg == 0) {
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const float d1 = qx[cc][0], d2 = qx[cc][1], d3 = qx[cc][2], d4 = qx[cc][3];
-          const float nb = adp_lane_prev(0.0f, d4);         // the left neighbour quad's last input
-          const float d0 = edge ? hx[cc] : nb;
-          const float g0 = av[cc * KT], g1 = av[cc * KT + 1], g2 = av[cc * KT + 2];
-          const float t1 = fmaf(-4.0f, d2, d4), t2 = fmaf(-4.0f, d1, d3);
-          const float gs = g0 + g2;
-          acc[0] = adp_mfma32(g0, fmaf(4.0f, d0, fmaf(-5.0f, d2, d4)), acc[0]);
-          acc[1] = adp_mfma32(gs + g1, t1 + t2, acc[1]);
-          acc[2] = adp_mfma32(gs - g1, t1 - t2, acc[2]);
+          for (int cc = 0; cc < 4; ++cc) {
+            const float d1 = qx[cc][0], d2 = qx[cc][1], d3 = qx[cc][2], d4 = qx[cc][3];
+            const float nb = adp_lane_next(0.0f, d1);         // the right neighbour quad's first input
+            const float d5 = edge ? hx[cc] : nb;
+            const float g0 = av[cc * KT], g1 = av[cc * KT + 1], g2 = av[cc * KT + 2];
+            const float t3 = d4 - d2, t4 = d3 - d1;
+            const float gq = fmaf(4.0f, g2, g0);
+            acc[0] = adp_mfma32(fmaf(2.0f, g1, gq), fmaf(2.0f, t4, t3), acc[0]);
+            acc[1] = adp_mfma32(fmaf(-2.0f, g1, gq), fmaf(-2.0f, t4, t3), acc[1]);
+            acc[2] = adp_mfma32(g2, fmaf(4.0f, d1, fmaf(-5.0f, d3, d5)), acc[2]);
+          }
         }
-      } else {
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const float d1 = qx[cc][0], d2 = qx[cc][1], d3 = qx[cc][2], d4 = qx[cc][3];
-          const float nb = adp_lane_next(0.0f, d1);         // the right neighbour quad's first input
-          const float d5 = edge ? hx[cc] : nb;
-          const float g0 = av[cc * KT], g1 = av[cc * KT + 1], g2 = av[cc * KT + 2];
-          const float t3 = d4 - d2, t4 = d3 - d1;
-          const float gq = fmaf(4.0f, g2, g0);
-          acc[0] = adp_mfma32(fmaf(2.0f, g1, gq), fmaf(2.0f, t4, t3), acc[0]);
-          acc[1] = adp_mfma32(fmaf(-2.0f, g1, gq), fmaf(-2.0f, t4, t3), acc[1]);
-          acc[2] = adp_mfma32(g2, fmaf(4.0f, d1, fmaf(-5.0f, d3, d5)), acc[2]);
-        }
-      }
       }
     }
+#ifdef ADP_KTRACE
+    if (c < 16) ADP_KT(3 + 3 * c);
+#endif
   }
+  ADP_KT(60);
   __syncthreads();  // the staging buffers are free
+  ADP_KT(61);
 
   // ---- plane / K-group exchange through LDS: tile (kg, plane P) at smem[(kg * 6 + P) * 1024 + r * 64 + lane]
 #pragma unroll
@@ -344,6 +481,8 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64) void conv_mm4_kern
       e[2] = fcnt;
     }
   }
+  ADP_KT(63);
+  ADP_KT_DUMP(blockIdx.x);
 }
 
 int64_t m4_min_blocks() {
@@ -410,11 +549,18 @@ int64_t adp_conv_mm4_ksplit(const adp_conv_desc& d) {
 // split).  Block shape, GroupNorm entry count and the launch all read THIS value, so they cannot disagree.
 static int64_t m4_ks_eff(const adp_conv_desc& d) { return d.ws ? adp_conv_mm4_ksplit(d) : 1; }
 
-static int m4_nkg(const adp_conv_desc& d) {
+static bool m4_light(const adp_conv_desc& d) {
   const char* e = getenv("ADP_MM4_LIGHT_MIN_BLOCKS");
   const int64_t blocks = (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B * m4_ks_eff(d);
-  return blocks >= (e ? atoll(e) : 400) ? 2 : 4;
+  return blocks >= (e ? atoll(e) : 400);
 }
+// ONE MMA wave per SIMD for the grids of one block per CU (2 K groups x 2 plane groups + 4 loaders, 64-channel chunks):
+// ADP_MM4_SOLO=1 (A/B, round 6; tools/ktrace.py: the two MMA waves of a SIMD leave every chunk barrier in lock step)
+static bool m4_solo(const adp_conv_desc& d) {
+  const char* so = getenv("ADP_MM4_SOLO");
+  return so && so[0] == '1' && !m4_light(d) && d.up == 1 && d.R % 64 == 0 && m4_ks_eff(d) == 1;
+}
+static int m4_nkg(const adp_conv_desc& d) { return (m4_light(d) || m4_solo(d)) ? 2 : 4; }
 
 int64_t adp_conv_mm4_gn_entries(const adp_conv_desc& d) {
   if (d.store != 0) return 0;
@@ -438,6 +584,12 @@ int adp_conv_mm4(const adp_conv_desc& d, void* stream) {
       else if (c64) ADP_LAUNCH((conv_mm4_kernel<false, 1, 64, 4, 4>), grid, block, stream, d);
       else ADP_LAUNCH((conv_mm4_kernel<false, 1, 32, 4, 4>), grid, block, stream, d);
     }
+    return ADP_LAUNCH_OK();
+  }
+  if (m4_solo(d)) {
+    const dim3 block8((2 * M4_NPG + M4_NLD) * 64);
+    if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64, 2>), grid, block8, stream, d);
+    else ADP_LAUNCH((conv_mm4_kernel<false, 1, 64, 2>), grid, block8, stream, d);
     return ADP_LAUNCH_OK();
   }
   if (m4_nkg(d) == 2) {  // light block: 32-channel chunks (60 KB of LDS: two blocks per CU)

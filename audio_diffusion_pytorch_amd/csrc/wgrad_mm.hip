@@ -33,6 +33,16 @@ struct adp_wg_items {
   float* ws[ADP_WGR_BATCH];
 };
 
+#ifdef ADP_KTRACE
+static __device__ unsigned long long* wg_kt_buf = nullptr;
+extern "C" int adp_ktrace_set_wgrad(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(wg_kt_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define WG_KT_BUF wg_kt_buf
+#else
+#define WG_KT_BUF nullptr
+#endif
+
 namespace {
 
 struct __attribute__((packed, aligned(4))) adp_f32x3 {  // 12-byte global access (global_store_dwordx3)
@@ -91,8 +101,13 @@ constexpr int WG_NLD = 4;  // loader waves per block
 // direct form twelve; six accumulator tiles; G^T with its constants once at the end:
 //     dw0 = P0/4 - (P1+P2)/6 + (P3+P4)/24     dw1 = (P2-P1)/6 + (P3-P4)/12     dw2 = -(P1+P2)/6 + (P3+P4)/6 + P5
 // 21 VALU ops per 6 MFMAs on fragments the lane reads anyway (the F(2,3) form: 7 per 8); fp32 error ~1e-6 of the max norm.
-template <int BM, int KT, int S, int UP, int PRO, int PD, bool WN = false, bool W4 = false>
-__global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NLD) * 64) void wgrad_mm_kernel(
+// NKGP: in-block K groups (0 = the default: 2 for 64 x 64 tiles, 4 for 32 x 32).  1 = ONE MMA wave per SIMD (round 6): the
+// in-kernel timeline showed the two MMA waves of a SIMD leaving every chunk barrier in lock step, the older one winning the
+// arbitration for ~3100 cycles and the younger one closing the barrier ~1000 cycles later with the pipe a third idle; a lone MMA
+// wave per SIMD owns its pipe, the block shrinks to 8 waves and the K-group exchange through LDS disappears.
+template <int BM, int KT, int S, int UP, int PRO, int PD, bool WN = false, bool W4 = false, int NKGP = 0>
+__global__ __launch_bounds__(((BM / 32) * (BM / 32) * (NKGP ? NKGP : (BM == 64 ? 2 : 4)) + WG_NLD) * 64, NKGP == 1 ? 4 : 1)
+void wgrad_mm_kernel(  // (NKGP = 1: TWO 8-wave blocks per CU -- 72 KB of LDS each -- = 4 waves per SIMD = at most 128 registers)
     adp_wgrad_desc d_in, int CPB, int CPS, int nsplit, adp_wg_items items, int nitems) {
   // nitems > 1: `nitems` weight gradients of ONE shape in this launch (adp_conv1d_wgrad_batch): blockIdx.x = item * nsplit + split,
   // the items differ in their eight pointers only.  The workgroups of consecutive items follow each other on a CU without the
@@ -113,7 +128,7 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
   }
   static_assert(!WN || (KT == 3 && S == 1), "Winograd F(2,3): kernel 3, stride 1 (any upsample factor)");
   static_assert(!W4 || WN, "F(4,3) is a variant of the Winograd form");
-  constexpr int BR = BM, BKN = WG_BKN, NKG = (BM == 64 ? 2 : 4), PPW = BKN / NKG;
+  constexpr int BR = BM, BKN = WG_BKN, NKG = NKGP ? NKGP : (BM == 64 ? 2 : 4), PPW = BKN / NKG;
   constexpr int NQR = BR / 32, NQ = (BM / 32) * NQR, NMMA = NQ * NKG, NLT = WG_NLD * 64;
   constexpr int PAD = (KT - 1) / 2;
   constexpr int HALO = (S == 1) ? 4 : 0;                       // positions staged on each side of the chunk's x rows
@@ -129,6 +144,11 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
+  ADP_KT_DECL(WG_KT_BUF)
+  ADP_KT(0);
+#ifdef ADP_KTRACE
+  const int kt_block = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+#endif
 
   const int M = (int)d.M, R = (int)d.R, L = (int)d.Lin, N = (int)d.N, G = (int)d.groups;
   const int Lv = L * UP;
@@ -143,8 +163,110 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
 
   if (wave >= NMMA) {
     // =========================== loader waves ===========================
+    ADP_LOADER_PRIO_SET();
     const int lt = tid - NMMA * 64;
     const bool do_bias = (d.dbias != nullptr) && (blockIdx.z == 0);
+    if constexpr (S == 1 && UP == 1 && PRO == 0) {
+      if (N % BKN == 0) {
+        // ---- LEAN loader (round 6; every layer of the README net: plain input, row length a multiple of the chunk).  The in-kernel
+        // timeline (tools/ktrace.py) showed the F(4,3) blocks waiting for THIS wave, not for memory: its loads landed within
+        // ~100-400 cycles of being asked for, but the ~150 instructions around them (a select per staged element for padding that
+        // only the two halo quads of a row can need, 64-bit address arithmetic per slot, per-slot LDS addresses) took 4500-5000
+        // cycles of issue slots next to two MFMA waves per SIMD, against 3060 cycles of MFMAs per chunk.  Here a lane's slots are
+        // rows row0 + 16 i of ONE quad column: one 32-bit lane offset on a wave-uniform base per tensor (scalar address updates per
+        // chunk), LDS addresses = one base + immediates, no select on the 16 interior quads; the two halo quads of a row are staged
+        // by the first 2 * BM lanes, the only ones that test for the row's ends.
+        constexpr int NS = BM / 16;  // slots per lane and tensor (16 quads of 4 positions per row and chunk)
+        const int row0 = lt >> 4, q = lt & 15;
+        const unsigned d_off = (unsigned)((m0 + row0) * N + 4 * q), x_off = (unsigned)((r0 + row0) * L + 4 * q);
+        const int d_lds = row0 * DS + 4 * q, x_lds = row0 * XS + 4 * q + HALO;
+        const bool halo_lane = (KT == 3) && lt < 2 * BM;  // (wave-uniform: 2 * BM is a multiple of 64)
+        const int hrow = lt % BM, hside = lt / BM;        // side 0: positions p0-4 .. p0-1, side 1: p0+64 .. p0+67
+        const unsigned h_off = (unsigned)((r0 + hrow) * L);
+        const int h_rel = hside ? BKN : -HALO, h_lds = hrow * XS + (hside ? BKN + HALO : 0);
+        float bsum[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) bsum[i] = 0.0f;
+        f32x4 rd[PD][NS], rx[PD][NS], rh[PD];
+        bool h_ok[PD];
+        auto load_chunk = [&](f32x4 (&qd)[NS], f32x4 (&qx)[NS], f32x4& qh, bool& okh, int k) {
+          const int c = cbeg + (k < nloc ? k : nloc - 1);
+          const int b = c / CPB, p0 = (c - b * CPB) * BKN;
+          const float* dyb = d.dy + ((int64_t)b * M * N + p0);   // wave-uniform bases
+          const float* xbp = d.x + ((int64_t)b * R * L + p0);
+#pragma unroll
+          for (int i = 0; i < NS; ++i) qd[i] = *reinterpret_cast<const f32x4*>(dyb + (d_off + (unsigned)(i * 16 * N)));
+#pragma unroll
+          for (int i = 0; i < NS; ++i) qx[i] = *reinterpret_cast<const f32x4*>(xbp + (x_off + (unsigned)(i * 16 * L)));
+          if (halo_lane) {
+            okh = (p0 + h_rel >= 0) && (p0 + h_rel < L);
+            qh = *reinterpret_cast<const f32x4*>(d.x + ((int64_t)b * R * L + h_off) + (okh ? p0 + h_rel : 0));
+          }
+        };
+        auto store_chunk = [&](const f32x4 (&qd)[NS], const f32x4 (&qx)[NS], const f32x4& qh, bool okh, int k) {
+          float* Db = smem + (k & 1) * (D_ELEMS + X_ELEMS);
+          float* Xb = Db + D_ELEMS;
+          if (k < nloc) {  // (ghost chunks pad the loop to PD: their rows must not count into dbias)
+#pragma unroll
+            for (int i = 0; i < NS; ++i) bsum[i] += (qd[i][0] + qd[i][1]) + (qd[i][2] + qd[i][3]);
+          }
+#pragma unroll
+          for (int i = 0; i < NS; ++i) *reinterpret_cast<f32x4*>(Db + d_lds + i * 16 * DS) = qd[i];
+#pragma unroll
+          for (int i = 0; i < NS; ++i) *reinterpret_cast<f32x4*>(Xb + x_lds + i * 16 * XS) = qx[i];
+          if (halo_lane) {
+            f32x4 v = qh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = okh ? v[j] : 0.0f;
+            *reinterpret_cast<f32x4*>(Xb + h_lds) = v;
+          }
+        };
+#pragma unroll
+        for (int s = 0; s < PD; ++s) load_chunk(rd[s], rx[s], rh[s], h_ok[s], s);
+        for (int k0 = 0; k0 < nrounds; k0 += PD) {
+#pragma unroll
+          for (int s = 0; s < PD; ++s) {
+#ifdef ADP_KTRACE
+            if (k0 + s < 16) ADP_KT(1 + 3 * (k0 + s));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (k0 + s < 16) ADP_KT(2 + 3 * (k0 + s));
+#endif
+            store_chunk(rd[s], rx[s], rh[s], h_ok[s], k0 + s);
+            load_chunk(rd[s], rx[s], rh[s], h_ok[s], k0 + s + PD);
+#ifdef ADP_KTRACE
+            if (k0 + s < 16) ADP_KT(3 + 3 * (k0 + s));
+#endif
+            __syncthreads();  // B_k
+          }
+        }
+        ADP_KT(60);
+        __syncthreads();
+#pragma unroll
+        for (int g = 1; g < NKG; ++g) {
+          __syncthreads();
+          __syncthreads();
+        }
+        if (do_bias) {  // a dy row is staged by 16 consecutive lanes of one slot: summed in a fixed order
+          float* bb = direct ? d.dbias : d.ws + (int64_t)nsplit * cnt + (int64_t)split * M;
+#pragma unroll
+          for (int i = 0; i < NS; ++i) {
+            float sv = bsum[i];
+            sv += __shfl_xor(sv, 1, 64);
+            sv += __shfl_xor(sv, 2, 64);
+            sv += __shfl_xor(sv, 4, 64);
+            sv += __shfl_xor(sv, 8, 64);
+            if (q == 0) {
+              const int m = m0 + row0 + 16 * i;
+              bb[m] = (direct && (d.accumulate & 1)) ? bb[m] + sv : sv;
+            }
+          }
+        }
+#ifdef ADP_KTRACE
+        ADP_KT_DUMP(kt_block);
+#endif
+        return;
+      }
+    }
     // staging slots (chunk independent parts); slot indices wrap instead of being guarded
     int d_src[ND4], d_dst[ND4], d_pos[ND4];
 #pragma unroll
@@ -238,11 +360,20 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
     for (int k0 = 0; k0 < nrounds; k0 += PD) {
 #pragma unroll
       for (int s = 0; s < PD; ++s) {
+#ifdef ADP_KTRACE
+        if (k0 + s < 16) ADP_KT(1 + 3 * (k0 + s));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (k0 + s < 16) ADP_KT(2 + 3 * (k0 + s));
+#endif
         store_chunk(rd[s], rx[s], rmean[s], rrstd[s], d_ok[s], x_ok[s], k0 + s);
         load_chunk(rd[s], rx[s], rmean[s], rrstd[s], d_ok[s], x_ok[s], k0 + s + PD);
+#ifdef ADP_KTRACE
+        if (k0 + s < 16) ADP_KT(3 + 3 * (k0 + s));
+#endif
         __syncthreads();  // B_k
       }
     }
+    ADP_KT(60);
     __syncthreads();
 #pragma unroll
     for (int g = 1; g < NKG; ++g) {
@@ -266,6 +397,9 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
         }
       }
     }
+#ifdef ADP_KTRACE
+    ADP_KT_DUMP(kt_block);
+#endif
     return;
   }
 
@@ -280,10 +414,55 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
   for (int k = 0; k < nrounds; ++k) {
+#ifdef ADP_KTRACE
+    if (k < 16) ADP_KT(1 + 3 * k);
+#endif
     __syncthreads();  // B_k: chunk k is in LDS[k & 1]
+#ifdef ADP_KTRACE
+    if (k < 16) ADP_KT(2 + 3 * k);
+#endif
     if (k < nloc) {
       const float* Db = smem + (k & 1) * (D_ELEMS + X_ELEMS);
       const float* Xb = Db + D_ELEMS;
+      if constexpr (W4 && S == 1) {
+        // F(4,3): of the lane's x row only d0 .. d5 = x[base-1 .. base+4] are read -- one 16-byte quad and two scalars instead of
+        // three quads (40 instead of 64 bytes per lane and position group; round 6).
+        const float* dp = Db + (wm0 + l31) * DS + kg * PPW + 4 * hi;
+        const float* xp = Xb + (wr0 + l31) * XS + kg * PPW + 4 * hi;   // xp[i] = x[base - 4 + i]
+#ifdef ADP_WG_PIPE  // (measured round 6: requesting group s + 1 ahead of group s's MFMAs changes nothing -- the pipe's idle time
+                    //  is the lock step of the two MMA waves of a SIMD after each barrier, not the LDS round trips; kept for A/B)
+        f32x4 dqn = *reinterpret_cast<const f32x4*>(dp), xmn = *reinterpret_cast<const f32x4*>(xp + 4);
+        float d0n = xp[3], d5n = xp[8];
+#endif
+#pragma unroll
+        for (int s = 0; s < PPW / 8; ++s) {
+#ifdef ADP_WG_PIPE
+          const f32x4 dq = dqn, xm = xmn;
+          const float d0 = d0n, d5 = d5n;
+          if (s + 1 < PPW / 8) {
+            dqn = *reinterpret_cast<const f32x4*>(dp + 8 * (s + 1));
+            xmn = *reinterpret_cast<const f32x4*>(xp + 8 * (s + 1) + 4);
+            d0n = xp[8 * (s + 1) + 3];
+            d5n = xp[8 * (s + 1) + 8];
+          }
+          adp_sched_fence();  // (the requests above stay above the matrix work that hides them)
+#else
+          const f32x4 dq = *reinterpret_cast<const f32x4*>(dp + 8 * s), xm = *reinterpret_cast<const f32x4*>(xp + 8 * s + 4);
+          const float d0 = xp[8 * s + 3], d5 = xp[8 * s + 8];
+#endif
+          const float e0 = dq[0], e1 = dq[1], e2 = dq[2], e3 = dq[3];
+          const float d1 = xm[0], d2 = xm[1], d3 = xm[2], d4 = xm[3];
+          const float s02 = e0 + e2, s13 = e1 + e3;
+          const float et = fmaf(4.0f, e2, e0), ev = fmaf(4.0f, e3, e1);
+          const float t1 = fmaf(-4.0f, d2, d4), t2 = fmaf(-4.0f, d1, d3), t3 = d4 - d2, t4 = d3 - d1;
+          acc[0] = adp_mfma32(e0, fmaf(4.0f, d0, fmaf(-5.0f, d2, d4)), acc[0]);
+          acc[1] = adp_mfma32(s02 + s13, t1 + t2, acc[1]);
+          acc[2] = adp_mfma32(s02 - s13, t1 - t2, acc[2]);
+          acc[3] = adp_mfma32(fmaf(2.0f, ev, et), fmaf(2.0f, t4, t3), acc[3]);
+          acc[4] = adp_mfma32(fmaf(-2.0f, ev, et), fmaf(-2.0f, t4, t3), acc[4]);
+          acc[5] = adp_mfma32(e3, fmaf(4.0f, d1, fmaf(-5.0f, d3, d5)), acc[5]);
+        }
+      } else {
 #pragma unroll
       for (int s = 0; s < PPW / 8; ++s) {
         const int base = kg * PPW + 8 * s + 4 * hi;
@@ -349,9 +528,15 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
             for (int t = 0; t < KT; ++t) acc[t] = adp_mfma32(dq[j], xq[j * S + t], acc[t]);
         }
       }
+      }
     }
+#ifdef ADP_KTRACE
+    if (k < 16) ADP_KT(3 + 3 * k);
+#endif
   }
+  ADP_KT(60);
   __syncthreads();
+  ADP_KT(61);
   if constexpr (W4) {  // G^T of F(4,3): six planes -> three taps (linear, so applied to this K group's partial sums)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -435,6 +620,10 @@ __global__ __launch_bounds__(((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NL
         }
     }
   }
+  ADP_KT(63);
+#ifdef ADP_KTRACE
+  ADP_KT_DUMP(kt_block);
+#endif
 }
 
 struct WgPlan {
@@ -586,7 +775,7 @@ int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, fl
 namespace {
 
 // PD: a 64x64 chunk is 2.6 us of MFMAs (one register stage), a 32x32 chunk 0.64 us (two)
-template <int BM, int KT, int S, int UP, int PRO, bool WN = false, bool W4 = false, int PD = (BM == 64 ? 1 : 2)>
+template <int BM, int KT, int S, int UP, int PRO, bool WN = false, bool W4 = false, int PD = (BM == 64 ? 1 : 2), int NKGP = 0>
 int launch_wg(const adp_wgrad_desc* ds, int n, const WgPlan& p, void* stream) {
   const adp_wgrad_desc& d = ds[0];
   adp_wg_items it;
@@ -596,8 +785,8 @@ int launch_wg(const adp_wgrad_desc* ds, int n, const WgPlan& p, void* stream) {
     it.dw[i] = e.dw, it.dbias[i] = e.dbias, it.ws[i] = e.ws;
   }
   dim3 grid((unsigned)(p.nsplit * n), (unsigned)(d.M / BM), (unsigned)(d.R / BM));
-  constexpr int NTH = ((BM / 32) * (BM / 32) * (BM == 64 ? 2 : 4) + WG_NLD) * 64;
-  ADP_LAUNCH((wgrad_mm_kernel<BM, KT, S, UP, PRO, PD, WN, W4>), grid, dim3(NTH), stream, d, (int)p.cpb, (int)p.cps,
+  constexpr int NTH = ((BM / 32) * (BM / 32) * (NKGP ? NKGP : (BM == 64 ? 2 : 4)) + WG_NLD) * 64;
+  ADP_LAUNCH((wgrad_mm_kernel<BM, KT, S, UP, PRO, PD, WN, W4, NKGP>), grid, dim3(NTH), stream, d, (int)p.cpb, (int)p.cps,
              (int)p.nsplit, it, n);
   if (p.nsplit > 1 && !(d.accumulate & 2)) {  // (bit 1 of `accumulate`: the caller parks the second stage, adp.h)
     if (ADP_LAUNCH_OK() != ADP_OK) return ADP_ERR_LAUNCH;
@@ -614,6 +803,15 @@ int pick_wg(const adp_wgrad_desc* ds, int n, void* stream) {
   const WgPlan p = wg_plan(ds[0], n);
   if constexpr (WN) {  // the F(4,3) form of the kernel-3 weight gradients (wg_winograd4)
     if (wg_winograd4(ds[0])) {
+      if constexpr (S == 1 && UP == 1 && PRO == 0) {
+        // One MMA wave per SIMD, TWO 8-wave blocks per CU, for the launches that are long K loops over many tiles without a
+        // position split (the batched 1024-channel layers: 2048 blocks of 16 chunks).  Measured per batched launch, 12-wave ->
+        // solo: n8 [4,1024,256] 270.9 -> 246.8 us, n8 [4,1024,128] 152.0 -> 132.5 us (K loop at 96 % of the matrix pipe); the
+        // split layers lose (n4 [4,512,1024] 129.8 -> 138.3 us) and keep the 12-wave block.  ADP_WG_SOLO=0 / 1 forces either.
+        const char* so = getenv("ADP_WG_SOLO");
+        const bool solo = so ? so[0] == '1' : (p.nsplit == 1 && (ds[0].M / 64) * (ds[0].R / 64) * n >= 1024);
+        if (p.bm == 64 && solo) return launch_wg<64, KT, S, UP, PRO, true, true, 1, 1>(ds, n, p, stream);
+      }
       if (p.bm == 64) return launch_wg<64, KT, S, UP, PRO, true, true>(ds, n, p, stream);
       return launch_wg<32, KT, S, UP, PRO, true, true>(ds, n, p, stream);
     }

@@ -30,6 +30,31 @@ import torch.nn as nn
 from torch import Tensor
 
 
+class _ProxyParameters:
+    """For the duration of a capture every Parameter of the module is replaced, in the modules' `_parameters` dicts, by a fresh
+    Parameter over the SAME storage.  Why: a loss tensor of an earlier step that the caller still holds keeps that step's autograd
+    graph alive, and with it the parameters' AccumulateGrad nodes, created on the stream that step ran on.  Autograd re-uses a
+    live node, and when a gradient produced on the capture stream reaches a node of another stream it makes THAT stream wait for
+    an event of the capture -- which pulls the caller's stream into the capture and breaks it (a segmentation fault inside
+    hipStreamEndCapture on ROCm 7; torch's "AccumulateGrad node's stream does not match" warning describes the mechanism).
+    Fresh tensor objects have no node yet; the kernels see the same memory, so the captured graphs serve the real parameters."""
+
+    def __init__(self, module: nn.Module):
+        self.params = tracked_parameters(module)
+        self.holders = module.__dict__["_adp_param_cache"][1]
+        self.proxies = [nn.Parameter(p.data, requires_grad=p.requires_grad) for p in self.params]
+
+    def __enter__(self):
+        for (d, leaf), q in zip(self.holders, self.proxies):
+            d[leaf] = q
+        return self.proxies
+
+    def __exit__(self, *exc):
+        for (d, leaf), p in zip(self.holders, self.params):
+            d[leaf] = p
+        return False
+
+
 def tracked_parameters(module: nn.Module) -> List[nn.Parameter]:
     """`list(module.parameters())` without the module-tree walk (1-2 ms for ~600 parameters) on every call: the list is cached
     on the module together with where each entry is registered and re-validated by identity per call (~30 us); replaced
@@ -124,7 +149,10 @@ class TrainStepGraphs:
             if not params:
                 return None
             try:
-                entry = self._capture(x, noise, kwargs, names, live, params)
+                with _ProxyParameters(self._owner()) as proxies:
+                    entry = self._capture(x, noise, kwargs, names, live, [q for q in proxies if q.requires_grad])
+                entry.params = params
+                del proxies
             except Exception as e:  # capture is a launch-overhead optimisation only
                 import warnings
                 warnings.warn(f"graph capture of the training step failed ({type(e).__name__}: {e}); this call structure runs "
@@ -178,6 +206,10 @@ class TrainStepGraphs:
             e.sloss = eager(e.sx, e.snoise, **skw)
         with torch.cuda.graph(e.g_b, pool=e.g_f.pool()):
             e.grads = torch.autograd.grad(e.sloss, params, grad_outputs=e.sgloss, allow_unused=True)
+        # Drop the captured step's autograd graph: it keeps the parameters' AccumulateGrad nodes alive, and those were created
+        # on the CAPTURE stream -- every later backward would then run its 600 gradient accumulations on that stream behind an
+        # event record / wait pair each ("AccumulateGrad node's stream does not match ...": ~5 ms of a replayed step).
+        e.sloss = e.sloss.detach()
         e.step = 0
         self.captures += 1
         return e

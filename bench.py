@@ -442,9 +442,13 @@ def calibration(dev, busy=None):
     from audio_diffusion_pytorch_amd._C import ptr
     out = {}
 
-    def ev_ms(fn, reps):
+    def ev_ms(fn, reps, warm_s=0.0):
         fn()
         torch.cuda.synchronize()
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < warm_s:  # (a probe that starts on an idle chip reads its clock ramp: MFMA 138-144 vs 154 TF)
+            fn()
+            torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(reps):
@@ -456,17 +460,53 @@ def calibration(dev, busy=None):
     try:
         n = 64 << 20
         src, dst = torch.randn(n, device=dev), torch.empty(n, device=dev)
-        ms = ev_ms(lambda: _C.call("adp_probe_copy", ptr(src), ptr(dst), n, _C.stream()), 10)
+        ms = ev_ms(lambda: _C.call("adp_probe_copy", ptr(src), ptr(dst), n, _C.stream()), 10, warm_s=0.2)
         out["copy_256MB_gbps"] = round(8 * n / ms / 1e6, 1)
         del src, dst
-        buf = torch.empty(512 * 256, device=dev)
+        # Ceiling search (round 6): 1 GiB source + 1 GiB destination -- four times the Infinity Cache, so nothing of a pass is
+        # served from it -- over the copy variants of csrc/probe.hip (persistent grids, 1-8 16-byte loads in flight per lane,
+        # nontemporal access).  `copy_1GiB_best_gbps` is what "a plain copy reaches on this box"; the guide's 6290 GB/s
+        # (MI355X_MICROARCH.md) is the reference the roofline_hbm_convblock object is read against.
+        try:
+            n1 = 256 << 20
+            src, dst = torch.empty(n1, device=dev).normal_(), torch.empty(n1, device=dev)
+            sweep = {}
+            for v in range(8):
+                ms = ev_ms(lambda: _C.call("adp_probe_copy_v", ptr(src), ptr(dst), n1, v, _C.stream()), 5)
+                sweep[str(v)] = round(8 * n1 / ms / 1e6, 1)
+            best = max(sweep, key=sweep.get)
+            out["copy_1GiB_gbps_by_variant"] = sweep
+            out["copy_1GiB_best_gbps"] = sweep[best]
+            out["copy_1GiB_best_variant"] = {"0": "grid 4096 grid-stride, 1 load in flight", "1": "2048 x 4 loads", "2": "2048 x 4 loads, nt",
+                                             "3": "2048 x 8 loads, nt", "4": "4096 x 2 loads, nt", "5": "1024 x 8 loads",
+                                             "6": "1024 x 4 loads, nt", "7": "8192 x 1 load, nt"}[best]
+            # one direction at a time: what the HBM delivers when it does not turn around between reads and writes
+            ms = ev_ms(lambda: _C.call("adp_probe_copy_v", ptr(src), ptr(dst), n1, 8, _C.stream()), 5)
+            out["read_1GiB_gbps"] = round(4 * n1 / ms / 1e6, 1)
+            ms = ev_ms(lambda: _C.call("adp_probe_copy_v", ptr(src), ptr(dst), n1, 9, _C.stream()), 5)
+            out["write_1GiB_gbps"] = round(4 * n1 / ms / 1e6, 1)
+            del src, dst
+        except Exception as e:
+            out["copy_1GiB_error"] = f"{type(e).__name__}: {e}"
+        buf = torch.empty(1024 * 256, device=dev)
         flops = [0]
 
         def mfma():
             flops[0] = _C.call_value("adp_probe_mfma", 8000, ptr(buf), buf.numel(), _C.stream())
-        ms = ev_ms(mfma, 5)
+        ms = ev_ms(mfma, 5, warm_s=0.3)
         out["mfma_f32_probe_tflops"] = round(flops[0] / ms / 1e9, 1)
         out["mfma_f32_probe_frac_of_peak"] = round(flops[0] / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)
+        try:  # the same loop with 16 / 32 MFMAs per trip and 1 / 2 / 4 waves per SIMD (the guide measures 155 TF)
+            sweep = {}
+            for v in range(5):
+                def mf(v=v):
+                    flops[0] = _C.call_value("adp_probe_mfma_v", 8000, ptr(buf), buf.numel(), v, _C.stream())
+                ms = ev_ms(mf, 5)
+                sweep[str(v)] = round(flops[0] / ms / 1e9, 1)
+            out["mfma_f32_probe_tflops_by_variant"] = sweep
+            out["mfma_f32_probe_best_tflops"] = max(sweep.values())
+        except Exception as e:
+            out["mfma_f32_probe_sweep_error"] = f"{type(e).__name__}: {e}"
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -970,6 +1010,10 @@ def main():
             with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
                 static_loss = model(x)
                 static_loss.backward()
+            # (drop the captured step's autograd graph: it would keep the parameters' AccumulateGrad nodes -- created on the
+            #  capture stream -- alive, and every later eager backward in this process would run its 600 gradient accumulations
+            #  on that stream behind an event pair each)
+            static_loss = static_loss.detach()
         except Exception as e:  # capture is a launch-overhead optimisation only; the kernels are identical
             if rank == 0:
                 print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); timing eager launches",
@@ -1071,7 +1115,7 @@ def main():
             rf, hbm, extra, eager_ms = roofline_leg(inner, x)
             line["roofline"] = rf
             if hbm:
-                copy = (calib or {}).get("copy_256MB_gbps")
+                copy = (calib or {}).get("copy_1GiB_best_gbps") or (calib or {}).get("copy_256MB_gbps")
                 if copy:  # the same launches against what a plain 16-byte copy reaches on THIS box (calibration probe)
                     hbm["copy_ceiling_gbps"] = copy
                     hbm["frac_of_copy_ceiling"] = round(hbm["achieved"] / copy, 4)

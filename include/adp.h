@@ -186,6 +186,15 @@ int adp_gn_silu_bwd_apply(const float* x, const float* dact, const float* stats,
                           void* stream);
 int adp_gn_param_grad(const float* ab, int64_t B, int64_t C, int64_t NS, float* dgamma, float* dbeta,
                       int64_t accumulate, void* stream);
+/* One-launch backward of SiLU(GroupNorm(x)) for the deep layers (a workgroup per (batch element, group) slab of at most 8192
+ * quads, rows of 64-4096 floats with a power-of-two quad count): dx (+ dres) and, when dgamma / dbeta are given, the parameter
+ * gradients -- their sum over the batch is finished by the workgroup that draws the group's last ticket, in batch order.
+ * ab: B*C*2 floats of scratch; tickets: G int32, zero before the first call and left zero by every call (re-armed in-kernel).
+ * adp_gn_silu_bwd_slab_ok: 1 when the shape is served (ADP_GN_BWD_SLAB=0 switches the form off), else the two-call form applies. */
+int64_t adp_gn_silu_bwd_slab_ok(int64_t B, int64_t C, int64_t L, int64_t G);
+int adp_gn_silu_bwd_slab(const float* x, const float* dact, const float* stats, const float* gamma, const float* beta,
+                         const float* dres, int64_t B, int64_t C, int64_t L, int64_t G, float* dx, float* ab, int32_t* tickets,
+                         float* dgamma, float* dbeta, int64_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Modulation (a_unet ModulationItem, components.py:90): per position LayerNorm over channels
@@ -375,6 +384,12 @@ int adp_probe_copy(const float* src, float* dst, int64_t n, void* stream);
 int adp_probe_chase(const int32_t* chain, int64_t steps, int32_t* out, void* stream);
 int64_t adp_probe_mfma(int64_t iters, float* out, int64_t out_elems, void* stream);
 int adp_probe_launch(int64_t workgroups, void* stream);
+/* Ceiling search of the two rate probes (bench.py reports the best variant and names it): copy variants 0-7 differ in grid
+ * (persistent 1024-8192 workgroups), 16-byte loads in flight per lane (1-8) and nontemporal access, 8 = read only (sums; n
+ * floats read), 9 = write only (n floats written); MFMA variants 0-4 in waves per
+ * SIMD (1 / 2 / 4) and MFMAs per loop trip (4 / 16 / 32; `iters` % 8 == 0).  Same return conventions as the plain probes. */
+int adp_probe_copy_v(const float* src, float* dst, int64_t n, int variant, void* stream);
+int64_t adp_probe_mfma_v(int64_t iters, float* out, int64_t out_elems, int variant, void* stream);
 
 #ifdef __cplusplus
 }

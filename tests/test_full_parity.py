@@ -265,8 +265,9 @@ def up_sample_input(up, low):
 
 @pytest.mark.gpu
 def test_winograd_and_direct_form_agree_inside_the_unet(hip, monkeypatch):
-    """The Winograd F(2,3) variants of the kernel-3 convs and weight gradients (the default) against the direct form
-    (ADP_CONV_WINO=0) inside a whole U-Net step: loss, prediction and every parameter gradient on the same weights and
+    """The Winograd variants of the kernel-3 convs and weight gradients (the default: F(4,3) -- conv_tile32, conv_mm4,
+    conv_tilek, wgrad_mm's W4 -- from 32 / 128 / 64 channels, F(2,3) below and for the shapes those kernels do not take)
+    against the direct form (ADP_CONV_WINO=0) inside a whole U-Net step: loss, prediction and every parameter gradient on the same weights and
     inputs.  Both are plain fp32 arithmetic, so the bound is 1e-4 (ten times tighter than the path's parity tolerance)."""
     env = "ADP_CONV_WINO"
     cfg = dict(in_channels=2, channels=[8, 32, 256, 512], factors=[1, 4, 4, 2], items=[1, 1, 2, 2])

@@ -4,6 +4,8 @@ with -m gpu, on the real gfx950 library.  Tolerance: 1e-3 rel (north_star), fp32
 """
 import math
 
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -497,6 +499,77 @@ def test_conv_tile32_trained_weight_dynamic_range(dev):
     assert ((dx.double().cpu() - dref).abs() / dcond).max().item() < 1e-4
 
 
+def _trained_like(shape, gen, lo=1e-3, hi=10.0):
+    """|w| log-uniform over lo ... hi with random signs (the recipe of test_conv_tile32_trained_weight_dynamic_range)."""
+    mag = torch.exp(torch.empty(*shape).uniform_(math.log(lo), math.log(hi), generator=gen))
+    return mag * torch.where(torch.rand(*shape, generator=gen) < 0.5, -1.0, 1.0)
+
+
+@pytest.mark.parametrize("family", ["mm4", "tilek"])
+def test_deep_f43_convs_trained_weight_dynamic_range(dev, family, monkeypatch):
+    """The F(4,3) kernels that carry the step's flops -- conv_mm4 (depths 3-7) and conv_tilek (depth 8, batch-1 deep layers) --
+    at the LONGEST reduction of the README net (R = 1024 input channels) with a trained-weight-like dynamic range: |w| log-uniform
+    over 1e-3 ... 10, inputs with 30 sigma outliers, fp64 reference.  Same bounds as the 32-channel wave tile: 1e-5 of the output's
+    max norm, 1e-4 element-wise against each output's conditioning sum |w|.|x| (+ |res| + |bias|); forward and data gradient."""
+    from ctypes import byref
+    B, R, M, L = 1, 1024, 32, 128
+    if family == "mm4":
+        monkeypatch.setenv("ADP_MM4_MIN_BLOCKS", "1")
+        monkeypatch.setenv("ADP_MM4_LIGHT_MIN_BLOCKS", "1000000")
+        monkeypatch.setenv("ADP_CONV_TILEK", "0")
+        want = 64032128
+    else:
+        monkeypatch.setenv("ADP_TILEK_MIN_R", "256")
+        monkeypatch.setenv("ADP_TILEK_MIN_TILES", "1")
+        want = 48000064
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, R, L, generator=g)
+    x[:, :, 37] += 30.0
+    x[:, 11, 90] -= 30.0
+    w = _trained_like((M, R, 3), g)
+    b, r = torch.randn(M, generator=g), torch.randn(B, M, L, generator=g)
+    xd, wd = x.to(dev), w.to(dev)
+    d = _C.ConvDesc(_C.ptr(xd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(xd), None, B, R, R, L, M, L,
+                    3, 1, 1, 1, 1, 0, 0, 1, 0, 1, 0)
+    assert _C.query("adp_conv1d_tile", byref(d)) == want, "the case must dispatch to the kernel under test"
+    ref = F.conv1d(x.double(), w.double(), b.double(), padding=1) + r.double()
+    out = ops.conv1d(xd, wd, b.to(dev), pad=1, res=r.to(dev))
+    assert rel_err(out, ref) < 1e-5
+    cond = F.conv1d(x.double().abs(), w.double().abs(), None, padding=1) + r.double().abs() + b.double().abs()[None, :, None]
+    assert ((out.double().cpu() - ref).abs() / cond).max().item() < 1e-4
+    # data gradient of a conv 32 -> 1024 read through the transposed weight view: [B, 1024, L] -> [B, 32, L], the same reduction
+    wt = _trained_like((R, M, 3), g)
+    d2 = _C.ConvDesc(_C.ptr(xd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(xd), None, B, R, R, L, M, L,
+                     3, 1, 1, 1, 1, 1, 0, 1, 0, 1, 0)
+    assert _C.query("adp_conv1d_tile", byref(d2)) == want
+    dref = F.conv_transpose1d(x.double(), wt.double(), None, padding=1)
+    dx = ops.conv1d(xd, wt.to(dev), None, pad=1, transposed=True)
+    assert rel_err(dx, dref) < 1e-5
+    dcond = F.conv_transpose1d(x.double().abs(), wt.double().abs(), None, padding=1)
+    assert ((dx.double().cpu() - dref).abs() / dcond).max().item() < 1e-4
+
+
+def test_wgrad_f43_trained_gradient_dynamic_range(dev, monkeypatch):
+    """The W4 (F(4,3)) weight gradient at the shape with the LONGEST position reduction it serves in the README net -- [4, 128, 4096]:
+    16384 positions per (m, r, tap) through A e (constants up to 8) and B^T d (up to 5) -- with a heavy-tailed upstream gradient
+    (|dy| log-uniform over 1e-3 ... 10) and 30 sigma outliers in the input; fp64 reference; 1e-5 of the max norm and 1e-4
+    element-wise against sum |dy| |x|.  (The emulator runs a shorter row: the arithmetic per chunk is the same.)"""
+    B, C, L = (4, 128, 4096) if dev.type == "cuda" else (1, 64, 512)
+    _wgrad_family_env(monkeypatch, "4")
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, C, L, generator=g)
+    x[:, :, 100] += 30.0
+    x[:, 3, 300] -= 30.0
+    dy = _trained_like((B, C, L), g)
+    w = torch.zeros(C, C, 3, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(F.conv1d(x.double(), w, None, padding=1), w, dy.double())
+    wa = torch.zeros(C, C, 3, dtype=torch.float64, requires_grad=True)
+    cond, = torch.autograd.grad(F.conv1d(x.double().abs(), wa, None, padding=1), wa, dy.double().abs())
+    dw, _ = ops.conv1d_wgrad(x.to(dev), dy.to(dev), 3, pad=1)
+    assert rel_err(dw, ref) < 1e-5
+    assert ((dw.double().cpu() - ref).abs() / cond).max().item() < 1e-4
+
+
 @pytest.mark.parametrize("B,R,M,L,tr", [(2, 128, 64, 256, False), (1, 160, 160, 132, False), (2, 128, 128, 128, True),
                                         (1, 256, 32, 260, True), (3, 128, 96, 4, False), (1, 128, 64, 1024, False)])
 @pytest.mark.parametrize("bkt", ["32", "64", "light"])
@@ -717,8 +790,12 @@ def test_conv_mm4_pooled_dgrad_of_wide_upsample_conv(dev, B, R, M, L, up, monkey
 def test_nearest_upsample_gather_is_bit_exact(dev, B, C, L, up, wino, monkeypatch):
     """UpsampleItem = nearest upsample (source index floor(dst / f)) then a k3 conv, with the gather folded into the conv
     loaders.  With a one-hot centre tap the conv is the identity, so the output must EQUAL the nearest-upsampled input
-    -- integer-valued inputs keep every evaluation order (direct, Winograd F(2,3)) exact, so torch.equal tests the index
-    math alone, on every kernel family that serves the shape (MFMA, direct VALU, generic)."""
+    -- integer-valued inputs keep the evaluation orders this test PINS exact: the direct form (wino = 0) and Winograd F(2,3)
+    (wino = 1 with ADP_WINO_MIN_R = 32: conv_mm's WN variant, whose constants 1/2 are dyadic), on every kernel family that serves
+    these <= 64-channel shapes (MFMA, direct VALU, generic), so torch.equal tests the index math alone.  The F(4,3) kernels
+    (conv_mm4 from 128 channels, conv_tile32 at 32 -> 32 'same' convs without upsample) are NOT pinned here: their constants
+    1/6 and 1/24 are not dyadic, so integer inputs do not make them exact -- their fused gather is compared bit-for-bit against
+    the materialised upsample through the SAME arithmetic in test_conv_mm4_upsample_and_pooled_dgrad."""
     monkeypatch.setenv("ADP_CONV_WINO", wino)
     monkeypatch.setenv("ADP_WINO_MIN_R", "32")
     g = torch.Generator().manual_seed(5)
@@ -1077,6 +1154,58 @@ def test_gn_silu_bwd(dev, B, C, L, G):
     assert rel_err(dx, dx_ref + dres) < TOL
     assert rel_err(dg, dg_ref) < TOL
     assert rel_err(db, db_ref) < TOL
+
+
+@pytest.mark.parametrize("B,C,L,G", [(4, 1024, 256, 8), (3, 1024, 128, 8), (1, 512, 512, 8), (2, 48, 1024, 2), (2, 256, 64, 4),
+                                     (4, 512, 256, 8)])
+def test_gn_silu_bwd_slab(dev, B, C, L, G, monkeypatch):
+    """gn_bwd_slab_kernel: the one-launch backward of SiLU(GroupNorm(x)) for the deep layers -- a workgroup per (batch element,
+    group) slab held in registers (1 / 2 / 4 / 8 quads per lane; rows shorter than a wave's reach: L = 64, 128; a group that is
+    not a power-of-two number of rows: 48 x 1024), the batch sum of the parameter gradients finished by the workgroup that draws
+    the group's last ticket.  Against autograd, against the two-launch form, bit-identical when repeated (deterministic order),
+    with accumulation into existing parameter gradients, and the ticket words left at zero."""
+    if dev.type != "cuda" and B * C * L > 300000:
+        pytest.skip("emulating 1024-thread workgroups over the largest slabs takes minutes; covered on the GPU")
+    assert _C.query("adp_gn_silu_bwd_slab_ok", B, C, L, G) == 1
+    x = (rnd(B, C, L, seed=1) * 1.5 + 0.4).requires_grad_()
+    gamma = (rnd(C, seed=2) * 0.5 + 1).requires_grad_()
+    beta = (rnd(C, seed=3) * 0.2).requires_grad_()
+    y = ref_gn_silu(x, G, gamma, beta)
+    dact, dres = rnd(B, C, L, seed=4), rnd(B, C, L, seed=5)
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(y, (x, gamma, beta), dact)
+    xd, gd, bd = x.detach().to(dev), gamma.detach().to(dev), beta.detach().to(dev)
+    stats = ops.gn_stats(xd, G)
+    dx, dg, db = ops.gn_silu_bwd(xd, dact.to(dev), stats, gd, bd, G, dres=dres.to(dev))
+    assert rel_err(dx, dx_ref + dres) < 1e-5 and rel_err(dg, dg_ref) < 1e-5 and rel_err(db, db_ref) < 1e-5
+    assert int(ops._tickets(xd.device, G).abs().sum()) == 0
+    dx2, dg2, db2 = ops.gn_silu_bwd(xd, dact.to(dev), stats, gd, bd, G, dres=dres.to(dev))
+    assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+    dg0, db0 = rnd(C, seed=6).to(dev), rnd(C, seed=7).to(dev)
+    _, dg3, db3 = ops.gn_silu_bwd(xd, dact.to(dev), stats, gd, bd, G, dgamma=dg0.clone(), dbeta=db0.clone(), accumulate=True)
+    assert rel_err(dg3, dg_ref + dg0.cpu()) < 1e-5 and rel_err(db3, db_ref + db0.cpu()) < 1e-5
+    monkeypatch.setenv("ADP_GN_BWD_SLAB", "0")  # the two-launch form it replaces
+    assert _C.query("adp_gn_silu_bwd_slab_ok", B, C, L, G) == 0
+    dx1, dg1, db1 = ops.gn_silu_bwd(xd, dact.to(dev), stats, gd, bd, G, dres=dres.to(dev))
+    assert rel_err(dx, dx1) < 1e-5 and rel_err(dg, dg1) < 1e-5 and rel_err(db, db1) < 1e-5
+
+
+def test_gn_silu_bwd_slab_window():
+    """Which shapes the slab form serves: the README net's depths 6-8 at any batch (and depth 5 at 8 groups of 64 x 1024 is too
+    large for one workgroup's registers); narrow or ragged rows stay on the two-launch form."""
+    from audio_diffusion_pytorch_amd import _C as C_
+    sys_path_emul = None  # (pure query: no launch)
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emul"))
+    import build_emul
+    C_._testing_use_library(build_emul.build(), allow_cpu=True)
+    try:
+        ok = lambda *a: C_.query("adp_gn_silu_bwd_slab_ok", *a)  # noqa: E731
+        for B in (1, 4, 8):
+            assert ok(B, 512, 512, 8) and ok(B, 1024, 256, 8) and ok(B, 1024, 128, 8)
+            assert not ok(B, 512, 1024, 8) and not ok(B, 32, 65536, 8) and not ok(B, 8, 262144, 8)
+        assert not ok(2, 64, 132, 8) and not ok(2, 64, 40, 8) and not ok(1, 16, 64, 8)
+    finally:
+        C_._testing_use_library(None, allow_cpu=False)
 
 
 # ------------------------------------------------------------------ Modulation / LayerNorm over channels
