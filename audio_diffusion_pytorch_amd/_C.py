@@ -63,8 +63,6 @@ SIGNATURES = {
     "adp_gn_silu_bwd_reduce": (c_int, [P, P, P, P, P, I, I, I, I, I, P, P]),
     "adp_gn_silu_bwd_apply": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, I, P]),
     "adp_gn_param_grad": (c_int, [P, I, I, I, P, P, I, P]),
-    "adp_gn_silu_bwd_slab_ok": (I, [I, I, I, I]),
-    "adp_gn_silu_bwd_slab": (c_int, [P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, I, P]),
     "adp_modulation_fwd": (c_int, [P, P, I, I, I, I, F, P, P, P]),
     "adp_modulation_ln_fwd": (c_int, [P, P, I, I, I, I, F, P, P, F, P, P, P, P, P, P, P, P]),
     "adp_chan_ln_bwd_ws_bytes": (I, [I, I, I]),

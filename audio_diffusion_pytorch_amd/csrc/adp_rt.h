@@ -34,25 +34,6 @@ __device__ __forceinline__ void adp_sched_fence() { __builtin_amdgcn_sched_barri
 template <class T> __device__ __forceinline__ T adp_nt_load(const T* p) { return __builtin_nontemporal_load(p); }
 template <class T> __device__ __forceinline__ void adp_nt_store(T v, T* p) { __builtin_nontemporal_store(v, p); }
 
-// Hand-off of a few words between WORKGROUPS of one launch (per-XCD L2s are not coherent with each other, a CU's L1 is never
-// refreshed by another CU's stores -- MI355X_MICROARCH.md, "inter-workgroup visibility"): the producer writes its payload with
-// write-through (sc1) stores, drains them (adp_drain_stores) and only then takes a ticket with an agent-scope atomic; the consumer
-// -- whoever draws the last ticket -- reads the payload with sc1 loads (L1 bypassed; its L2 cannot hold the lines: nobody on its
-// XCD read them in this launch).  No release / acquire fence (those write back / invalidate whole caches: microseconds).
-__device__ __forceinline__ void adp_agent_store(float* p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float adp_agent_load(const float* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ int adp_agent_ticket(int* p) {
-  return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void adp_agent_store_int(int* p, int v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void adp_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
 // v_rcp_f32 (1 ulp) instead of the IEEE division sequence
 __device__ __forceinline__ float adp_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
@@ -187,10 +168,13 @@ __device__ __forceinline__ void adp_wait_until(long long t) {
   do {                                                                                                        \
     if ((threadIdx.x & 63) == 0) adp_kt_lds[(threadIdx.x >> 6) * 64 + (slot)] = __builtin_readcyclecounter(); \
   } while (0)
+#ifndef ADP_KT_STRIDE
+#define ADP_KT_STRIDE 1  /* trace every ADP_KT_STRIDE-th workgroup (64 of them) */
+#endif
 #define ADP_KT_DUMP(block_linear)                                                                                   \
   do {                                                                                                              \
-    if (adp_kt_out && (block_linear) < 64)                                                                          \
-      adp_kt_out[((int64_t)(block_linear) * 16 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63)] =                   \
+    if (adp_kt_out && ((block_linear) % ADP_KT_STRIDE) == 0 && (block_linear) / ADP_KT_STRIDE < 64)                 \
+      adp_kt_out[((int64_t)((block_linear) / ADP_KT_STRIDE) * 16 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63)] = \
           adp_kt_lds[(threadIdx.x >> 6) * 64 + (threadIdx.x & 63)];                                                 \
   } while (0)
 #else

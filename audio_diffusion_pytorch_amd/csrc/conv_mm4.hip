@@ -389,9 +389,9 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
   }
   __syncthreads();
 
-  // ---- output transform + epilogue: this wave finishes accumulator rows RPW * wave .. (for both halves of the wave)
+  // ---- output transform: this wave finishes accumulator rows RPW * wave .. (for both halves of the wave)
   const bool nok = nq < N;  // N % 4 == 0: a quad is inside or outside
-  float vfin[RPW][4];
+  f32x4 yv[RPW];
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr) {
     const int r = RPW * wave + rr;
@@ -406,11 +406,19 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
     const float p0 = 0.25f * s[0], p1 = s[1] * (-1.0f / 6.0f), p2 = s[2] * (-1.0f / 6.0f);
     const float p3 = s[3] * (1.0f / 24.0f), p4 = s[4] * (1.0f / 24.0f), p5 = s[5];
     const float a12 = p1 + p2, d12 = p1 - p2, a34 = p3 + p4, d34 = p3 - p4;
-    f32x4 y;
-    y[0] = p0 + a12 + a34;
-    y[1] = fmaf(2.0f, d34, d12);
-    y[2] = fmaf(4.0f, a34, a12);
-    y[3] = fmaf(8.0f, d34, d12) + p5;
+    yv[rr][0] = p0 + a12 + a34;
+    yv[rr][1] = fmaf(2.0f, d34, d12);
+    yv[rr][2] = fmaf(4.0f, a34, a12);
+    yv[rr][3] = fmaf(8.0f, d34, d12) + p5;
+  }
+  const bool final_tile = (KS == 1);
+
+  // ---- epilogue
+  float vfin[RPW][4];
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int r = RPW * wave + rr;
+    f32x4 y = yv[rr];
     const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
     const bool ok = (m < M) && nok;
 #pragma unroll
@@ -433,7 +441,7 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
       }
       continue;
     }
-    if (KS > 1) {  // raw partial tile; the epilogue runs in the reduce kernel
+    if (!final_tile) {  // raw partial tile; the epilogue runs in the reduce kernel
       *reinterpret_cast<f32x4*>(d.ws + (((int64_t)ks * d.B + b) * M + m) * N + nq) = y;
       continue;
     }
@@ -450,7 +458,7 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
 
   // ---- GroupNorm partial statistics of the tile just stored: one (mean, M2, count) entry per (the RPW rows of a row quad this
   // wave finished: half a quad or all of it) x (128-position tile); the consumer Chan-combines the entries whatever their counts
-  if (d.gn_part != nullptr && n0 < N && KS == 1 && d.store == 0) {
+  if (d.gn_part != nullptr && n0 < N && final_tile && d.store == 0) {
     const int cntv = (N - n0) < M4_BN ? (N - n0) : M4_BN;
     const float fcnt = (float)RPW * (float)cntv;
     float sv = 0.0f;

@@ -532,139 +532,6 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_vec_kernel(const float* __re
   }
 }
 
-// ---- the same backward as ONE launch for the deep layers: a workgroup owns a (batch element, group) slab ------------------------
-// At depths 6-8 a group's slab is Cg x L = 64-128 rows of 128-512 floats: 64-128 KB of x and as much of dact -- 8 quads of
-// each per lane of a 1024-thread workgroup.  The pair above reads both tensors twice and pays two launches whose kernels are
-// 5-8 us of latency, not bandwidth (rocprofv3, round 5: 96 launches, 0.70 ms per step at batch 4).  Here the slab is read ONCE
-// into registers: ds = dact * silu'(h) and xhat replace the loaded values, per-row sums (A_c, B_c) are reduced over the lanes of
-// a row segment and parked in LDS, every wave folds them into the group's (m1, m2) in the same fixed order, dx is formed from the
-// registers and stored.  The parameter gradients need the sum over the BATCH, i.e. over workgroups: each workgroup publishes its
-// (A_c, B_c) rows write-through, the one that draws the group's last ticket adds them in batch order (deterministic) and re-arms
-// the ticket (adp_rt.h: agent-scope hand-off without cache-wide fences).
-template <int NV>
-__global__ __launch_bounds__(1024) void gn_bwd_slab_kernel(const float* __restrict__ x, const float* __restrict__ dact,
-                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, const float* __restrict__ dres,
-                                                           int C, int L, int G, int B, float* __restrict__ dx, float* ab,
-                                                           int* tickets, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int accumulate) {
-  __shared__ float ent[2 * 8192 / 16];  // (A, B) per row segment: at most 8192 quads / 16 lanes
-  __shared__ int last_flag;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int bg = blockIdx.x, b = bg / G, g = bg % G, Cg = C / G;
-  const int LQ = L >> 2, Q = Cg * LQ;            // quads per row / per slab
-  const int SEG = LQ < 64 ? LQ : 64;             // lanes of a wave that share a row (LQ is a power of two >= 16)
-  const int64_t base = (int64_t)bg * Cg * L;
-  const float* xs = x + base;
-  const float* ds_ = dact + base;
-  f32x4 xv[NV], dv[NV];
-  float gm[NV], bt[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int e = i * 1024 + tid;
-    if (e < Q) {
-      xv[i] = *reinterpret_cast<const f32x4*>(xs + 4 * (int64_t)e);
-      dv[i] = *reinterpret_cast<const f32x4*>(ds_ + 4 * (int64_t)e);
-      const int c = g * Cg + e / LQ;
-      gm[i] = gamma[c];
-      bt[i] = beta[c];
-    }
-  }
-  const float mean = stats[bg * 2], rstd = stats[bg * 2 + 1];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int e = i * 1024 + tid;
-    float a = 0.0f, bs = 0.0f;
-    if (e < Q) {
-      const float ga = gm[i] * rstd, be = bt[i] - mean * ga;  // h = x * ga + be
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float xh = (xv[i][k] - mean) * rstd;
-        const float dsv = dv[i][k] * adp_dsilu_fast(fmaf(xv[i][k], ga, be));
-        a = fmaf(dsv, xh, a);
-        bs += dsv;
-        xv[i][k] = xh;
-        dv[i][k] = dsv;
-      }
-    }
-    for (int o = 1; o < SEG; o <<= 1) {  // (uniform bound; idle lanes of a partly filled last pass carry zeros)
-      a += __shfl_xor(a, o, 64);
-      bs += __shfl_xor(bs, o, 64);
-    }
-    if ((lane & (SEG - 1)) == 0 && e < Q) {
-      const int s = e / SEG;  // segment index: consecutive segments of a row are adjacent
-      ent[2 * s] = a;
-      ent[2 * s + 1] = bs;
-    }
-  }
-  __syncthreads();
-  // group sums, by every wave in the same order: lane j takes segments j, j + 64, ...; then a wave reduction
-  const int NSEG = Q / SEG, SPR = LQ / SEG;  // segments per slab / per row
-  float sa = 0.0f, sb = 0.0f;
-  for (int s0 = lane; s0 < NSEG; s0 += 64) {
-    const float gmr = gamma[g * Cg + s0 / SPR];
-    sa = fmaf(gmr, ent[2 * s0], sa);
-    sb = fmaf(gmr, ent[2 * s0 + 1], sb);
-  }
-  sa = adp_wave_sum(sa);
-  sb = adp_wave_sum(sb);
-  const float inv = 1.0f / ((float)Cg * (float)L);
-  const float m2 = sa * inv, m1 = sb * inv;
-  // this batch element's (A_c, B_c) rows, published for the parameter gradients
-  if (dgamma != nullptr && tid < Cg) {
-    float pa = 0.0f, pb = 0.0f;
-    for (int k = 0; k < SPR; ++k) {
-      pa += ent[2 * (tid * SPR + k)];
-      pb += ent[2 * (tid * SPR + k) + 1];
-    }
-    float* o = ab + ((int64_t)b * C + g * Cg + tid) * 2;
-    adp_agent_store(o, pa);
-    adp_agent_store(o + 1, pb);
-  }
-  float* dxs = dx + base;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int e = i * 1024 + tid;
-    if (e >= Q) continue;
-    f32x4 o;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = rstd * (gm[i] * dv[i][k] - m1 - xv[i][k] * m2);
-    if (dres) {
-      const f32x4 r = *reinterpret_cast<const f32x4*>(dres + base + 4 * (int64_t)e);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] += r[k];
-    }
-    *reinterpret_cast<f32x4*>(dxs + 4 * (int64_t)e) = o;
-  }
-  if (dgamma == nullptr) return;
-  adp_drain_stores();  // (this lane's published rows have reached memory before the workgroup takes its ticket)
-  __syncthreads();
-  if (tid == 0) {
-    const int t = adp_agent_ticket(tickets + g);
-    last_flag = (t == B - 1);
-    if (t == B - 1) adp_agent_store_int(tickets + g, 0);  // re-armed for the next launch (the stream orders launches)
-  }
-  __syncthreads();
-  if (last_flag && tid < Cg) {
-    const int c = g * Cg + tid;
-    float pa = 0.0f, pb = 0.0f;
-    for (int bb = 0; bb < B; ++bb) {  // batch order: deterministic
-      pa += adp_agent_load(ab + ((int64_t)bb * C + c) * 2);
-      pb += adp_agent_load(ab + ((int64_t)bb * C + c) * 2 + 1);
-    }
-    dgamma[c] = accumulate ? dgamma[c] + pa : pa;
-    dbeta[c] = accumulate ? dbeta[c] + pb : pb;
-  }
-}
-
-// slab form: rows of 64-4096 floats with a power-of-two quad count, the slab within 8 quads per lane of x and of dact
-static bool gn_bwd_slab_ok(int64_t B, int64_t C, int64_t L, int64_t G) {
-  if (C % G || (L & 3)) return false;
-  const int64_t LQ = L / 4, Q = (C / G) * LQ;
-  if (LQ < 16 || (LQ & (LQ - 1)) || Q > 8192 || Q < 1024 || C / G > 1024) return false;
-  return B * G <= 65535;
-}
-
 // threads per (row, split) segment of the vector form: one float4 per lane up to a wave, the whole workgroup beyond
 static int gn_bwd_tpr(int64_t CL) { return CL <= 64 ? 16 : (CL <= 128 ? 32 : (CL <= 1024 ? 64 : 256)); }
 static bool gn_bwd_vec_ok(const float* x, const float* dact, const float* dres, const float* dx, int64_t L, int64_t CL) {
@@ -1669,39 +1536,6 @@ extern "C" int adp_gn_silu_bwd_apply(const float* x, const float* dact, const fl
   }
   ADP_LAUNCH(gn_bwd_apply_kernel, dim3((unsigned)NS, (unsigned)(B * C)), dim3(256), stream, x, dact, stats, gamma,
              beta, ab, dres, C, L, G, NS, CL, dx, B, dgamma, dbeta, (int)accumulate);
-  return ADP_LAUNCH_OK();
-}
-
-// One-launch form of the two calls above for the deep layers (gn_bwd_slab_kernel).  `ab`: B * C * 2 floats of scratch (the
-// per-batch-element rows of the parameter gradients), `tickets`: G ints, ZERO when first used and left zero by every launch.
-// Returns ADP_ERR_UNSUPPORTED when the shape is outside the slab form (adp_gn_silu_bwd_slab_ok says so without a launch).
-extern "C" int64_t adp_gn_silu_bwd_slab_ok(int64_t B, int64_t C, int64_t L, int64_t G) {
-  const char* e = getenv("ADP_GN_BWD_SLAB");  // (A/B: "0" keeps the two-launch form)
-  if (e && e[0] == '0') return 0;
-  return (B > 0 && C > 0 && L > 0 && G > 0 && gn_bwd_slab_ok(B, C, L, G)) ? 1 : 0;
-}
-
-extern "C" int adp_gn_silu_bwd_slab(const float* x, const float* dact, const float* stats, const float* gamma,
-                                    const float* beta, const float* dres, int64_t B, int64_t C, int64_t L, int64_t G,
-                                    float* dx, float* ab, int32_t* tickets, float* dgamma, float* dbeta, int64_t accumulate,
-                                    void* stream) {
-  if (!x || !dact || !stats || !gamma || !beta || !dx || (!dgamma != !dbeta) || (dgamma && (!ab || !tickets)))
-    return ADP_ERR_NULL;
-  if (B <= 0 || C <= 0 || L <= 0 || G <= 0) return ADP_ERR_SHAPE;
-  if (!gn_bwd_slab_ok(B, C, L, G)) return ADP_ERR_UNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dact) | reinterpret_cast<uintptr_t>(dres) |
-       reinterpret_cast<uintptr_t>(dx)) & 15)
-    return ADP_ERR_ALIGN;
-  const int64_t Q = (C / G) * (L / 4);
-  const dim3 grid((unsigned)(B * G));
-#define ADP_GN_SLAB(NVV)                                                                                              \
-  ADP_LAUNCH((gn_bwd_slab_kernel<NVV>), grid, dim3(1024), stream, x, dact, stats, gamma, beta, dres, (int)C, (int)L, \
-             (int)G, (int)B, dx, ab, (int*)tickets, dgamma, dbeta, (int)accumulate)
-  if (Q <= 1024) ADP_GN_SLAB(1);
-  else if (Q <= 2048) ADP_GN_SLAB(2);
-  else if (Q <= 4096) ADP_GN_SLAB(4);
-  else ADP_GN_SLAB(8);
-#undef ADP_GN_SLAB
   return ADP_LAUNCH_OK();
 }
 

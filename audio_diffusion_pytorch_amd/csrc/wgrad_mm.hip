@@ -647,7 +647,7 @@ static int64_t wg_split(int64_t tiles, int64_t total, int64_t target) {
 // and read back, longer K loops per workgroup, and for the 512-channel layers (64 tiles x 4 items) no second stage at all.  The tile
 // edge is the lone launch's (the scratch was sized for that plan; a batched plan never needs more).  ADP_WGRAD_BATCH_SPLIT=0: every
 // item keeps the lone split (A/B; then batched and lone calls are bit-identical, otherwise they differ in summation order).
-WgPlan wg_plan(const adp_wgrad_desc& d, int n = 1) {
+WgPlan wg_plan(const adp_wgrad_desc& d, int n = 1, int64_t slots64 = 256) {  // slots64: 64 x 64 workgroups the chip holds at once
   WgPlan p;
   p.nkg = 4;
   p.cpb = adp_cdiv(d.N, WG_BKN);
@@ -655,14 +655,14 @@ WgPlan wg_plan(const adp_wgrad_desc& d, int n = 1) {
   // 12-wave workgroups (64x64 tiles): one per CU fills the SIMDs; 8-wave workgroups (32x32): about three per CU
   const bool can64 = d.M % 64 == 0 && d.R % 64 == 0 && d.stride != 4;  // stride 4: x rows are 4x wider in LDS
   const int64_t t64 = (d.M / 64) * (d.R / 64), t32 = (d.M / 32) * (d.R / 32);
-  const int64_t ns64 = can64 ? wg_split(t64, total, 256) : 0, ns32 = wg_split(t32, total, 768);
+  const int64_t ns64 = can64 ? wg_split(t64, total, slots64) : 0, ns32 = wg_split(t32, total, 768);
   // 64x64 tiles unless they leave most CUs idle while 32x32 tiles (4x as many, half the staging per workgroup) do not
   p.bm = (can64 && (t64 * ns64 >= 200 || t32 * ns32 <= 3 * t64 * ns64)) ? 64 : 32;
   // (32 x 32 tiles WITHOUT the position split were measured for the 512-channel layers: batch 4 +0.13 ms, batch 1 -0.08 ms)
   int64_t ns = p.bm == 64 ? ns64 : ns32;
   if (n > 1) {
     const char* e = getenv("ADP_WGRAD_BATCH_SPLIT");
-    if (!e || e[0] != '0') ns = p.bm == 64 ? wg_split(t64 * n, total, 256) : wg_split(t32 * n, total, 768);
+    if (!e || e[0] != '0') ns = p.bm == 64 ? wg_split(t64 * n, total, slots64) : wg_split(t32 * n, total, 768);
   }
   p.cps = adp_cdiv(total, ns);
   p.nsplit = adp_cdiv(total, p.cps);
@@ -804,13 +804,16 @@ int pick_wg(const adp_wgrad_desc* ds, int n, void* stream) {
   if constexpr (WN) {  // the F(4,3) form of the kernel-3 weight gradients (wg_winograd4)
     if (wg_winograd4(ds[0])) {
       if constexpr (S == 1 && UP == 1 && PRO == 0) {
-        // One MMA wave per SIMD, TWO 8-wave blocks per CU, for the launches that are long K loops over many tiles without a
-        // position split (the batched 1024-channel layers: 2048 blocks of 16 chunks).  Measured per batched launch, 12-wave ->
-        // solo: n8 [4,1024,256] 270.9 -> 246.8 us, n8 [4,1024,128] 152.0 -> 132.5 us (K loop at 96 % of the matrix pipe); the
-        // split layers lose (n4 [4,512,1024] 129.8 -> 138.3 us) and keep the 12-wave block.  ADP_WG_SOLO=0 / 1 forces either.
+        // One MMA wave per SIMD, TWO 8-wave blocks per CU (independent blocks: no lock step, K loop at 96 % of the matrix pipe),
+        // planned for 512 resident workgroups.  Measured per batched launch, 12-wave -> solo: n8 [4,1024,256] 270.9 -> 246.8 us,
+        // n8 [4,1024,128] 152.0 -> 132.5 us.  Taken when the 512-slot plan keeps >= 8 chunks per workgroup, fills the slots and
+        // needs no more scratch than the lone launch's plan sized (adp_wgrad_mm_ws_floats).  ADP_WG_SOLO=0 / 1 forces either.
+        const WgPlan ps = wg_plan(ds[0], n, 512);
+        const int64_t t64 = (ds[0].M / 64) * (ds[0].R / 64);
         const char* so = getenv("ADP_WG_SOLO");
-        const bool solo = so ? so[0] == '1' : (p.nsplit == 1 && (ds[0].M / 64) * (ds[0].R / 64) * n >= 1024);
-        if (p.bm == 64 && solo) return launch_wg<64, KT, S, UP, PRO, true, true, 1, 1>(ds, n, p, stream);
+        const bool fits = ps.bm == 64 && (ps.nsplit == 1 || ps.nsplit <= wg_plan(ds[0]).nsplit);
+        const bool solo = fits && (so ? so[0] == '1' : (t64 * n * ps.nsplit >= 512 && ps.cps >= 8));
+        if (solo) return launch_wg<64, KT, S, UP, PRO, true, true, 1, 1>(ds, n, ps, stream);
       }
       if (p.bm == 64) return launch_wg<64, KT, S, UP, PRO, true, true>(ds, n, p, stream);
       return launch_wg<32, KT, S, UP, PRO, true, true>(ds, n, p, stream);

@@ -237,18 +237,6 @@ def gn_stats_act(x: Tensor, groups: int, gamma: Tensor, beta: Tensor, eps: float
     return stats, act
 
 
-_TICKETS = {}
-
-
-def _tickets(device, n: int) -> Tensor:
-    """Zeroed int32 ticket words of the in-kernel hand-offs (adp_gn_silu_bwd_slab): allocated once per device; every launch
-    that uses them leaves them zero, and launches on one stream are ordered, so all calls share the same words."""
-    t = _TICKETS.get(device)
-    if t is None or t.numel() < n:
-        t = _TICKETS[device] = torch.zeros(max(64, n), dtype=torch.int32, device=device)
-    return t
-
-
 def gn_silu_bwd(x: Tensor, dact: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor, groups: int,
                 dres: Optional[Tensor] = None, dx: Optional[Tensor] = None, dgamma: Optional[Tensor] = None,
                 dbeta: Optional[Tensor] = None, accumulate: bool = False):
@@ -261,13 +249,6 @@ def gn_silu_bwd(x: Tensor, dact: Tensor, stats: Tensor, gamma: Tensor, beta: Ten
     if dbeta is None:
         dbeta = torch.empty_like(beta)
     s = _C.stream()
-    if _C.query("adp_gn_silu_bwd_slab_ok", B, C, L, groups):
-        # deep layers: one launch, x and dact read once (a workgroup per (batch element, group) slab)
-        ab = torch.empty((B, C, 2), dtype=torch.float32, device=x.device)
-        _C.tag(bytes=(12 + (4 if dres is not None else 0)) * x.numel(), shape=f"B{B} C{C} L{L}")
-        _C.call("adp_gn_silu_bwd_slab", ptr(x), ptr(dact), ptr(stats), ptr(gamma), ptr(beta), ptr(dres), B, C, L, groups,
-                ptr(dx), ptr(ab), ptr(_tickets(x.device, groups), torch.int32), ptr(dgamma), ptr(dbeta), int(accumulate), s)
-        return dx, dgamma, dbeta
     NS = _C.query("adp_row_nsplit", B * C, L)
     ab = torch.empty((B, C, NS, 2), dtype=torch.float32, device=x.device)
     _C.tag(bytes=8 * x.numel(), shape=f"B{B} C{C} L{L}")

@@ -186,15 +186,6 @@ int adp_gn_silu_bwd_apply(const float* x, const float* dact, const float* stats,
                           void* stream);
 int adp_gn_param_grad(const float* ab, int64_t B, int64_t C, int64_t NS, float* dgamma, float* dbeta,
                       int64_t accumulate, void* stream);
-/* One-launch backward of SiLU(GroupNorm(x)) for the deep layers (a workgroup per (batch element, group) slab of at most 8192
- * quads, rows of 64-4096 floats with a power-of-two quad count): dx (+ dres) and, when dgamma / dbeta are given, the parameter
- * gradients -- their sum over the batch is finished by the workgroup that draws the group's last ticket, in batch order.
- * ab: B*C*2 floats of scratch; tickets: G int32, zero before the first call and left zero by every call (re-armed in-kernel).
- * adp_gn_silu_bwd_slab_ok: 1 when the shape is served (ADP_GN_BWD_SLAB=0 switches the form off), else the two-call form applies. */
-int64_t adp_gn_silu_bwd_slab_ok(int64_t B, int64_t C, int64_t L, int64_t G);
-int adp_gn_silu_bwd_slab(const float* x, const float* dact, const float* stats, const float* gamma, const float* beta,
-                         const float* dres, int64_t B, int64_t C, int64_t L, int64_t G, float* dx, float* ab, int32_t* tickets,
-                         float* dgamma, float* dbeta, int64_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Modulation (a_unet ModulationItem, components.py:90): per position LayerNorm over channels

@@ -358,12 +358,6 @@ static inline float __fdividef(float a, float b) { return a / b; }
 static inline void adp_barrier_consume() { adp_emul::sync_block(); }
 static inline void adp_barrier_lds() { adp_emul::sync_block(); }
 static inline void adp_sched_fence() {}
-// (the emulator runs the workgroups of a launch one after another: the last one to run draws the last ticket)
-static inline void adp_agent_store(float* p, float v) { *p = v; }
-static inline float adp_agent_load(const float* p) { return *p; }
-static inline int adp_agent_ticket(int* p) { return (*p)++; }
-static inline void adp_agent_store_int(int* p, int v) { *p = v; }
-static inline void adp_drain_stores() {}
 template <class T> static inline T adp_nt_load(const T* p) { return *p; }
 template <class T> static inline void adp_nt_store(T v, T* p) { *p = v; }
 static inline void adp_wave_sync() { adp_emul::sync_wave(); }

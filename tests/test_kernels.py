@@ -1156,58 +1156,6 @@ def test_gn_silu_bwd(dev, B, C, L, G):
     assert rel_err(db, db_ref) < TOL
 
 
-@pytest.mark.parametrize("B,C,L,G", [(4, 1024, 256, 8), (3, 1024, 128, 8), (1, 512, 512, 8), (2, 48, 1024, 2), (2, 256, 64, 4),
-                                     (4, 512, 256, 8)])
-def test_gn_silu_bwd_slab(dev, B, C, L, G, monkeypatch):
-    """gn_bwd_slab_kernel: the one-launch backward of SiLU(GroupNorm(x)) for the deep layers -- a workgroup per (batch element,
-    group) slab held in registers (1 / 2 / 4 / 8 quads per lane; rows shorter than a wave's reach: L = 64, 128; a group that is
-    not a power-of-two number of rows: 48 x 1024), the batch sum of the parameter gradients finished by the workgroup that draws
-    the group's last ticket.  Against autograd, against the two-launch form, bit-identical when repeated (deterministic order),
-    with accumulation into existing parameter gradients, and the ticket words left at zero."""
-    if dev.type != "cuda" and B * C * L > 300000:
-        pytest.skip("emulating 1024-thread workgroups over the largest slabs takes minutes; covered on the GPU")
-    assert _C.query("adp_gn_silu_bwd_slab_ok", B, C, L, G) == 1
-    x = (rnd(B, C, L, seed=1) * 1.5 + 0.4).requires_grad_()
-    gamma = (rnd(C, seed=2) * 0.5 + 1).requires_grad_()
-    beta = (rnd(C, seed=3) * 0.2).requires_grad_()
-    y = ref_gn_silu(x, G, gamma, beta)
-    dact, dres = rnd(B, C, L, seed=4), rnd(B, C, L, seed=5)
-    dx_ref, dg_ref, db_ref = torch.autograd.grad(y, (x, gamma, beta), dact)
-    xd, gd, bd = x.detach().to(dev), gamma.detach().to(dev), beta.detach().to(dev)
-    stats = ops.gn_stats(xd, G)
-    dx, dg, db = ops.gn_silu_bwd(xd, dact.to(dev), stats, gd, bd, G, dres=dres.to(dev))
-    assert rel_err(dx, dx_ref + dres) < 1e-5 and rel_err(dg, dg_ref) < 1e-5 and rel_err(db, db_ref) < 1e-5
-    assert int(ops._tickets(xd.device, G).abs().sum()) == 0
-    dx2, dg2, db2 = ops.gn_silu_bwd(xd, dact.to(dev), stats, gd, bd, G, dres=dres.to(dev))
-    assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
-    dg0, db0 = rnd(C, seed=6).to(dev), rnd(C, seed=7).to(dev)
-    _, dg3, db3 = ops.gn_silu_bwd(xd, dact.to(dev), stats, gd, bd, G, dgamma=dg0.clone(), dbeta=db0.clone(), accumulate=True)
-    assert rel_err(dg3, dg_ref + dg0.cpu()) < 1e-5 and rel_err(db3, db_ref + db0.cpu()) < 1e-5
-    monkeypatch.setenv("ADP_GN_BWD_SLAB", "0")  # the two-launch form it replaces
-    assert _C.query("adp_gn_silu_bwd_slab_ok", B, C, L, G) == 0
-    dx1, dg1, db1 = ops.gn_silu_bwd(xd, dact.to(dev), stats, gd, bd, G, dres=dres.to(dev))
-    assert rel_err(dx, dx1) < 1e-5 and rel_err(dg, dg1) < 1e-5 and rel_err(db, db1) < 1e-5
-
-
-def test_gn_silu_bwd_slab_window():
-    """Which shapes the slab form serves: the README net's depths 6-8 at any batch (and depth 5 at 8 groups of 64 x 1024 is too
-    large for one workgroup's registers); narrow or ragged rows stay on the two-launch form."""
-    from audio_diffusion_pytorch_amd import _C as C_
-    sys_path_emul = None  # (pure query: no launch)
-    import sys as _sys
-    _sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emul"))
-    import build_emul
-    C_._testing_use_library(build_emul.build(), allow_cpu=True)
-    try:
-        ok = lambda *a: C_.query("adp_gn_silu_bwd_slab_ok", *a)  # noqa: E731
-        for B in (1, 4, 8):
-            assert ok(B, 512, 512, 8) and ok(B, 1024, 256, 8) and ok(B, 1024, 128, 8)
-            assert not ok(B, 512, 1024, 8) and not ok(B, 32, 65536, 8) and not ok(B, 8, 262144, 8)
-        assert not ok(2, 64, 132, 8) and not ok(2, 64, 40, 8) and not ok(1, 16, 64, 8)
-    finally:
-        C_._testing_use_library(None, allow_cpu=False)
-
-
 # ------------------------------------------------------------------ Modulation / LayerNorm over channels
 @pytest.mark.parametrize("B,C,L", [(2, 8, 300), (2, 32, 70), (1, 130, 64), (2, 100, 50), (2, 300, 40), (1, 1024, 24),
                                    (4, 512, 784), (4, 512, 400), (2, 1024, 128)])  # 16 / 8 / 4-position tiles

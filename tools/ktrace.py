@@ -66,6 +66,12 @@ def report(name, t, nwaves, nmma, mhz=2400.0):
             ds = [int(t[b, 0, 2 + 3 * c]) - int(row[slot(c)]) for c in range(4, 13) if row[slot(c)] > 0 and t[b, 0, 2 + 3 * c] > 0]
             arr.append(round(sum(ds) / max(1, len(ds))))
         print(f"  block {b}: cycles between a wave's arrival at the chunk barrier and its release, waves 0..{nmma - 1} MMA then loaders: {arr}")
+    # when did the traced workgroups start / end (one resident generation, or several?)
+    t00 = min(int(t[b, :nwaves, 0][t[b, :nwaves, 0] > 0].min()) for b in blocks)
+    starts = [round(us(int(t[b, :nwaves, 0][t[b, :nwaves, 0] > 0].min()) - t00), 1) for b in blocks]
+    ends = [round(us(max(int(v) for v in t[b, :nwaves, 60:64].flatten() if v > 0) - t00), 1) for b in blocks]
+    print(f"  start of every traced workgroup (us after the first): {starts}")
+    print(f"  end of every traced workgroup (us after the first start): {ends}")
     # aggregate over all traced blocks
     tot_wait = tot_work = n = 0
     span = []
