@@ -562,13 +562,7 @@ static bool m4_light(const adp_conv_desc& d) {
   const int64_t blocks = (d.M / M4_BM) * adp_cdiv(d.N, M4_BN) * d.B * m4_ks_eff(d);
   return blocks >= (e ? atoll(e) : 400);
 }
-// ONE MMA wave per SIMD for the grids of one block per CU (2 K groups x 2 plane groups + 4 loaders, 64-channel chunks):
-// ADP_MM4_SOLO=1 (A/B, round 6; tools/ktrace.py: the two MMA waves of a SIMD leave every chunk barrier in lock step)
-static bool m4_solo(const adp_conv_desc& d) {
-  const char* so = getenv("ADP_MM4_SOLO");
-  return so && so[0] == '1' && !m4_light(d) && d.up == 1 && d.R % 64 == 0 && m4_ks_eff(d) == 1;
-}
-static int m4_nkg(const adp_conv_desc& d) { return (m4_light(d) || m4_solo(d)) ? 2 : 4; }
+static int m4_nkg(const adp_conv_desc& d) { return m4_light(d) ? 2 : 4; }
 
 int64_t adp_conv_mm4_gn_entries(const adp_conv_desc& d) {
   if (d.store != 0) return 0;
@@ -592,12 +586,6 @@ int adp_conv_mm4(const adp_conv_desc& d, void* stream) {
       else if (c64) ADP_LAUNCH((conv_mm4_kernel<false, 1, 64, 4, 4>), grid, block, stream, d);
       else ADP_LAUNCH((conv_mm4_kernel<false, 1, 32, 4, 4>), grid, block, stream, d);
     }
-    return ADP_LAUNCH_OK();
-  }
-  if (m4_solo(d)) {
-    const dim3 block8((2 * M4_NPG + M4_NLD) * 64);
-    if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64, 2>), grid, block8, stream, d);
-    else ADP_LAUNCH((conv_mm4_kernel<false, 1, 64, 2>), grid, block8, stream, d);
     return ADP_LAUNCH_OK();
   }
   if (m4_nkg(d) == 2) {  // light block: 32-channel chunks (60 KB of LDS: two blocks per CU)

@@ -166,7 +166,7 @@ void wgrad_mm_kernel(  // (NKGP = 1: TWO 8-wave blocks per CU -- 72 KB of LDS ea
     ADP_LOADER_PRIO_SET();
     const int lt = tid - NMMA * 64;
     const bool do_bias = (d.dbias != nullptr) && (blockIdx.z == 0);
-    if constexpr (S == 1 && UP == 1 && PRO == 0) {
+    if constexpr (S == 1 && UP == 1 && (PRO == 0 || BM == 64)) {  // (32 x 32 tiles with the prologue: measured slower, 92 -> 115 us)
       if (N % BKN == 0) {
         // ---- LEAN loader (round 6; every layer of the README net: plain input, row length a multiple of the chunk).  The in-kernel
         // timeline (tools/ktrace.py) showed the F(4,3) blocks waiting for THIS wave, not for memory: its loads landed within
@@ -187,9 +187,30 @@ void wgrad_mm_kernel(  // (NKGP = 1: TWO 8-wave blocks per CU -- 72 KB of LDS ea
         float bsum[NS];
 #pragma unroll
         for (int i = 0; i < NS; ++i) bsum[i] = 0.0f;
+        // PRO = 1: GroupNorm + SiLU of the conv input on the way into LDS (per-slot gamma / beta in registers, the (mean, rstd)
+        // pair of the chunk's batch element fetched with the prefetch)
+        float x_ga[NS], x_be[NS], h_ga = 1.0f, h_be = 0.0f;
+        int x_st[NS], h_st = 0;
+        if constexpr (PRO == 1) {
+#pragma unroll
+          for (int i = 0; i < NS; ++i) {
+            const int r = r0 + row0 + 16 * i;
+            x_st[i] = (r / (R / G)) * 2;
+            x_ga[i] = d.pro_gamma ? d.pro_gamma[r] : 1.0f;
+            x_be[i] = d.pro_beta ? d.pro_beta[r] : 0.0f;
+          }
+          if (halo_lane) {
+            const int r = r0 + hrow;
+            h_st = (r / (R / G)) * 2;
+            h_ga = d.pro_gamma ? d.pro_gamma[r] : 1.0f;
+            h_be = d.pro_beta ? d.pro_beta[r] : 0.0f;
+          }
+        }
         f32x4 rd[PD][NS], rx[PD][NS], rh[PD];
+        float rm[PD][NS + 1], rr[PD][NS + 1];  // (mean, rstd) of the slots' rows, [NS] = the halo lane's row
         bool h_ok[PD];
-        auto load_chunk = [&](f32x4 (&qd)[NS], f32x4 (&qx)[NS], f32x4& qh, bool& okh, int k) {
+        auto load_chunk = [&](f32x4 (&qd)[NS], f32x4 (&qx)[NS], f32x4& qh, bool& okh, float (&qm)[NS + 1], float (&qr)[NS + 1],
+                              int k) {
           const int c = cbeg + (k < nloc ? k : nloc - 1);
           const int b = c / CPB, p0 = (c - b * CPB) * BKN;
           const float* dyb = d.dy + ((int64_t)b * M * N + p0);   // wave-uniform bases
@@ -202,8 +223,15 @@ void wgrad_mm_kernel(  // (NKGP = 1: TWO 8-wave blocks per CU -- 72 KB of LDS ea
             okh = (p0 + h_rel >= 0) && (p0 + h_rel < L);
             qh = *reinterpret_cast<const f32x4*>(d.x + ((int64_t)b * R * L + h_off) + (okh ? p0 + h_rel : 0));
           }
+          if constexpr (PRO == 1) {
+            const float* st = d.pro_stats + (int64_t)b * G * 2;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) qm[i] = st[x_st[i]], qr[i] = st[x_st[i] + 1];
+            if (halo_lane) qm[NS] = st[h_st], qr[NS] = st[h_st + 1];
+          }
         };
-        auto store_chunk = [&](const f32x4 (&qd)[NS], const f32x4 (&qx)[NS], const f32x4& qh, bool okh, int k) {
+        auto store_chunk = [&](const f32x4 (&qd)[NS], const f32x4 (&qx)[NS], const f32x4& qh, bool okh,
+                               const float (&qm)[NS + 1], const float (&qr)[NS + 1], int k) {
           float* Db = smem + (k & 1) * (D_ELEMS + X_ELEMS);
           float* Xb = Db + D_ELEMS;
           if (k < nloc) {  // (ghost chunks pad the loop to PD: their rows must not count into dbias)
@@ -213,16 +241,29 @@ void wgrad_mm_kernel(  // (NKGP = 1: TWO 8-wave blocks per CU -- 72 KB of LDS ea
 #pragma unroll
           for (int i = 0; i < NS; ++i) *reinterpret_cast<f32x4*>(Db + d_lds + i * 16 * DS) = qd[i];
 #pragma unroll
-          for (int i = 0; i < NS; ++i) *reinterpret_cast<f32x4*>(Xb + x_lds + i * 16 * XS) = qx[i];
+          for (int i = 0; i < NS; ++i) {
+            f32x4 v = qx[i];
+            if constexpr (PRO == 1) {
+              const float pa = x_ga[i] * qr[i], pb = x_be[i] - qm[i] * pa;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = adp_silu_fast(fmaf(v[j], pa, pb));
+            }
+            *reinterpret_cast<f32x4*>(Xb + x_lds + i * 16 * XS) = v;
+          }
           if (halo_lane) {
             f32x4 v = qh;
+            if constexpr (PRO == 1) {
+              const float pa = h_ga * qr[NS], pb = h_be - qm[NS] * pa;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = adp_silu_fast(fmaf(v[j], pa, pb));
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = okh ? v[j] : 0.0f;
             *reinterpret_cast<f32x4*>(Xb + h_lds) = v;
           }
         };
 #pragma unroll
-        for (int s = 0; s < PD; ++s) load_chunk(rd[s], rx[s], rh[s], h_ok[s], s);
+        for (int s = 0; s < PD; ++s) load_chunk(rd[s], rx[s], rh[s], h_ok[s], rm[s], rr[s], s);
         for (int k0 = 0; k0 < nrounds; k0 += PD) {
 #pragma unroll
           for (int s = 0; s < PD; ++s) {
@@ -231,8 +272,8 @@ void wgrad_mm_kernel(  // (NKGP = 1: TWO 8-wave blocks per CU -- 72 KB of LDS ea
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (k0 + s < 16) ADP_KT(2 + 3 * (k0 + s));
 #endif
-            store_chunk(rd[s], rx[s], rh[s], h_ok[s], k0 + s);
-            load_chunk(rd[s], rx[s], rh[s], h_ok[s], k0 + s + PD);
+            store_chunk(rd[s], rx[s], rh[s], h_ok[s], rm[s], rr[s], k0 + s);
+            load_chunk(rd[s], rx[s], rh[s], h_ok[s], rm[s], rr[s], k0 + s + PD);
 #ifdef ADP_KTRACE
             if (k0 + s < 16) ADP_KT(3 + 3 * (k0 + s));
 #endif
