@@ -53,6 +53,37 @@ def capture_step(step, warmup: int = 2):
     return graph, graph.replay
 
 
+def capture_step_deferred(step, dp: "DataParallel", warmup: int = 2):
+    """Fallback of capture_step for a stack on which collectives cannot be captured: the step's KERNELS are captured (the
+    data-parallel hook only notes which regions of the flat gradient buffer it would have sent), and `replay()` = graph replay +
+    the noted bucket all-reduces issued eagerly behind it on RCCL's stream + the wait.  No overlap with the backward pass, but no
+    per-kernel host launches either (an eager data-parallel step is host bound at ~2x the kernels' time).  Returns (graph, replay)."""
+    dp._deferred = []
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step()
+                dp.flush_deferred()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            step()
+        regions, flat = list(dp._deferred), dp._deferred_flat
+    except Exception:
+        dp._deferred = None
+        raise
+    dp._deferred = []
+
+    def replay():
+        graph.replay()
+        dp._deferred, dp._deferred_flat = list(regions), flat
+        dp.flush_deferred()
+    return graph, replay
+
+
 def init_process_group_from_env(backend: Optional[str] = None, graph_safe: bool = False) -> int:
     """Initialises torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).  `graph_safe=True`
     (opt-in: only jobs that will call capture_step need it) applies the settings of graph_safe_rccl_env, so that the
@@ -108,6 +139,8 @@ class DataParallel(nn.Module):
         self._collect = self.world > 1 or (force_collectives and dist.is_initialized())
         self.min_bucket = min_bucket_bytes // 4
         self._works: List = []
+        self._deferred: Optional[List] = None  # capture_step_deferred: regions noted instead of sent
+        self._deferred_flat: Optional[torch.Tensor] = None
         self._pending: List = []  # contiguous (start, end) regions not yet sent
         self._final_queued = False
         self.unet = self._find_unet(module)
@@ -142,6 +175,8 @@ class DataParallel(nn.Module):
 
     # ---- end-of-backward synchronisation (one autograd final callback per backward pass)
     def _queue_final(self):
+        if self._deferred is not None:  # (flush_deferred runs the trailing bucket behind the replay)
+            return
         if not self._final_queued:
             self._final_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
@@ -256,7 +291,25 @@ class DataParallel(nn.Module):
         self._works = []
 
     # ---- called from the U-Net backward as regions of the flat gradient become final
+    def flush_deferred(self) -> None:
+        """Sends the regions noted in deferred mode (capture_step_deferred) and waits for them (stream wait, no host sync)."""
+        regions, flat = self._deferred or [], self._deferred_flat
+        self._deferred = None
+        try:
+            for a, b in regions:
+                self._send(flat, a, b)
+            if self._extra:
+                self._finalize()
+            else:
+                self._wait_all()
+        finally:
+            self._deferred = []
+
     def _send(self, flat: torch.Tensor, a: int, b: int):
+        if self._deferred is not None:
+            self._deferred.append((a, b))
+            self._deferred_flat = flat
+            return
         buf = flat[a:b]
         if self._avg:
             self._works.append((dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))

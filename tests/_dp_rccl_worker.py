@@ -81,6 +81,16 @@ def main():
         assert (p.grad is None) == (e is None), name
         if e is not None:
             assert torch.equal(p.grad, e), f"replayed data-parallel step differs from the eager one at {name}"
+    # the fallback form: kernels captured, the bucket all-reduces issued eagerly behind every replay (capture_step_deferred)
+    from audio_diffusion_pytorch_amd.parallel import capture_step_deferred
+    g2, replay2 = capture_step_deferred(one_step, dp, warmup=1)
+    for _ in range(2):
+        replay2()
+    torch.cuda.synchronize()
+    for (name, p), e in zip(model.named_parameters(), eager):
+        if e is not None:
+            assert torch.equal(p.grad, e), f"deferred-collective replay differs from the eager step at {name}"
+    dp._deferred = None  # back to sending from inside backward
     print(f"rank {rank}/{world}: DataParallel over RCCL ok, worst relative gradient difference {worst:.2e}; the step replays "
           f"from a hipGraph with its collectives, bit-identical", flush=True)
     dist.barrier()

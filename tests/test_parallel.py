@@ -128,6 +128,13 @@ def _worker(rank, world, port, out_dir):
     saved["overlap"] = dp.measure_overlap(step, timer, reps=1)
     step()  # the wrapper still reduces after the measurement (hook re-attached)
     saved["grads_after"] = {n: p.grad.clone() for n, p in model.net.named_parameters()}
+    # deferred mode (parallel.capture_step_deferred without the graph): the hook only notes its regions, flush_deferred sends them
+    dp._deferred = []
+    step()
+    assert len(dp._deferred) >= 1 and not dp._works
+    dp.flush_deferred()
+    dp._deferred = None
+    saved["grads_deferred"] = {n: p.grad.clone() for n, p in model.net.named_parameters()}
     torch.save(saved, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -145,6 +152,8 @@ def test_dp2_gloo_equals_single_process(emul, tmp_path):
     assert len(ov["buckets_mb"]) >= 1 and 0.0 <= ov["hidden_frac"] <= 1.0
     for n in r0["grads"]:
         assert torch.equal(r0["grads_after"][n], r0["grads"][n]), n     # measuring leaves the reduction intact
+        assert torch.equal(r0["grads_deferred"][n], r0["grads"][n]), n  # regions noted during backward, sent behind it
+        assert torch.equal(r1["grads_deferred"][n], r0["grads"][n]), n
         assert torch.equal(r0["params"][n], r1["params"][n]), n          # broadcast happened
         assert torch.allclose(r0["grads"][n], r1["grads"][n], atol=0, rtol=0), n  # same averaged gradient
     # single process on the concatenated batch with rank 0's parameters
