@@ -1035,7 +1035,7 @@ def test_wgrad_mm_resample(dev, B, R, M, L, KT, stride, pad, up, wino, monkeypat
     assert rel_err(db, db_ref) < TOL
 
 
-@pytest.mark.parametrize("B,C,L", [(4, 128, 1024), (2, 64, 4096)])
+@pytest.mark.parametrize("B,C,L", [(4, 128, 1024), (2, 64, 4096), (4, 32, 65536)])
 def test_wgrad_winograd_f43_accuracy(dev, B, C, L, monkeypatch):
     """The F(4,3) weight gradient sums B * L positions through transform constants up to 8 (A e) and 5 (B^T d): bound its fp32
     error against fp64 next to the F(2,3) and direct forms on long rows (measured on the GPU: see DESIGN.md section 4)."""

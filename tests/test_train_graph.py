@@ -143,3 +143,61 @@ def test_replayed_step_with_conditioning_kwargs(hip):
         for a, b in zip(out[0][1], out[1][1]):
             assert torch.equal(a, b)
     assert graphed.GRAPHS_OF[up_g.diffusion].captures == 1
+
+
+@pytest.mark.gpu
+def test_training_with_an_optimizer_follows_the_eager_trajectory(hip):
+    """Five AdamW steps of the README loop (zero_grad / model(x) / backward / step), replayed vs launched eagerly, same seeds:
+    the parameters must end up bit-identical -- the optimizer reads gradients that alias the graph's static buffer, zero_grad drops
+    them, the next replay overwrites them."""
+    xs = [torch.randn(2, 2, 4096, device=hip) for _ in range(5)]
+    finals = []
+    for use_graph in (True, False):
+        m = _model(hip, seed=3, diffusion_use_graph=use_graph)
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+        torch.manual_seed(11)
+        torch.cuda.manual_seed(11)
+        losses = []
+        for x in xs:
+            opt.zero_grad()
+            loss = m(x)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        finals.append(([p.detach().clone() for p in m.parameters()], losses))
+    assert finals[0][1] == finals[1][1]
+    for a, b in zip(finals[0][0], finals[1][0]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_replayed_step_of_a_guided_text_conditional_net(hip):
+    """UNetV0(use_embedding_cfg=True) with cross attention: `embedding` becomes a static input, the Bernoulli batch mask is drawn
+    inside the captured step (fresh per replay), the fixed-embedding table OUTSIDE the U-Net gets its gradient through autograd
+    inside graph B."""
+    cfg = dict(in_channels=2, channels=[8, 32, 64], factors=[1, 4, 4], items=[1, 2, 2], modulation_features=64,
+               cross_attentions=[0, 1, 1], attention_heads=2, attention_features=16, embedding_features=24,
+               use_embedding_cfg=True, embedding_max_length=6)
+    out = []
+    emb = torch.randn(2, 6, 24, device=hip)
+    x = torch.randn(2, 2, 2048, device=hip)
+    for use_graph in (True, False):
+        torch.manual_seed(5)
+        m = adp.DiffusionModel(net_t=adp.UNetV0, diffusion_use_graph=use_graph, **cfg).to(hip)
+        torch.manual_seed(9)
+        torch.cuda.manual_seed(9)
+        steps = []
+        for _ in range(2):
+            _zero(m)
+            loss = m(x, embedding=emb, embedding_mask_proba=0.5)
+            loss.backward()
+            steps.append((loss.item(), [None if p.grad is None else p.grad.clone() for p in m.parameters()]))
+        out.append(steps)
+        if use_graph:
+            assert graphed.GRAPHS_OF[m.diffusion].captures == 1 and graphed.GRAPHS_OF[m.diffusion].replays == 2
+    for (la, ga), (lb, gb) in zip(out[0], out[1]):
+        assert la == lb
+        for a, b in zip(ga, gb):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b)

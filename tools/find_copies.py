@@ -1,28 +1,43 @@
-"""Which host-side ops issue device copies / fills in one training step (GPU box; kernel-work tool)."""
-import os, sys
+"""Which host-side torch ops put device copies (`__amd_rocclr_copyBuffer`, memset / fill kernels) into a training step?
+usage: python tools/find_copies.py [batch]"""
+import os
+import sys
 from collections import Counter
+
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import bench
-from torch.profiler import profile, ProfilerActivity
+from torch.profiler import ProfilerActivity, profile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+os.environ["ADP_TRAIN_GRAPH"] = "0"
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 dev = torch.device("cuda:0")
-m = bench.build_model(dev)
-x = torch.randn(1, 2, bench.LENGTH, device=dev)
+model = bench.build_model(dev)
+x = torch.randn(B, 2, bench.LENGTH, device=dev)
+
+
+def step():
+    for p in model.parameters():
+        p.grad = None
+    model(x).backward()
+
+
 for _ in range(2):
-    for p in m.parameters(): p.grad = None
-    m(x).backward()
-for p in m.parameters(): p.grad = None
+    step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    m(x).backward()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+    step()
     torch.cuda.synchronize()
-c = Counter()
+ops = Counter()
 for e in prof.events():
-    if e.name in ("aten::copy_", "aten::clone", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::mul", "aten::cat", "aten::sum"):
-        st = [s for s in (e.stack or []) if "audio_diffusion" in s or "bench" in s][:2]
-        shp = ""
-        c[(e.name, tuple(st))] += 1
-for k, v in c.most_common(25):
-    print(v, k)
-print([ (e.key, e.count) for e in prof.key_averages() if "copy" in e.key.lower() or "Memcpy" in e.key or "fill" in e.key.lower()][:20])
+    if e.name in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::fill_", "aten::zero_", "aten::zeros", "aten::to",
+                  "aten::_to_copy", "aten::cat", "aten::add_", "aten::mul_", "aten::mul", "aten::add"):
+        st = [s for s in (e.stack or []) if "audio_diffusion_pytorch_amd" in s or "bench.py" in s]
+        ops[(e.name, str(e.input_shapes)[:60], st[0][-90:] if st else "?")] += 1
+for (name, shp, where), c in ops.most_common(40):
+    print(f"{c:4d}  {name:18s} {shp:60s} {where}")
+kern = Counter(e.name[:70] for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
+for k, c in kern.most_common(60):
+    if any(t in k for t in ("copy", "Memcpy", "Memset", "fill", "elementwise")):
+        print(f"GPU {c:4d}  {k}")
