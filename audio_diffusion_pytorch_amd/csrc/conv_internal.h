@@ -27,7 +27,7 @@ int adp_wgrad_mm(const adp_wgrad_desc& d, void* stream);
 int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, float* dw, float* dbias, int accumulate,
                      void* stream);
 
-// conv_mm4.hip: Winograd F(4,3) variant of the same block for the wide kernel-3 'same' convs without prologue (>= 128 channels,
+// conv_mm4.hip: Winograd F(4,3) variant of the same block for the wide kernel-3 'same' convs without prologue (>= 64 channels,
 // >= 200 blocks of 32 rows x 128 positions): MMA waves split the six Winograd planes and the chunk's channels
 bool adp_conv_mm4_eligible(const adp_conv_desc& d);
 int adp_conv_mm4(const adp_conv_desc& d, void* stream);

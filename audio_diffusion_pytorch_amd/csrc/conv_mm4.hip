@@ -1,5 +1,5 @@
 // Winograd F(4,3) implicit-GEMM Conv1d for the wide ResnetItem ConvBlock convs and their data gradients
-// (kernel 3, stride 1, 'same' padding, >= 128 channels, SiLU(GroupNorm(.)) already materialised by the statistics' second
+// (kernel 3, stride 1, 'same' padding, >= 64 channels (round 6; 128 before), SiLU(GroupNorm(.)) already materialised by the statistics' second
 // stage; /root/reference/audio_diffusion_pytorch/components.py:89).  Same machine model as
 // conv_mm_impl.h -- wave-specialised block, loaders that only copy, exact-f32 v_mfma_f32_32x32x2_f32 -- with one change of
 // tile economy:
@@ -520,7 +520,7 @@ bool adp_conv_mm4_eligible(const adp_conv_desc& d) {
   const char* mr = getenv("ADP_WINO4_MIN_R");
   // (from 128 channels: the materialised-activation layers; with the 12-wave block only, the short-K layers of depths 3-4 lost
   //  to conv_mm's wide-N F(2,3) blocks -- 12.22 vs 12.15 ms per step -- the light block wins them back: m4_nkg)
-  if (d.R < (mr ? atoll(mr) : 128) || d.R % 32 != 0 || d.M % M4_BM != 0) return false;
+  if (d.R < (mr ? atoll(mr) : 64) || d.R % 32 != 0 || d.M % M4_BM != 0) return false;  // (round 6: from 64 channels)
   if ((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.w) | reinterpret_cast<uintptr_t>(d.out) |
        reinterpret_cast<uintptr_t>(d.res) | reinterpret_cast<uintptr_t>(d.out_pre)) & 15)
     return false;

@@ -504,8 +504,10 @@ MOD_LN_FUSE = os.environ.get("ADP_MOD_LN_FUSE", "1") != "0"
 MOD_LN_BWD_FUSE = os.environ.get("ADP_MOD_LN_BWD_FUSE", "1") != "0"
 
 # channel count from which SiLU(GroupNorm(x)) is materialised instead of recomputed in the conv loaders
-# (round 3, with the Winograd variants: 128 -> 14.14, 256 -> 14.15, 512 -> 14.20, 64 -> 14.21, 1024 -> 14.37 ms per step)
-ACT_MATERIALIZE_MIN_C = int(os.environ.get("ADP_ACT_MATERIALIZE_MIN_C", "128"))
+# (round 3, with the Winograd variants: 128 -> 14.14, 256 -> 14.15, 512 -> 14.20, 64 -> 14.21, 1024 -> 14.37 ms per step;
+#  round 6: 64, together with the F(4,3) block from 64 input channels -- ADP_WINO4_MIN_R, conv_mm4.hip -- 11.11 -> 11.05 ms, 64
+#  alone 11.17)
+ACT_MATERIALIZE_MIN_C = int(os.environ.get("ADP_ACT_MATERIALIZE_MIN_C", "64"))
 
 
 class _Run:

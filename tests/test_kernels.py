@@ -451,8 +451,8 @@ def test_conv_dispatch_of_the_readme_layers(emul):
     for tr in (0, 1):
         assert tile(4, 32, 65536, tr)[0] == TILE32 and tile(1, 32, 65536, tr)[0] == TILE32
         for B in (4, 8):
-            for depth in (3, 4, 5, 6, 7):
-                C, L = {3: (128, 4096), 4: (256, 2048), **deep}[depth]
+            for depth in (2, 3, 4, 5, 6, 7):
+                C, L = {2: (64, 16384), 3: (128, 4096), 4: (256, 2048), **deep}[depth]
                 assert tile(B, C, L, tr)[0] == MM4, (B, depth)
         for depth in (5, 6, 7):
             assert tile(1, *deep[depth], tr) == (TILEK, 0), depth
