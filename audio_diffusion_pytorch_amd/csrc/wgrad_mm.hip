@@ -847,13 +847,13 @@ int pick_wg(const adp_wgrad_desc* ds, int n, void* stream) {
       if constexpr (S == 1 && UP == 1 && PRO == 0) {
         // One MMA wave per SIMD, TWO 8-wave blocks per CU (independent blocks: no lock step, K loop at 96 % of the matrix pipe),
         // planned for 512 resident workgroups.  Measured per batched launch, 12-wave -> solo: n8 [4,1024,256] 270.9 -> 246.8 us,
-        // n8 [4,1024,128] 152.0 -> 132.5 us.  Taken when the 512-slot plan keeps >= 8 chunks per workgroup, fills the slots and
+        // n8 [4,1024,128] 152.0 -> 132.5 us.  Taken when the 512-slot plan keeps >= 4 chunks per workgroup, fills the slots and
         // needs no more scratch than the lone launch's plan sized (adp_wgrad_mm_ws_floats).  ADP_WG_SOLO=0 / 1 forces either.
         const WgPlan ps = wg_plan(ds[0], n, 512);
         const int64_t t64 = (ds[0].M / 64) * (ds[0].R / 64);
         const char* so = getenv("ADP_WG_SOLO");
         const bool fits = ps.bm == 64 && (ps.nsplit == 1 || ps.nsplit <= wg_plan(ds[0]).nsplit);
-        const bool solo = fits && (so ? so[0] == '1' : (t64 * n * ps.nsplit >= 512 && ps.cps >= 8));
+        const bool solo = fits && (so ? so[0] == '1' : (t64 * n * ps.nsplit >= 512 && ps.cps >= 4));  // (batch 1, 4 chunks per block: step 6.16 -> 6.11 ms)
         if (solo) return launch_wg<64, KT, S, UP, PRO, true, true, 1, 1>(ds, n, ps, stream);
       }
       if (p.bm == 64) return launch_wg<64, KT, S, UP, PRO, true, true>(ds, n, p, stream);

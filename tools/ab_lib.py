@@ -1,6 +1,8 @@
 """A/B of two builds of libadp_hip.so on one GPU box (kernel work): tools/ab/lib_old.so vs tools/ab/lib_new.so, the
 headline training step replayed from a hipGraph, interleaved.  usage: python tools/ab_lib.py [rounds]"""
 import os
+
+os.environ.setdefault("ADP_TRAIN_GRAPH", "0")  # these tools launch / capture the step themselves (graphed.py is the README loop's path)
 import sys
 
 import torch

@@ -2,6 +2,8 @@
 usage: python tools/cfg_prof.py {config4|readme_attention|batch1} [steps] [batch]
 Prints the replayed (hipGraph) step time too, so a kernel table and the step it belongs to come from one process."""
 import os
+
+os.environ.setdefault("ADP_TRAIN_GRAPH", "0")  # these tools launch / capture the step themselves (graphed.py is the README loop's path)
 import sys
 
 import torch

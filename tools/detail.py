@@ -2,6 +2,8 @@
 variant -- kernel-work tool, run on the GPU box:  python tools/detail.py <out.txt> [--batch B] [--variant plain|attn|cfg4] [--fwd]"""
 import argparse
 import os
+
+os.environ.setdefault("ADP_TRAIN_GRAPH", "0")  # these tools launch / capture the step themselves (graphed.py is the README loop's path)
 import sys
 
 import torch

@@ -2,6 +2,8 @@
 ProcessGroupNCCL watchdog is kept away from the capture?  One-rank group, DataParallel(force_collectives=True).
 usage: python tools/dp_capture_probe.py <mode>   mode = thread_local | relaxed | global   (run each in its own process)"""
 import os
+
+os.environ.setdefault("ADP_TRAIN_GRAPH", "0")  # these tools launch / capture the step themselves (graphed.py is the README loop's path)
 import sys
 import time
 

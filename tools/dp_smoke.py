@@ -2,6 +2,8 @@
 offers): init, parameter broadcast, hook-driven bucketed all-reduce (ReduceOp.AVG, async, RCCL stream) from inside the
 U-Net backward, final wait -- and checks the gradients equal the plain single-process step."""
 import os
+
+os.environ.setdefault("ADP_TRAIN_GRAPH", "0")  # these tools launch / capture the step themselves (graphed.py is the README loop's path)
 import sys
 
 import torch

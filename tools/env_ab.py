@@ -1,6 +1,8 @@
 """Interleaved A/B of one environment switch on the headline training step (hipGraph replay), batch 4 and 1 (GPU box).
 usage: python tools/env_ab.py NAME A_VALUE B_VALUE [rounds]   e.g.  python tools/env_ab.py ADP_WGRAD_SIDE 0 1"""
 import os
+
+os.environ.setdefault("ADP_TRAIN_GRAPH", "0")  # these tools launch / capture the step themselves (graphed.py is the README loop's path)
 import sys
 
 import torch

@@ -2,6 +2,8 @@
 batch 4, launches asynchronous (no sync inside the profiled region).  usage: python tools/host_profile.py [batch]"""
 import cProfile
 import os
+
+os.environ.setdefault("ADP_TRAIN_GRAPH", "0")  # these tools launch / capture the step themselves (graphed.py is the README loop's path)
 import pstats
 import sys
 import time

@@ -4,6 +4,8 @@ usage: python tools/leg_ab.py {headline|batch1|config4|readme_attention} NAME=v1
   audio_diffusion_pytorch_amd/unet.py read at import (e.g. unet.MOD_LN_BWD_FUSE=0,1).  Settings are taken one at a time
   against the defaults (not the cross product)."""
 import os
+
+os.environ.setdefault("ADP_TRAIN_GRAPH", "0")  # these tools launch / capture the step themselves (graphed.py is the README loop's path)
 import sys
 
 import torch

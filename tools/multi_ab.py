@@ -1,6 +1,8 @@
 """Interleaved A/B/C... of environment settings on the headline training step (hipGraph replay) at one batch size.
 usage: python tools/multi_ab.py BATCH ROUNDS "A=1,B=2" "A=0" ...   (an empty string = the defaults)"""
 import os
+
+os.environ.setdefault("ADP_TRAIN_GRAPH", "0")  # these tools launch / capture the step themselves (graphed.py is the README loop's path)
 import sys
 
 import torch
