@@ -235,6 +235,101 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* q, const flo
   if (hi == 0 && qok) lse[(b * H + h) * (int64_t)n + iq] = mrun + logf(lrun);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// forward for FEW KEYS (m <= 64: cross attention over the 64-token embedding), D = 64 (round 6).  In the kernel above one wave owns
+// a 32-query tile and walks a serial chain of 128 MFMAs behind ~100 scalar loads whatever n is: 10-14 us per call with the chip idle
+// (batch x heads x n / 32 = 32 ... 1024 waves).  Here the FOUR waves of a workgroup share ONE 32-query tile: wave = (key block
+// kb, channel half dh).  S^T of key block kb is contracted over the 32 channels of half dh (16 MFMAs) and the two halves meet in
+// LDS; the softmax runs per wave on its 32 keys with the row maximum / sum exchanged through LDS; O^T rows 32 dh .. + 31 are
+// accumulated over the keys of block kb (16 MFMAs) and the two key blocks meet in LDS: 32 MFMAs and a quarter of the loads per
+// wave, four workgroup barriers.  Sums of two partials only: the order cannot matter (a + b = b + a), results are deterministic.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_fewkeys_kernel(const float* q, const float* k, const float* v, int H, int n, int m,
+                                                               int64_t qbs, int64_t kvbs, float scale, float* o, float* lse) {
+  constexpr int D = 64;
+  __shared__ float xch[4][16 * 64];  // one accumulator tile per wave
+  __shared__ float red[2][2][32];    // [max | sum][key block][query]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int kb = wave >> 1, dh = wave & 1;
+  const int64_t b = blockIdx.z, h = blockIdx.y;
+  const int i0 = blockIdx.x * 32, iq = i0 + l31;
+  const bool qok = iq < n;
+  const float* qh = q + b * qbs + h * (int64_t)D * n;
+  const float* kh = k + b * kvbs + h * (int64_t)D * m;
+  const float* vh = v + b * kvbs + h * (int64_t)D * m;
+  const int j0 = 32 * kb;
+  const bool kfull = j0 + 32 <= m, kany = j0 < m;
+  // ---- S^T partial over channels 32 dh .. 32 dh + 31: A = k[d][j0 + l31], B = q[d][i] * scale (d = 32 dh + 2 s + hi)
+  float kc[16], qf[16];
+  {
+    const int qcol = (32 * dh + hi) * n + (qok ? iq : n - 1);
+    const bool jok = j0 + l31 < m;
+    const int kcol = (32 * dh + hi) * m + (jok ? j0 + l31 : m - 1);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float qv = qh[2 * s * n + qcol], kv = kh[2 * s * m + kcol];
+      qf[s] = qok ? qv * scale : 0.0f;
+      kc[s] = jok ? kv : 0.0f;
+    }
+  }
+  // V rows of this wave's output half and key block, requested now (needed after the softmax)
+  float vr[16];
+  ld_row16<true>(vh, m, 32 * dh + l31, D, kany ? j0 : 0, hi, kfull && ((m & 3) == 0) && aligned16(vh), vr);
+  f32x16 st;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) st = adp_mfma32(kc[s], qf[s], st);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) xch[wave][r * 64 + lane] = st[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st[r] = xch[2 * kb][r * 64 + lane] + xch[2 * kb + 1][r * 64 + lane];  // (channel half 0 + half 1)
+  // ---- softmax over the 64 keys: this wave's 32 + the other key block's maximum / sum through LDS
+  float tmax = -3.0e38f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (!kfull && j0 + acc_row(r, hi) >= m) st[r] = -3.0e38f;
+    tmax = fmaxf(tmax, st[r]);
+  }
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+  if (dh == 0 && hi == 0) red[0][kb][l31] = tmax;
+  __syncthreads();
+  const float mrow = fmaxf(red[0][0][l31], red[0][1][l31]);
+  float psum = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float p = (kfull || j0 + acc_row(r, hi) < m) ? __expf(st[r] - mrow) : 0.0f;
+    st[r] = p;
+    psum += p;
+  }
+  psum += __shfl_xor(psum, 32, 64);
+  if (dh == 0 && hi == 0) red[1][kb][l31] = psum;
+  // ---- O^T rows 32 dh + l31 over the keys of block kb: A = v[d][j(s, hi)], B = P^T (own register s)
+  f32x16 oacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = 0.0f;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) oacc = adp_mfma32(kany ? vr[s] : 0.0f, st[s], oacc);
+  __syncthreads();  // (the S tiles have been read by everybody; the sums are there)
+  if (kb == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xch[wave][r * 64 + lane] = oacc[r];
+  }
+  __syncthreads();
+  if (kb == 0) {
+    const float lrow = red[1][0][l31] + red[1][1][l31];
+    const float inv = lrow > 0.0f ? 1.0f / lrow : 0.0f;
+    float* oh = o + (b * H + h) * (int64_t)D * n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dd = 32 * dh + acc_row(r, hi);
+      if (qok) oh[dd * n + iq] = (oacc[r] + xch[2 + dh][r * 64 + lane]) * inv;  // (key block 0 + block 1)
+    }
+    if (dh == 0 && hi == 0 && qok) lse[(b * H + h) * (int64_t)n + iq] = mrow + logf(lrow);
+  }
+}
+
 // merge of the forward key split (fixed order): M = max_s m_s, w_s = exp(m_s - M), L = sum_s w_s l_s,
 // o[d][i] = sum_s w_s O_s[d][i] / L, lse = M + log L.  One workgroup = 64 queries x 4 channels (blockIdx.z picks the
 // channel quad): every thread owns one output element, so the launch is wide instead of long.
@@ -633,6 +728,195 @@ __global__ __launch_bounds__(256) void attn_bwd_merged_kernel(attn_bwd_args a) {
                                 a.tps, a.pstride, a.dk, a.dv, (int)blockIdx.x - a.gq);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// backward for FEW KEYS (m <= 64), D = 64 (round 6): the two passes above as ONE launch whose workgroups -- like the few-keys
+// forward -- put FOUR waves (key block kb, channel half dh) on what one wave did alone.
+//   blocks [0, gq): query-major, one workgroup per 32-query tile.  S^T and dP^T of key block kb are contracted over channel half
+//     dh (16 + 16 MFMAs), the halves meet in LDS (with the halves of delta_i), dS^T is formed by both waves of a pair, dq rows
+//     32 dh .. + 31 are accumulated over the keys of block kb (16 MFMAs) and the two key blocks meet in LDS.
+//   blocks [gq, gq + ns): key-major, one workgroup per slice of query tiles.  Per tile S and dP - delta (the -delta_i column as
+//     one more MFMA step per half) are contracted over channel half dh and meet in LDS; wave (kb, dh) then owns the output tiles
+//     dv / dk [32 dh .. + 31][keys of block kb] outright (16 + 16 MFMAs per tile): nothing to exchange at the end.
+// 48 / 65 MFMAs per wave and tile instead of 192 / 129, a quarter / half of the scalar loads.  Two-term sums only (a + b).
+// ---------------------------------------------------------------------------------------------------
+struct attn_fk_args {
+  const float *q, *k, *v, *o, *dout, *lse;
+  int H, n, m;
+  int64_t qbs, kvbs;
+  float scale;
+  float* dq;
+  float *dk, *dv;  // destination or its ns partial copies (stride pstride)
+  int ns, tps;
+  int64_t pstride;
+  int gq;
+};
+__global__ __launch_bounds__(256) void attn_bwd_fewkeys_kernel(attn_fk_args a) {
+  constexpr int D = 64;
+  __shared__ float xch[4][2][16 * 64];  // two accumulator tiles per wave
+  __shared__ float dred[2][32];         // halves of delta_i (query-major role)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int kb = wave >> 1, dh = wave & 1;
+  const int64_t b = blockIdx.z, h = blockIdx.y;
+  const int n = a.n, m = a.m, H = a.H;
+  const float scale = a.scale;
+  const float* qh = a.q + b * a.qbs + h * (int64_t)D * n;
+  const float* kh = a.k + b * a.kvbs + h * (int64_t)D * m;
+  const float* vh = a.v + b * a.kvbs + h * (int64_t)D * m;
+  const float* doh = a.dout + (b * H + h) * (int64_t)D * n;
+  const float* oh = a.o + (b * H + h) * (int64_t)D * n;
+  const float* lh = a.lse + (b * H + h) * (int64_t)n;
+  const int j0 = 32 * kb;
+  const bool kfull = j0 + 32 <= m, kany = j0 < m;
+  const int jk = j0 + l31;
+  const bool jok = jk < m;
+  if ((int)blockIdx.x < a.gq) {
+    // =========================== query-major: dq of one 32-query tile ===========================
+    const int i0 = blockIdx.x * 32, iq = i0 + l31;
+    const bool qok = iq < n;
+    float qf[16], df[16], kc[16], vc[16];
+    float dpart = 0.0f;
+    {
+      const int qcol = (32 * dh + hi) * n + (qok ? iq : n - 1);
+      const int kcol = (32 * dh + hi) * m + (jok ? jk : m - 1);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float qv = qh[2 * s * n + qcol], dv_ = doh[2 * s * n + qcol], ov = oh[2 * s * n + qcol];
+        const float kv = kh[2 * s * m + kcol], vv = vh[2 * s * m + kcol];
+        qf[s] = qok ? qv : 0.0f;
+        df[s] = qok ? dv_ : 0.0f;
+        dpart = fmaf(df[s], qok ? ov : 0.0f, dpart);
+        kc[s] = jok ? kv : 0.0f;
+        vc[s] = jok ? vv : 0.0f;
+      }
+    }
+    dpart += __shfl_xor(dpart, 32, 64);  // this channel half's part of delta_i, query i0 + l31
+    float kr[16];                        // K rows of this wave's dq half and key block (needed last)
+    ld_row16<true>(kh, m, 32 * dh + l31, D, kany ? j0 : 0, hi, kfull && ((m & 3) == 0) && aligned16(kh), kr);
+    const float li = qok ? lh[iq] : 0.0f;
+    f32x16 st, dpt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = dpt[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      st = adp_mfma32(kc[s], qf[s], st);    // S^T[j][i], this half of the channels
+      dpt = adp_mfma32(vc[s], df[s], dpt);  // dP^T[j][i]
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      xch[wave][0][r * 64 + lane] = st[r];
+      xch[wave][1][r * 64 + lane] = dpt[r];
+    }
+    if (kb == 0 && hi == 0) dred[dh][l31] = dpart;
+    __syncthreads();
+    const float di = dred[0][l31] + dred[1][l31];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float sv = xch[2 * kb][0][r * 64 + lane] + xch[2 * kb + 1][0][r * 64 + lane];
+      const float dv_ = xch[2 * kb][1][r * 64 + lane] + xch[2 * kb + 1][1][r * 64 + lane];
+      const bool ok = (kfull || j0 + acc_row(r, hi) < m) && qok;
+      const float pr = ok ? __expf(sv * scale - li) : 0.0f;
+      dpt[r] = pr * (dv_ - di) * scale;  // dS^T[j][i]
+    }
+    f32x16 dqa;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqa[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) dqa = adp_mfma32(kany ? kr[s] : 0.0f, dpt[s], dqa);  // dq[32 dh + l31'][i] over the keys of block kb
+    __syncthreads();  // (everybody has read the S / dP tiles)
+    if (kb == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xch[wave][0][r * 64 + lane] = dqa[r];
+    }
+    __syncthreads();
+    if (kb == 0 && qok) {
+      float* dqh = a.dq + b * a.qbs + h * (int64_t)D * n;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dqh[(32 * dh + acc_row(r, hi)) * n + iq] = dqa[r] + xch[2 + dh][0][r * 64 + lane];
+    }
+    return;
+  }
+  // =========================== key-major: dk / dv over one slice of query tiles ===========================
+  const int sp = (int)blockIdx.x - a.gq;
+  const int i_beg = sp * a.tps * 32;
+  const int i_end = (i_beg + a.tps * 32 < n) ? i_beg + a.tps * 32 : n;
+  // K and V fragments of key block kb, channel half dh: B operands (lane (j = l31, kk = hi) -> x[32 dh + 2 s + hi][j])
+  float kf[16], vf[16];
+  {
+    const int kcol = (32 * dh + hi) * m + (jok ? jk : m - 1);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float kv = kh[2 * s * m + kcol], vv = vh[2 * s * m + kcol];
+      kf[s] = jok ? kv : 0.0f;
+      vf[s] = jok ? vv : 0.0f;
+    }
+  }
+  f32x16 dka, dva;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dka[r] = dva[r] = 0.0f;
+  const bool vecq = ((n & 3) == 0) && aligned16(qh) && aligned16(doh) && aligned16(lh);
+  for (int i0 = i_beg; i0 < i_end; i0 += 32) {
+    const bool full = i0 + 32 <= n;
+    const bool iok = i0 + l31 < n;
+    float qc[16], dc[16];
+    float dpart = 0.0f;
+    {
+      const int col = (32 * dh + hi) * n + (iok ? i0 + l31 : n - 1);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float qv = qh[2 * s * n + col], dv_ = doh[2 * s * n + col], ov = oh[2 * s * n + col];
+        qc[s] = iok ? qv : 0.0f;
+        dc[s] = iok ? dv_ : 0.0f;
+        dpart = fmaf(dc[s], iok ? ov : 0.0f, dpart);
+      }
+    }
+    dpart += __shfl_xor(dpart, 32, 64);  // this half's part of delta_i for query i0 + l31
+    float dor[16], qr[16], ls[16];       // rows 32 dh + l31 of dO and q (A operands of dv / dk), lse of the accumulator rows
+    ld_row16<true>(doh, n, 32 * dh + l31, D, i0, hi, full && vecq, dor);
+    ld_row16<true>(qh, n, 32 * dh + l31, D, i0, hi, full && vecq, qr);
+    ld_vec16(lh, i0, hi, n, full && vecq, ls);
+    f32x16 sa, dpa;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sa[r] = dpa[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      sa = adp_mfma32(qc[s], kf[s], sa);    // S[i][j], this half of the channels
+      dpa = adp_mfma32(dc[s], vf[s], dpa);  // dP[i][j]
+    }
+    dpa = adp_mfma32(hi == 0 ? -dpart : 0.0f, 1.0f, dpa);  // - (this half of delta_i) for every key column
+    if (i0 != i_beg) __syncthreads();                      // (the previous tile's exchange has been read)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      xch[wave][0][r * 64 + lane] = sa[r];
+      xch[wave][1][r * 64 + lane] = dpa[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float sv = xch[2 * kb][0][r * 64 + lane] + xch[2 * kb + 1][0][r * 64 + lane];
+      const float dv_ = xch[2 * kb][1][r * 64 + lane] + xch[2 * kb + 1][1][r * 64 + lane];
+      const bool ok = (full || i0 + acc_row(r, hi) < n) && jok;
+      const float pr = ok ? __expf(sv * scale - ls[r]) : 0.0f;
+      sa[r] = pr;                    // P[i][j]
+      dpa[r] = pr * dv_ * scale;     // dS[i][j]
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      dva = adp_mfma32(dor[s], sa[s], dva);   // dv[32 dh + l31'][j] += sum_i dO[d][i] P[i][j]
+      dka = adp_mfma32(qr[s], dpa[s], dka);   // dk[32 dh + l31'][j] += sum_i q[d][i] dS[i][j]
+    }
+  }
+  if (jok) {
+    float* dkh = (a.ns > 1 ? a.dk + sp * a.pstride : a.dk) + b * a.kvbs + h * (int64_t)D * m;
+    float* dvh = (a.ns > 1 ? a.dv + sp * a.pstride : a.dv) + b * a.kvbs + h * (int64_t)D * m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dd = 32 * dh + acc_row(r, hi);
+      dkh[dd * m + jk] = dka[r];
+      dvh[dd * m + jk] = dva[r];
+    }
+  }
+}
+
 // query split of the key-major pass: enough waves to cover the chip when there are few key tiles
 int64_t kv_nsplit(int64_t B, int64_t H, int64_t n, int64_t m) {
   const int64_t ktiles = (m + 31) / 32, qtiles = (n + 31) / 32;
@@ -680,6 +964,14 @@ extern "C" int adp_attn_fwd(const float* q, const float* k, const float* v, int6
   int64_t tps = adp_cdiv(m, 32);
   const int64_t ns = ws ? q_nsplit(B, H, n, m, &tps) : 1;
   if (ns == 1) tps = adp_cdiv(m, 32);
+  {  // few keys (cross attention over the embedding): four waves per query tile (ADP_ATTN_FEWKEYS=0: the one-wave form, A/B)
+    const char* fk = getenv("ADP_ATTN_FEWKEYS");
+    if (D == 64 && m <= 64 && ns == 1 && (!fk || fk[0] != '0')) {
+      ADP_LAUNCH(attn_fwd_fewkeys_kernel, dim3((unsigned)adp_cdiv(n, 32), (unsigned)H, (unsigned)B), dim3(256), stream, q, k, v,
+                 (int)H, (int)n, (int)m, q_bstride, kv_bstride, scale, o, lse);
+      return ADP_LAUNCH_OK();
+    }
+  }
   const dim3 grid((unsigned)(adp_cdiv(n, 128) * ns), (unsigned)H, (unsigned)B);
   if (D == 64)
     ADP_LAUNCH(attn_fwd_kernel<true>, grid, dim3(256), stream, q, k, v, (int)H, (int)D, (int)n, (int)m, q_bstride,
@@ -733,6 +1025,43 @@ extern "C" int adp_attn_bwd(const float* q, const float* k, const float* v, cons
   if (nq > 1) {
     pq = ws + B * H * n + (ns > 1 ? 2 * ns * pstride : 0);
     qstride = B * q_bstride;
+  }
+  {  // few keys: four waves per query tile / per query slice in one launch (ADP_ATTN_FEWKEYS=0: the one-wave forms, A/B)
+    const char* fk = getenv("ADP_ATTN_FEWKEYS");
+    // (taken while the query tiles are few: at 1024+ the chip is full of one-wave items either way -- hipGraph microbench, us per
+    // backward, one-wave forms -> this kernel: batch 1 n = 128 16.4 -> 9.8, 256 16.2 -> 9.5, 1024 20.9 -> 17.0, 4096 52.1 ->
+    // 51.3; batch 4 n = 256 20.0 -> 15.9, n = 1024 40.4 -> 45.6, n = 4096 123 -> 177)
+    if (D == 64 && m <= 64 && B * H * qtiles <= (B * H <= 8 ? 1024 : 512) && (!fk || fk[0] != '0')) {
+      const char* et = getenv("ADP_ATTN_FK_SLICES");
+      int64_t ns4 = (et ? atoi(et) : 512) / (B * H);  // ~two workgroups per CU for the key-major role
+      if (ns4 > qtiles) ns4 = qtiles;
+      if (ns4 > 32) ns4 = 32;
+      if (ns4 < 1) ns4 = 1;
+      if (ns4 > ns) ns4 = ns;  // (the scratch is sized for kv_nsplit partial copies)
+      const int64_t tps4 = adp_cdiv(qtiles, ns4);
+      ns4 = adp_cdiv(qtiles, tps4);  // every slice non-empty
+      attn_fk_args a;
+      a.q = q, a.k = k, a.v = v, a.o = o, a.dout = dout, a.lse = lse;
+      a.H = (int)H, a.n = (int)n, a.m = (int)m, a.qbs = q_bstride, a.kvbs = kv_bstride, a.scale = scale;
+      a.dq = dq;
+      a.dk = ns4 > 1 ? pk : dk, a.dv = ns4 > 1 ? pv : dv;
+      a.ns = (int)ns4, a.tps = (int)tps4, a.pstride = pstride, a.gq = (int)qtiles;
+      unsigned gx4 = (unsigned)(qtiles + ns4);
+#ifdef ADP_ATTN_FK_DEBUG
+      if (const char* eo = getenv("ADP_ATTN_FK_ONLY")) {  // timing only (results incomplete): one role alone
+        if (eo[0] == 'q') gx4 = (unsigned)qtiles;
+        if (eo[0] == 'k') a.gq = 0, gx4 = (unsigned)ns4;
+      }
+#endif
+      ADP_LAUNCH(attn_bwd_fewkeys_kernel, dim3(gx4, (unsigned)H, (unsigned)B), dim3(256), stream, a);
+      if (ns4 > 1) {
+        const int64_t gx = adp_cdiv(H * D * m, 256);
+        ADP_LAUNCH(attn_bwd_reduce_kernel, dim3((unsigned)(gx < 2048 ? gx : 2048), (unsigned)(2 * B)), dim3(256), stream,
+                   (const float*)dq, 1, (int64_t)0, q_bstride, H * D * n, dq, 0, (const float*)pk, (const float*)pv, (int)ns4,
+                   pstride, kv_bstride, H * D * m, dk, dv);
+      }
+      return ADP_LAUNCH_OK();
+    }
   }
   const dim3 gq2((unsigned)(adp_cdiv(n, 128) * nq), (unsigned)H, (unsigned)B);
   const dim3 gkv((unsigned)adp_cdiv(ktiles * ns, 4), (unsigned)H, (unsigned)B);

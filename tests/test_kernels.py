@@ -1373,10 +1373,16 @@ def test_v_noise_mse_step(dev):
 @pytest.mark.parametrize("B,H,D,n,m", [(2, 2, 64, 160, 160), (1, 3, 32, 70, 45), (1, 8, 64, 128, 64),
                                        (1, 2, 64, 512, 64),    # few key tiles: the dk/dv pass splits the queries
                                        (2, 1, 16, 203, 37),    # ragged both ways, query split with a short last slice
-                                       (1, 2, 64, 96, 256)])
-@pytest.mark.parametrize("merge", ["1", "0"])  # backward: both passes in one launch (own delta) / two launches, delta through ws
-def test_attention_fwd_bwd(dev, B, H, D, n, m, merge, monkeypatch):
-    monkeypatch.setenv("ADP_ATTN_MERGE", merge)
+                                       (1, 2, 64, 96, 256),
+                                       (2, 2, 64, 70, 45), (1, 2, 64, 64, 20)])  # few keys: ragged second key block / one block
+# backward: both passes in one launch (own delta) / two launches, delta through ws; "fk": the four-wave kernels where 64 channels
+# meet at most 64 keys (the other two modes switch them off: the one-wave forms still serve those shapes at large batch * length)
+@pytest.mark.parametrize("mode", ["fk", "merged", "split"])
+def test_attention_fwd_bwd(dev, B, H, D, n, m, mode, monkeypatch):
+    if mode == "fk" and not (D == 64 and m <= 64):
+        pytest.skip("not a few-keys shape")
+    monkeypatch.setenv("ADP_ATTN_MERGE", "0" if mode == "split" else "1")
+    monkeypatch.setenv("ADP_ATTN_FEWKEYS", "1" if mode == "fk" else "0")
     mid = H * D
     q = rnd(B, mid, n, seed=1).requires_grad_()
     kv = rnd(B, 2 * mid, m, seed=2).requires_grad_()
@@ -1387,6 +1393,8 @@ def test_attention_fwd_bwd(dev, B, H, D, n, m, merge, monkeypatch):
     o_ref = torch.einsum("bhnm,bhmd->bhnd", att, vh).transpose(2, 3).reshape(B, mid, n)
     o, lse = ops.attn_fwd(q.detach().to(dev), kv.detach().to(dev), H, D)
     assert rel_err(o, o_ref) < TOL
+    lse_ref = torch.logsumexp(torch.einsum("bhnd,bhmd->bhnm", qh, kh) * D ** -0.5, dim=-1)
+    assert rel_err(lse.view(B, H, n), lse_ref) < 1e-5
     do = rnd(B, mid, n, seed=3)
     dq_ref, dkv_ref = torch.autograd.grad(o_ref, (q, kv), do)
     dq, dkv = ops.attn_bwd(q.detach().to(dev), kv.detach().to(dev), o, do.to(dev), lse, H, D)
