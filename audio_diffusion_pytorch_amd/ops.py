@@ -4,6 +4,7 @@ These only marshal tensors (device pointers, shapes, the current HIP stream) int
 gfx950 kernels; they hold no arithmetic of their own and have no fallback.  Outputs are allocated by
 the caller or with torch.empty on the input's device (PyTorch = device memory + streams only).
 """
+import contextlib
 import ctypes
 import os
 from ctypes import byref
@@ -96,11 +97,39 @@ class WgradPark:
     # 80 MB 12.77 -> 12.72 -> 12.68 ms per step; 80 MB covers every layer of the README configuration)
     BATCH_BYTES = 80 << 20
 
+    # flush() on a SIDE stream (ADP_WGRAD_SIDE=1): nothing downstream of a weight gradient is on the backward's critical path --
+    # the data-gradient chain goes on while the batched launches run beside it (a branch of the captured graph), join() is where
+    # somebody reads the gradients (the data-parallel hook, the end of the backward).  What the launches read stays referenced
+    # until join(): freed on the main stream it could be handed to a later main-stream kernel while the side stream still reads it.
+    SIDE = os.environ.get("ADP_WGRAD_SIDE", "0") != "0"
+    _side_streams = {}
+
     def __init__(self):
         self.items = []  # (key = (partials, cnt, M, accumulate, has_bias), ws, dw, dbias)
         self.calls = []  # (shape key, WgradDesc, tensors kept alive)
+        self.held = []   # what side-stream launches still read
+        self.forked = None
         if "ADP_WGRAD_BATCH_MB" in os.environ:  # (A/B: 0 = only second stages are parked)
             self.BATCH_BYTES = int(os.environ["ADP_WGRAD_BATCH_MB"]) << 20
+
+    def _fork(self, t: Tensor):
+        if not (self.SIDE and t.is_cuda):
+            return contextlib.nullcontext()
+        side = self.forked
+        if side is None:
+            side = self._side_streams.get(t.device)
+            if side is None:
+                side = self._side_streams[t.device] = torch.cuda.Stream(device=t.device)
+            self.forked = side
+        side.wait_stream(torch.cuda.current_stream(t.device))  # (the inputs were produced on the main stream)
+        return torch.cuda.stream(side)
+
+    def join(self) -> None:
+        """The main stream waits for the side-stream launches: gradients are final for whatever is enqueued next."""
+        if self.forked is not None:
+            torch.cuda.current_stream(self.forked.device).wait_stream(self.forked)
+            self.forked = None
+            self.held.clear()
 
     def add(self, key, ws: Tensor, dw: Tensor, dbias: Optional[Tensor]) -> None:
         self.items.append((key, ws, dw, dbias))
@@ -109,6 +138,12 @@ class WgradPark:
         self.calls.append((key, d, keep))
 
     def flush(self) -> None:
+        if not self.calls and not self.items:
+            return
+        with self._fork(self.calls[0][2][0] if self.calls else self.items[0][1]):
+            self._flush()
+
+    def _flush(self) -> None:
         if self.calls:
             groups = {}
             for key, d, keep in self.calls:
@@ -121,12 +156,16 @@ class WgradPark:
                     _C.tag(flops=2 * B * M * N * R * KT * len(ds), bytes=4 * len(ds) * (B * R * Lin + B * M * N + M * R * KT),
                            shape=f"n{len(ds)} B{B} R{R} M{M} N{N} KT{KT}")
                 _C.call("adp_conv1d_wgrad_batch", arr, len(ds), _C.stream())
+            if self.forked is not None:
+                self.held.append(calls)
             del calls
         if not self.items:
             return
         groups = {}
         for key, ws, dw, dbias in self.items:
             groups.setdefault(key, []).append((ws, dw, dbias))
+        if self.forked is not None:
+            self.held.append(self.items)
         self.items = []
         for (partials, cnt, M, acc, has_bias), g in groups.items():
             n = len(g)

@@ -938,6 +938,8 @@ class _UNetFn(torch.autograd.Function):
                     run.wpark.flush()  # (a block's gradients are final when its tag is reached: the data-parallel hook)
                 ra, rb = run.bank_grad_for_depth(tag, defer=defer_bank)
                 if hook is not None:
+                    if run.wpark is not None:
+                        run.wpark.join()
                     hook(flat, *net.block_param_range(tag))
                     if rb > ra:  # this depth's weight rows of the conditioning bank (the small bias goes out at the end)
                         w0 = offs["bank_weight"][0]
@@ -960,6 +962,8 @@ class _UNetFn(torch.autograd.Function):
         if defer_bank:
             run.bank_grad_all()
         dfeat = run.conditioning_backward()
+        if run.wpark is not None:
+            run.wpark.join()  # (side-stream weight gradients: final before anybody can read the flat buffer)
         if hook is not None:
             for a, b in net.nonblock_param_ranges():
                 hook(flat, a, b)
