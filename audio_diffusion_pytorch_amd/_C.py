@@ -30,7 +30,8 @@ class ConvDesc(Structure):
                                         "res", "out", "out_pre")] + \
                [(n, c_int64) for n in ("B", "R", "R1", "Lin", "M", "N", "KT", "stride", "dil", "pad", "up",
                                        "transposed", "prologue", "groups", "store", "sp", "e_bstride")] + \
-               [("ws", c_void_p), ("gn_part", c_void_p)]
+               [("ws", c_void_p), ("gn_part", c_void_p)] + \
+               [(n, c_void_p) for n in ("gnb_x", "gnb_stats", "gnb_gamma", "gnb_beta", "gnb_ab")] + [("gnb_groups", c_int64)]
 
 
 class WgradDesc(Structure):
@@ -46,6 +47,7 @@ SIGNATURES = {
     "adp_launch_times": (I, [P, I]),
     "adp_conv1d_ws_bytes": (I, [POINTER(ConvDesc)]),
     "adp_conv1d_gn_entries": (I, [POINTER(ConvDesc)]),
+    "adp_conv1d_gnb_entries": (I, [POINTER(ConvDesc)]),
     "adp_conv1d": (c_int, [POINTER(ConvDesc), P]),
     "adp_conv1d_tile": (I, [POINTER(ConvDesc)]),
     "adp_conv1d_wgrad_ws_bytes": (I, [POINTER(WgradDesc)]),
@@ -62,6 +64,7 @@ SIGNATURES = {
     "adp_row_nsplit": (I, [I, I]),
     "adp_gn_silu_bwd_reduce": (c_int, [P, P, P, P, P, I, I, I, I, I, P, P]),
     "adp_gn_silu_bwd_apply": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, I, P]),
+    "adp_gn_silu_bwd_apply_ab": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, I, P]),
     "adp_gn_param_grad": (c_int, [P, I, I, I, P, P, I, P]),
     "adp_modulation_fwd": (c_int, [P, P, I, I, I, I, F, P, P, P]),
     "adp_modulation_ln_fwd": (c_int, [P, P, I, I, I, I, F, P, P, F, P, P, P, P, P, P, P, P]),

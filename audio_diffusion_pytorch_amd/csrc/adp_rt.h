@@ -218,6 +218,10 @@ __device__ __forceinline__ float adp_dsilu(float h) {
   float s = adp_sigmoid(h);
   return s * (1.0f + h * (1.0f - s));
 }
+__device__ __forceinline__ float adp_dsilu_fast(float h) {
+  const float sg = adp_rcp(1.0f + __expf(-h));
+  return sg * fmaf(h, 1.0f - sg, 1.0f);
+}
 // block-wide sum of one value per thread (NW waves); sh needs NW floats; all threads get the result
 template <int NW>
 __device__ __forceinline__ float adp_block_sum(float v, float* sh) {

@@ -836,6 +836,8 @@ bool ks_supported(int64_t KT, int64_t S) {
 
 }  // namespace
 
+extern "C" int64_t adp_conv1d_gnb_entries(const adp_conv_desc* dp);
+
 extern "C" int adp_conv1d(const adp_conv_desc* dp, void* stream) {
   if (!dp) return ADP_ERR_NULL;
   const adp_conv_desc& d = *dp;
@@ -851,6 +853,11 @@ extern "C" int adp_conv1d(const adp_conv_desc* dp, void* stream) {
   if (d.store == 1 && (d.sp < 1 || d.M % d.sp != 0)) return ADP_ERR_SHAPE;
   if (d.store == 2 && ((d.sp != 2 && d.sp != 4) || d.N % d.sp != 0 || d.bias)) return ADP_ERR_UNSUPPORTED;
   if (d.B > 65535 || adp_cdiv(d.M, 32) > 65535) return ADP_ERR_SHAPE;
+  if (d.gnb_ab) {  // (the caller asks adp_conv1d_gnb_entries first; a launch that cannot fill gnb_ab must not pretend to)
+    if (!d.gnb_x || !d.gnb_stats || !d.gnb_gamma || !d.gnb_beta) return ADP_ERR_NULL;
+    if (d.gnb_groups < 1 || d.M % d.gnb_groups != 0) return ADP_ERR_SHAPE;
+    if (adp_conv1d_gnb_entries(dp) <= 0) return ADP_ERR_UNSUPPORTED;
+  }
   if (adp_conv_tile_eligible(d)) return adp_conv_tile(d, stream);
   if (adp_conv_tilek_eligible(d)) return adp_conv_tilek(d, stream);
   if (adp_conv_mm4_eligible(d)) return adp_conv_mm4(d, stream);
@@ -887,6 +894,16 @@ extern "C" int64_t adp_conv1d_gn_entries(const adp_conv_desc* dp) {
   // (the K split only happens when the caller passed its scratch: set d.ws before asking)
   if (adp_conv_mm_eligible(d))  // one slice per 64-position tile, or the K-split reduce kernel's slices
     return d.ws && adp_conv_mm_ksplit(d) > 1 ? adp_conv_splitk_gn_entries(d) : adp_cdiv(d.N, 64);
+  return 0;
+}
+
+extern "C" int64_t adp_conv1d_gnb_entries(const adp_conv_desc* dp) {
+  if (!dp) return ADP_ERR_NULL;
+  const adp_conv_desc& d = *dp;
+  if (d.B <= 0 || d.R <= 0 || d.M <= 0 || d.N <= 0 || d.Lin <= 0) return ADP_ERR_SHAPE;
+  if (d.store != 0) return 0;
+  if (adp_conv_tile_eligible(d) || adp_conv_tilek_eligible(d)) return 0;
+  if (adp_conv_mm4_eligible(d)) return adp_conv_mm4_gnb_entries(d);
   return 0;
 }
 

@@ -31,6 +31,7 @@ int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, fl
 // >= 200 blocks of 32 rows x 128 positions): MMA waves split the six Winograd planes and the chunk's channels
 bool adp_conv_mm4_eligible(const adp_conv_desc& d);
 int adp_conv_mm4(const adp_conv_desc& d, void* stream);
+int64_t adp_conv_mm4_gnb_entries(const adp_conv_desc& d);  // slices per row of gnb_ab (0: K-split launch)
 int64_t adp_conv_mm4_gn_entries(const adp_conv_desc& d);  // two entries (row pairs) per row quad and 128-position tile
 int64_t adp_conv_mm4_ksplit(const adp_conv_desc& d);      // cross-workgroup K split (1 = none)
 

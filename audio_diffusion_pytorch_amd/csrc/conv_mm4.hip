@@ -276,6 +276,17 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
     if (d.res && m < M && nq < N && KS == 1 && d.store == 0) pre_res[rr] = *reinterpret_cast<const f32x4*>(d.res + ((int64_t)b * M + m) * N + nq);
   }
 
+  // (gnb_x, wanted after the K loop, is touched now -- one dword per lane and row, dropped: the rows' lines wait in L2 by then)
+  float gnb_warm = 0.0f;
+  if (d.gnb_ab != nullptr && KS == 1 && d.store == 0 && nq < N) {
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int r = RPW * wave + rr;
+      const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (m < M) gnb_warm += d.gnb_x[((int64_t)b * M + m) * N + nq];
+    }
+  }
+
   const int xfrag = 4 * hi * XSP + 4 * l31 + 4;                         // + (ci + cc) * XSP: the lane's input quad d1..d4
   const int hfrag = 4 * hi * XSP + (pg == 0 ? 3 : 4 + M4_BN);           // tile-edge halo (d0 of quad 0 / d5 of quad 31)
   const int afrag = TR ? 4 * hi * AS + l31 * KT : l31 * AS + 4 * hi * KT;
@@ -377,6 +388,29 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
 #endif
   }
   ADP_KT(60);
+  // first stage of the backward of SiLU(GroupNorm(gnb_x)) whose output gradient this tile is (adp_conv_desc.gnb_ab): the rows'
+  // operands are requested here, AFTER the K loop (no registers held through it), under the plane exchange below
+  const bool gnb = d.gnb_ab != nullptr && KS == 1 && d.store == 0;
+#ifndef ADP_EMULATE
+  asm volatile("" ::"v"(gnb_warm));  // (keeps the touch above alive; the value is not used)
+#endif
+  f32x4 gnb_xq[RPW];
+  float gnb_ga[RPW], gnb_be[RPW], gnb_mean[RPW], gnb_rstd[RPW];
+  if (gnb) {
+    const int cg = M / (int)d.gnb_groups;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int r = RPW * wave + rr;
+      const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int mc = m < M ? m : M - 1;
+      const float* st = d.gnb_stats + ((int64_t)b * d.gnb_groups + mc / cg) * 2;
+      gnb_mean[rr] = st[0], gnb_rstd[rr] = st[1];
+      gnb_ga[rr] = d.gnb_gamma[mc] * gnb_rstd[rr];
+      gnb_be[rr] = d.gnb_beta[mc] - gnb_mean[rr] * gnb_ga[rr];
+      gnb_xq[rr] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (m < M && nq < N) gnb_xq[rr] = *reinterpret_cast<const f32x4*>(d.gnb_x + ((int64_t)b * M + m) * N + nq);
+    }
+  }
   __syncthreads();  // the staging buffers are free
   ADP_KT(61);
 
@@ -489,6 +523,25 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
       e[2] = fcnt;
     }
   }
+  // ---- (sum ds * xhat, sum ds) of each finished row over the tile's 128 positions, ds = da * silu'(gamma * xhat + beta): what
+  // gn_bwd_reduce_vec_kernel (norm.hip) computes from a pass over x and da, taken from the registers that hold da
+  if (gnb && n0 < N) {
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int r = RPW * wave + rr;
+      const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = (gnb_xq[rr][k] - gnb_mean[rr]) * gnb_rstd[rr];
+        const float ds = vfin[rr][k] * adp_dsilu_fast(fmaf(gnb_xq[rr][k], gnb_ga[rr], gnb_be[rr]));  // (vfin = 0 outside the tensor)
+        sa = fmaf(ds, xh, sa);
+        sb += ds;
+      }
+      sa = adp_half_sum(sa), sb = adp_half_sum(sb);  // (five DPP adds each; the half-wave sums stand in lanes 16-31 / 48-63)
+      if (l31 == 16 && m < M) *reinterpret_cast<f32x2*>(d.gnb_ab + (((int64_t)b * M + m) * ntn + nt) * 2) = f32x2{sa, sb};
+    }
+  }
   ADP_KT(63);
   ADP_KT_DUMP(blockIdx.x);
 }
@@ -568,6 +621,15 @@ int64_t adp_conv_mm4_gn_entries(const adp_conv_desc& d) {
   if (d.store != 0) return 0;
   if (m4_ks_eff(d) > 1) return adp_conv_splitk_gn_entries(d);
   return (m4_nkg(d) == 2 ? 1 : 2) * adp_cdiv(d.N, M4_BN);
+}
+
+// slices per row of gnb_ab: one per 128-position tile (unsplit launches).  From 128 rows: the 64-channel layer ([4,64,16384]) is
+// HBM-bound, the epilogue's read of x costs what the separate first stage's did (measured: conv 24.8 -> 34.8 us for 11.3 saved).
+// Per-launch effect at batch 4 (eager event pairs, us): conv +0 .. +4, second stage +0.6 .. +2.3, first stage's 6.7 .. 8.5 gone;
+// 48 launches less per step, step time within +-0.04 ms (a small kernel costs ~3 us inside the replayed graph).
+int64_t adp_conv_mm4_gnb_entries(const adp_conv_desc& d) {
+  if (d.store != 0 || m4_ks_eff(d) > 1 || d.M < 128) return 0;
+  return adp_cdiv(d.N, M4_BN);
 }
 
 int adp_conv_mm4(const adp_conv_desc& d, void* stream) {

@@ -356,17 +356,17 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* x, const
                                                            const float* gamma, const float* beta, const float* ab,
                                                            const float* dres, int64_t C, int64_t L, int64_t G,
                                                            int64_t NS, int64_t CL, float* dx, int64_t B,
-                                                           float* dgamma, float* dbeta, int accumulate) {
+                                                           float* dgamma, float* dbeta, int accumulate, int64_t NSab) {
   __shared__ float sh[4];
   const int64_t row = blockIdx.y, split = blockIdx.x;
   const int64_t b = row / C, c = row % C, Cg = C / G, g = c / Cg;
   if (dgamma && b == 0 && split == 0) {
     // parameter gradients of this channel (what adp_gn_param_grad computes): dgamma = sum_{b,s} A, dbeta = sum B
     float pa = 0.0f, pb = 0.0f;
-    for (int64_t e = threadIdx.x; e < B * NS; e += 256) {
-      const int64_t bb = e / NS, spx = e % NS;
-      pa += ab[((bb * C + c) * NS + spx) * 2];
-      pb += ab[((bb * C + c) * NS + spx) * 2 + 1];
+    for (int64_t e = threadIdx.x; e < B * NSab; e += 256) {
+      const int64_t bb = e / NSab, spx = e % NSab;
+      pa += ab[((bb * C + c) * NSab + spx) * 2];
+      pb += ab[((bb * C + c) * NSab + spx) * 2 + 1];
     }
     pa = adp_block_sum<4>(pa, sh);
     pb = adp_block_sum<4>(pb, sh);
@@ -377,11 +377,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* x, const
   }
   const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
   float sa = 0.0f, sb = 0.0f;
-  for (int64_t e = threadIdx.x; e < Cg * NS; e += 256) {
-    const int64_t cc = g * Cg + e / NS, spx = e % NS;
+  for (int64_t e = threadIdx.x; e < Cg * NSab; e += 256) {
+    const int64_t cc = g * Cg + e / NSab, spx = e % NSab;
     const float gm = gamma[cc];
-    sa = fmaf(gm, ab[((b * C + cc) * NS + spx) * 2], sa);
-    sb = fmaf(gm, ab[((b * C + cc) * NS + spx) * 2 + 1], sb);
+    sa = fmaf(gm, ab[((b * C + cc) * NSab + spx) * 2], sa);
+    sb = fmaf(gm, ab[((b * C + cc) * NSab + spx) * 2 + 1], sb);
   }
   const float inv = 1.0f / ((float)Cg * (float)L);
   const float m2 = adp_block_sum<4>(sa, sh) * inv;
@@ -404,10 +404,6 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* x, const
 // CL % 4 == 0): a segment of the deep layers is 128-256 floats, one float4 per lane of ONE wave (TPR = 32 / 64: no LDS,
 // no workgroup barrier, four segments per workgroup) where the row form spent a 256-thread workgroup with two
 // barrier-synchronised block sums on it; long segments take the whole workgroup (TPR = 256) as before.
-__device__ __forceinline__ float adp_dsilu_fast(float h) {
-  const float sg = adp_rcp(1.0f + __expf(-h));
-  return sg * fmaf(h, 1.0f - sg, 1.0f);
-}
 template <int TPR>
 __device__ __forceinline__ float gn_seg_sum(float v, float* sh) {
   if (TPR == 256) return adp_block_sum<4>(v, sh);
@@ -457,7 +453,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_vec_kernel(const float* __re
                                                                const float* __restrict__ dres, int64_t C, int64_t L, int64_t G,
                                                                int64_t NS, int64_t CL, int64_t nseg, float* __restrict__ dx,
                                                                int64_t B, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta, int accumulate) {
+                                                               float* __restrict__ dbeta, int accumulate, int64_t NSab) {
   __shared__ float sh[4];
   const int sl = threadIdx.x / TPR, li = threadIdx.x % TPR;
   const int64_t seg = (int64_t)blockIdx.x * (256 / TPR) + sl;
@@ -480,20 +476,35 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_vec_kernel(const float* __re
   const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
   const float gam = gamma[c], bet = beta[c];
   float sa = 0.0f, sb = 0.0f;
-  for (int64_t e = li; e < Cg * NS; e += TPR) {
-    const int64_t cc = g * Cg + e / NS, spx = e % NS;
-    const float gm = gamma[cc];
-    const f32x2 p = *reinterpret_cast<const f32x2*>(ab + ((b * C + cc) * NS + spx) * 2);
-    sa = fmaf(gm, p[0], sa);
-    sb = fmaf(gm, p[1], sb);
+  // (NSab: slices per row of the first stage's sums; NS: this launch's own split.  The group's entries are contiguous: rows
+  //  g * Cg .. + Cg - 1 x NSab slices; four independent requests per trip -- the trips are round trips to L2)
+  {
+    const f32x2* gab = reinterpret_cast<const f32x2*>(ab) + (b * C + g * Cg) * NSab;
+    const float* ggm = gamma + g * Cg;
+    const int64_t ne = Cg * NSab;
+    int64_t e = li;
+    for (; e + 3 * TPR < ne; e += 4 * TPR) {
+      f32x2 p[4];
+      float gm[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] = gab[e + u * TPR], gm[u] = ggm[(e + u * TPR) / NSab];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sa = fmaf(gm[u], p[u][0], sa), sb = fmaf(gm[u], p[u][1], sb);
+    }
+    for (; e < ne; e += TPR) {
+      const f32x2 p = gab[e];
+      const float gm = ggm[e / NSab];
+      sa = fmaf(gm, p[0], sa);
+      sb = fmaf(gm, p[1], sb);
+    }
   }
   if (dgamma) {  // parameter gradients of this channel: dgamma = sum_{b,s} A, dbeta = sum_{b,s} B (batch 0's segments)
     const bool mine = (b == 0 && split == 0);
     float pa = 0.0f, pb = 0.0f;
     if (TPR == 256 ? mine : true) {  // (sub-wave segments: every lane walks, only batch 0's keep the result)
-      for (int64_t e = li; e < B * NS; e += TPR) {
-        const int64_t bb = e / NS, spx = e % NS;
-        const f32x2 p = *reinterpret_cast<const f32x2*>(ab + ((bb * C + c) * NS + spx) * 2);
+      for (int64_t e = li; e < B * NSab; e += TPR) {
+        const int64_t bb = e / NSab, spx = e % NSab;
+        const f32x2 p = *reinterpret_cast<const f32x2*>(ab + ((bb * C + c) * NSab + spx) * 2);
         pa += p[0];
         pb += p[1];
       }
@@ -1512,12 +1523,12 @@ extern "C" int adp_gn_silu_bwd_reduce(const float* x, const float* dact, const f
   return ADP_LAUNCH_OK();
 }
 
-extern "C" int adp_gn_silu_bwd_apply(const float* x, const float* dact, const float* stats, const float* gamma,
-                                     const float* beta, const float* ab, const float* dres, int64_t B, int64_t C,
-                                     int64_t L, int64_t G, int64_t NS, float* dx, float* dgamma, float* dbeta,
-                                     int64_t accumulate, void* stream) {
+extern "C" int adp_gn_silu_bwd_apply_ab(const float* x, const float* dact, const float* stats, const float* gamma,
+                                        const float* beta, const float* ab, const float* dres, int64_t B, int64_t C,
+                                        int64_t L, int64_t G, int64_t NS, int64_t NSab, float* dx, float* dgamma,
+                                        float* dbeta, int64_t accumulate, void* stream) {
   if (!x || !dact || !stats || !gamma || !beta || !ab || !dx || (!dgamma != !dbeta)) return ADP_ERR_NULL;
-  if (B <= 0 || C <= 0 || L <= 0 || G <= 0 || C % G || NS < 1 || NS > 65535 || B * C > 65535) return ADP_ERR_SHAPE;
+  if (B <= 0 || C <= 0 || L <= 0 || G <= 0 || C % G || NS < 1 || NS > 65535 || NSab < 1 || B * C > 65535) return ADP_ERR_SHAPE;
   int64_t CL = adp_cdiv(L, NS);
   if ((L & 3) == 0) CL = (CL + 3) & ~(int64_t)3;
   if (gn_bwd_vec_ok(x, dact, dres, dx, L, CL) && (reinterpret_cast<uintptr_t>(ab) & 7) == 0) {
@@ -1526,7 +1537,7 @@ extern "C" int adp_gn_silu_bwd_apply(const float* x, const float* dact, const fl
     const dim3 grid((unsigned)adp_cdiv(nseg, 256 / tpr));
 #define ADP_GN_APP(T)                                                                                                  \
   ADP_LAUNCH((gn_bwd_apply_vec_kernel<T>), grid, dim3(256), stream, x, dact, stats, gamma, beta, ab, dres, C, L, G, NS, \
-             CL, nseg, dx, B, dgamma, dbeta, (int)accumulate)
+             CL, nseg, dx, B, dgamma, dbeta, (int)accumulate, NSab)
     if (tpr == 16) ADP_GN_APP(16);
     else if (tpr == 32) ADP_GN_APP(32);
     else if (tpr == 64) ADP_GN_APP(64);
@@ -1535,8 +1546,16 @@ extern "C" int adp_gn_silu_bwd_apply(const float* x, const float* dact, const fl
     return ADP_LAUNCH_OK();
   }
   ADP_LAUNCH(gn_bwd_apply_kernel, dim3((unsigned)NS, (unsigned)(B * C)), dim3(256), stream, x, dact, stats, gamma,
-             beta, ab, dres, C, L, G, NS, CL, dx, B, dgamma, dbeta, (int)accumulate);
+             beta, ab, dres, C, L, G, NS, CL, dx, B, dgamma, dbeta, (int)accumulate, NSab);
   return ADP_LAUNCH_OK();
+}
+
+extern "C" int adp_gn_silu_bwd_apply(const float* x, const float* dact, const float* stats, const float* gamma,
+                                     const float* beta, const float* ab, const float* dres, int64_t B, int64_t C,
+                                     int64_t L, int64_t G, int64_t NS, float* dx, float* dgamma, float* dbeta,
+                                     int64_t accumulate, void* stream) {
+  return adp_gn_silu_bwd_apply_ab(x, dact, stats, gamma, beta, ab, dres, B, C, L, G, NS, NS, dx, dgamma, dbeta, accumulate,
+                                  stream);
 }
 
 extern "C" int adp_gn_param_grad(const float* ab, int64_t B, int64_t C, int64_t NS, float* dgamma, float* dbeta,

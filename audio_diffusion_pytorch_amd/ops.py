@@ -36,10 +36,13 @@ def conv1d(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int =
            pro_stats: Optional[Tensor] = None, pro_gamma: Optional[Tensor] = None, pro_beta: Optional[Tensor] = None,
            groups: int = 1, e_scale: Optional[Tensor] = None, e_bstride: int = 0, res: Optional[Tensor] = None,
            store: int = 0, sp: int = 1, N: Optional[int] = None, out: Optional[Tensor] = None,
-           out_pre: Optional[Tensor] = None, gn: Optional["GnPart"] = None) -> Tensor:
+           out_pre: Optional[Tensor] = None, gn: Optional["GnPart"] = None, gnb: Optional["GnBwdPart"] = None) -> Tensor:
     """Fused implicit-GEMM conv (adp_conv1d).  w: [M, R, KT] (or [R, M, KT] when transposed).
     `gn`: a GnPart to fill with the GroupNorm partial statistics of the output (left empty when the dispatched kernel
-    family cannot produce them; the consumer then runs adp_gn_stats)."""
+    family cannot produce them; the consumer then runs adp_gn_stats).
+    `gnb`: a GnBwdPart naming the SiLU(GroupNorm(x)) whose output gradient this (data-gradient) launch produces: the epilogue
+    leaves the first stage of that backward in gnb.ab when the dispatched kernel can (else gnb.ab stays None and
+    gn_silu_bwd runs its own pass)."""
     B, R1, Lin = x.shape
     R = R1 + (x2.shape[1] if x2 is not None else 0)
     if transposed:
@@ -72,6 +75,13 @@ def conv1d(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int =
             gn.part = torch.empty((B, M // 4, E, 3), dtype=torch.float32, device=x.device)
             gn.of = out
             d.gn_part = ptr(gn.part)
+    if gnb is not None and GNB_EPILOGUE:
+        d.gnb_groups = gnb.groups  # (the query checks nothing else of the gnb fields)
+        E = _C.query("adp_conv1d_gnb_entries", byref(d))
+        if E > 0:
+            gnb.ab = torch.empty((B, M, E, 2), dtype=torch.float32, device=x.device)
+            d.gnb_x, d.gnb_stats, d.gnb_gamma, d.gnb_beta = ptr(gnb.x), ptr(gnb.stats), ptr(gnb.gamma), ptr(gnb.beta)
+            d.gnb_ab = ptr(gnb.ab)
     if _C.PROFILE is not None:  # algorithmic work of this launch: A_in + A_out (+A_res) + weights
         _C.tag(flops=2 * B * M * N * R * KT,
                bytes=4 * (B * R * Lin + out.numel() + w.numel() + (res.numel() if res is not None else 0)),
@@ -211,6 +221,19 @@ def conv1d_wgrad(x: Tensor, dy: Tensor, KT: int, *, stride: int = 1, dil: int = 
     return dw, dbias
 
 
+GNB_EPILOGUE = os.environ.get("ADP_GNB_EPILOGUE", "1") != "0"  # (A/B switch: 0 = the GroupNorm backward always runs its own first stage)
+
+
+class GnBwdPart:
+    """Names the SiLU(GroupNorm(x)) behind a data-gradient conv (x, its statistics and affine parameters); after the conv,
+    `ab` [B, C, E, 2] holds the first stage of that GroupNorm backward if the conv's epilogue produced it (adp_conv_desc.gnb_ab)."""
+    __slots__ = ("x", "stats", "gamma", "beta", "groups", "ab")
+
+    def __init__(self, x: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor, groups: int):
+        self.x, self.stats, self.gamma, self.beta, self.groups = x, stats, gamma, beta, groups
+        self.ab: Optional[Tensor] = None
+
+
 class GnPart:
     """GroupNorm partial statistics [B, C/4, E, 3] = (mean, M2, count) per slice of a 4-channel row quad, written by
     the kernel that PRODUCED tensor `of` (conv epilogue), so that the consuming GroupNorm needs no pass of its own."""
@@ -278,8 +301,9 @@ def gn_stats_act(x: Tensor, groups: int, gamma: Tensor, beta: Tensor, eps: float
 
 def gn_silu_bwd(x: Tensor, dact: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor, groups: int,
                 dres: Optional[Tensor] = None, dx: Optional[Tensor] = None, dgamma: Optional[Tensor] = None,
-                dbeta: Optional[Tensor] = None, accumulate: bool = False):
-    """Backward of SiLU(GroupNorm(x)): returns (dx [+ dres], dgamma, dbeta)."""
+                dbeta: Optional[Tensor] = None, accumulate: bool = False, ab: Optional[Tensor] = None):
+    """Backward of SiLU(GroupNorm(x)): returns (dx [+ dres], dgamma, dbeta).  `ab` [B, C, E, 2]: the first stage, already
+    left by the epilogue of the conv that produced dact (GnBwdPart.ab): one launch instead of two."""
     B, C, L = x.shape
     if dx is None:
         dx = torch.empty_like(x)
@@ -289,6 +313,11 @@ def gn_silu_bwd(x: Tensor, dact: Tensor, stats: Tensor, gamma: Tensor, beta: Ten
         dbeta = torch.empty_like(beta)
     s = _C.stream()
     NS = _C.query("adp_row_nsplit", B * C, L)
+    if ab is not None:
+        _C.tag(bytes=(12 + (4 if dres is not None else 0)) * x.numel(), shape=f"B{B} C{C} L{L}")
+        _C.call("adp_gn_silu_bwd_apply_ab", ptr(x), ptr(dact), ptr(stats), ptr(gamma), ptr(beta), ptr(ab), ptr(dres), B, C,
+                L, groups, NS, ab.shape[2], ptr(dx), ptr(dgamma), ptr(dbeta), int(accumulate), s)
+        return dx, dgamma, dbeta
     ab = torch.empty((B, C, NS, 2), dtype=torch.float32, device=x.device)
     _C.tag(bytes=8 * x.numel(), shape=f"B{B} C{C} L{L}")
     _C.call("adp_gn_silu_bwd_reduce", ptr(x), ptr(dact), ptr(stats), ptr(gamma), ptr(beta), B, C, L, groups, NS,

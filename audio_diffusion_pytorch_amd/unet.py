@@ -690,13 +690,16 @@ class _Run:
         if self.need_grad:
             def bwd(gy):
                 ops.conv1d_wgrad(a2, gy, 3, pad=1, dw=self.g(p.conv2.weight), dbias=self.g(p.conv2.bias), park=self.wpark)
-                dact2 = ops.conv1d(gy, p.conv2.weight, None, pad=1, transposed=True)
+                # (the data-gradient convs leave the first stage of the GroupNorm backward behind them: ops.GnBwdPart)
+                gb2 = ops.GnBwdPart(h1, st2, p.gn2.weight, p.gn2.bias, G)
+                dact2 = ops.conv1d(gy, p.conv2.weight, None, pad=1, transposed=True, gnb=gb2)
                 dh1, _, _ = ops.gn_silu_bwd(h1, dact2, st2, p.gn2.weight, p.gn2.bias, G, dgamma=self.g(p.gn2.weight),
-                                            dbeta=self.g(p.gn2.bias))
+                                            dbeta=self.g(p.gn2.bias), ab=gb2.ab)
                 ops.conv1d_wgrad(a1, dh1, 3, pad=1, dw=self.g(p.conv1.weight), dbias=self.g(p.conv1.bias), park=self.wpark)
-                dact1 = ops.conv1d(dh1, p.conv1.weight, None, pad=1, transposed=True)
+                gb1 = ops.GnBwdPart(x, st1, p.gn1.weight, p.gn1.bias, G)
+                dact1 = ops.conv1d(dh1, p.conv1.weight, None, pad=1, transposed=True, gnb=gb1)
                 dx, _, _ = ops.gn_silu_bwd(x, dact1, st1, p.gn1.weight, p.gn1.bias, G, dres=gy,
-                                           dgamma=self.g(p.gn1.weight), dbeta=self.g(p.gn1.bias))
+                                           dgamma=self.g(p.gn1.weight), dbeta=self.g(p.gn1.bias), ab=gb1.ab)
                 return dx
             self.tape.append((bwd, None))
         return y

@@ -87,6 +87,17 @@ typedef struct adp_conv_desc {
                               4-channel row quad q of batch element b, E = adp_conv1d_gn_entries(d) (0: this shape /
                               kernel family cannot, pass NULL).  The consumer's GroupNorm then needs no pass of its
                               own over the tensor: adp_gn_finalize. */
+  /* optional (round 6): this launch is the data gradient that feeds the backward of a = SiLU(GroupNorm(gnb_x)) -- its output
+     is da.  The epilogue then also leaves the first stage of that backward (what adp_gn_silu_bwd_reduce computes from a pass
+     over x and da): gnb_ab[((b*M + m)*E + e)*2 + {0,1}] = (sum ds*xhat, sum ds) over the e-th position slice of row m,
+     ds = da * silu'(gamma*xhat + beta), E = adp_conv1d_gnb_entries(d) (0: this launch cannot; leave gnb_ab NULL).
+     The second stage is adp_gn_silu_bwd_apply_ab(..., NSab = E).  components.py:89 (ConvBlock), backward. */
+  const float* gnb_x;      /* [B, M, N], the GroupNorm's input */
+  const float* gnb_stats;  /* [B, gnb_groups, 2] (mean, rstd) */
+  const float* gnb_gamma;  /* [M] */
+  const float* gnb_beta;   /* [M] */
+  float* gnb_ab;
+  int64_t gnb_groups;
 } adp_conv_desc;
 
 /* Scratch the launch wants (0 for most shapes).  With ws == NULL the call still succeeds on the unsplit path. */
@@ -94,6 +105,9 @@ int64_t adp_conv1d_ws_bytes(const adp_conv_desc* d);
 /* Slices per output row the epilogue would report statistics for (see gn_part); 0 = not available for this launch.
    Depends on whether the launch will K-split: fill in d->ws (adp_conv1d_ws_bytes) BEFORE asking. */
 int64_t adp_conv1d_gn_entries(const adp_conv_desc* d);
+/* Position slices per output row of gnb_ab (see there); 0 = the kernel this launch dispatches to has no such epilogue
+   (fill in d->ws first, as above). */
+int64_t adp_conv1d_gnb_entries(const adp_conv_desc* d);
 int adp_conv1d(const adp_conv_desc* d, void* stream);
 /* tile the dispatcher selects for this problem, BM*1000+BN (introspection for profiling / roofline reports) */
 int64_t adp_conv1d_tile(const adp_conv_desc* d);
@@ -184,6 +198,12 @@ int adp_gn_silu_bwd_apply(const float* x, const float* dact, const float* stats,
                           const float* beta, const float* ab, const float* dres, int64_t B, int64_t C, int64_t L,
                           int64_t G, int64_t NS, float* dx, float* dgamma, float* dbeta, int64_t accumulate,
                           void* stream);
+/* adp_gn_silu_bwd_apply with the first stage's sums laid out for NSab slices per row (written by a data-gradient conv's
+   epilogue: adp_conv_desc.gnb_ab) while the launch itself splits its rows NS ways; NSab == NS is the call above. */
+int adp_gn_silu_bwd_apply_ab(const float* x, const float* dact, const float* stats, const float* gamma,
+                             const float* beta, const float* ab, const float* dres, int64_t B, int64_t C, int64_t L,
+                             int64_t G, int64_t NS, int64_t NSab, float* dx, float* dgamma, float* dbeta,
+                             int64_t accumulate, void* stream);
 int adp_gn_param_grad(const float* ab, int64_t B, int64_t C, int64_t NS, float* dgamma, float* dbeta,
                       int64_t accumulate, void* stream);
 

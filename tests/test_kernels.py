@@ -618,6 +618,44 @@ def test_conv_mm4_winograd_f43(dev, B, R, M, L, tr, bkt, monkeypatch):
     assert rel_err(plain, ops.conv1d(xd, wd, None, pad=1, transposed=tr)) < 1e-5
 
 
+@pytest.mark.parametrize("B,C,L", [(2, 128, 256), (1, 160, 132), (2, 192, 1024), (1, 256, 260)])
+@pytest.mark.parametrize("bkt", ["64", "light"])
+def test_conv_mm4_leaves_first_stage_of_groupnorm_backward(dev, B, C, L, bkt, monkeypatch):
+    """The data gradient of a ConvBlock conv is the output gradient of SiLU(GroupNorm(x)) (components.py:89): conv_mm4's epilogue
+    leaves (sum ds * xhat, sum ds) per row and 128-position tile (adp_conv_desc.gnb_ab), adp_gn_silu_bwd_apply_ab finishes from
+    them -- against autograd through the fp64 composite, and against the two-launch GroupNorm backward on the same da."""
+    from ctypes import byref
+    monkeypatch.setenv("ADP_MM4_MIN_BLOCKS", "1")
+    monkeypatch.setenv("ADP_WINO4_MIN_R", "64")
+    monkeypatch.setenv("ADP_MM4_LIGHT_MIN_BLOCKS", "1" if bkt == "light" else "1000000")
+    G = 8
+    x = (rnd(B, C, L, seed=1) * 1.5 + 0.4).double().requires_grad_()
+    gamma = (rnd(C, seed=2) * 0.5 + 1).double().requires_grad_()
+    beta = (rnd(C, seed=3) * 0.2).double().requires_grad_()
+    w = rnd(C, C, 3, seed=4, scale=0.05)  # forward weight [M = C, R = C, 3]
+    gy, dres = rnd(B, C, L, seed=5), rnd(B, C, L, seed=6)
+    y = F.conv1d(ref_gn_silu(x, G, gamma, beta), w.double(), None, padding=1)
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(y, (x, gamma, beta), gy.double())
+    xd, wd, gyd = x.detach().float().to(dev), w.to(dev), gy.to(dev)
+    gd, bd = gamma.detach().float().to(dev), beta.detach().float().to(dev)
+    st = ops.gn_stats(xd, G)
+    d = _C.ConvDesc(_C.ptr(gyd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(gyd), None, B, C, C, L, C, L,
+                    3, 1, 1, 1, 1, 1, 0, 1, 0, 1, 0)
+    assert _C.query("adp_conv1d_tile", byref(d)) == 64032128, "case must dispatch to the F(4,3) block"
+    gb = ops.GnBwdPart(xd, st, gd, bd, G)
+    dact = ops.conv1d(gyd, wd, None, pad=1, transposed=True, gnb=gb)
+    assert gb.ab is not None and tuple(gb.ab.shape) == (B, C, (L + 127) // 128, 2)
+    dx, dg, db = ops.gn_silu_bwd(xd, dact, st, gd, bd, G, dres=dres.to(dev), ab=gb.ab)
+    assert rel_err(dx, dx_ref + dres.double()) < 2e-5 and rel_err(dg, dg_ref) < 2e-5 and rel_err(db, db_ref) < 2e-5
+    dx2, dg2, db2 = ops.gn_silu_bwd(xd, dact, st, gd, bd, G, dres=dres.to(dev))  # the two-launch form on the same da
+    assert rel_err(dx, dx2) < 2e-6 and rel_err(dg, dg2) < 2e-6 and rel_err(db, db2) < 2e-6
+    # a launch that cannot fill gnb_ab says so instead of leaving it unwritten (here: the K-split form)
+    monkeypatch.setenv("ADP_CONV_WINO4", "0")
+    gb0 = ops.GnBwdPart(xd, st, gd, bd, G)
+    ops.conv1d(gyd, wd, None, pad=1, transposed=True, gnb=gb0)
+    assert gb0.ab is None
+
+
 @pytest.mark.parametrize("B,R,M,L,tr,ksmax", [(1, 1024, 32, 128, False, 2), (2, 2048, 32, 132, True, 4), (1, 1024, 64, 8, False, 2)])
 def test_conv_mm4_cross_workgroup_split_k(dev, B, R, M, L, tr, ksmax, monkeypatch):
     """conv_mm4 with fewer tiles than the chip has CUs (depth 8 at batch 4: 128 tiles of 32 x 128): the channel reduction is cut

@@ -240,7 +240,10 @@ def _conv_desc(dev, B=1, R=8, M=8, L=64, KT=3, **over):
              e_scale=None, res=None, out=out.data_ptr(), out_pre=None, B=B, R=R, R1=R, Lin=L, M=M, N=L, KT=KT, stride=1,
              dil=1, pad=1, up=1, transposed=0, prologue=0, groups=1, store=0, sp=1, e_bstride=0, ws=None, gn_part=None)
     f.update(over)
-    d = ConvDesc(*[f[n] for n, _ in ConvDesc._fields_])
+    d = ConvDesc(*[f.get(n) for n, _ in ConvDesc._fields_ if not n.startswith("gnb_")])  # (the trailing gnb_* fields stay zero)
+    for n in f:
+        if n.startswith("gnb_"):
+            setattr(d, n, f[n])
     d._keep = (x, w, out)
     return d
 
@@ -261,6 +264,14 @@ def test_c_abi_returns_error_codes(dev):
     st = torch.zeros(1, 3, 2).to(dev)
     assert lib.adp_conv1d(ctypes.byref(_conv_desc(dev, prologue=1, pro_stats=st.data_ptr(), groups=3)), s) == ERR_SHAPE
     assert lib.adp_conv1d(ctypes.byref(_conv_desc(dev, store=2, sp=3)), s) == ERR_UNSUPPORTED
+    # a launch asked for the GroupNorm-backward sums (gnb_ab) that its kernel family cannot leave refuses instead of not writing
+    ab = torch.empty(64).to(dev)
+    assert lib.adp_conv1d_gnb_entries(ctypes.byref(_conv_desc(dev))) == 0
+    assert lib.adp_conv1d(ctypes.byref(_conv_desc(dev, gnb_ab=ab.data_ptr())), s) == ERR_NULL  # gnb_x / stats / affine missing
+    full = dict(gnb_ab=ab.data_ptr(), gnb_x=ab.data_ptr(), gnb_stats=ab.data_ptr(), gnb_gamma=ab.data_ptr(),
+                gnb_beta=ab.data_ptr())
+    assert lib.adp_conv1d(ctypes.byref(_conv_desc(dev, gnb_groups=3, **full)), s) == ERR_SHAPE
+    assert lib.adp_conv1d(ctypes.byref(_conv_desc(dev, gnb_groups=4, **full)), s) == ERR_UNSUPPORTED
     x = torch.randn(2, 8, 32).to(dev)
     stats = torch.empty(2, 4, 2).to(dev)
     ws = torch.empty(1 << 14).to(dev)
