@@ -6,6 +6,7 @@
 // kernel = stride 2/4, nearest-upsample loader; channels % 32 == 0)
 bool adp_conv_mm_eligible(const adp_conv_desc& d);
 int adp_conv_mm(const adp_conv_desc& d, void* stream);
+int64_t adp_conv_mm_gnb_entries(const adp_conv_desc& d);  // slices per row of gnb_ab (set d.ws before asking)
 int64_t adp_conv_mm_tile(const adp_conv_desc& d);  // NKG * 1000000 + BM * 1000 + BN
 int64_t adp_conv_mm_ksplit(const adp_conv_desc& d);  // cross-workgroup K split the dispatcher picks (1 = none)
 bool adp_conv_mm_winograd(const adp_conv_desc& d);   // this conv runs conv_mm's Winograd F(2,3) variant (WN)
@@ -45,6 +46,7 @@ int64_t adp_conv_tile_gn_entries(const adp_conv_desc& d);  // GroupNorm partial 
 // eight waves of a workgroup split the input channels, 16- or 32-row tiles, no cross-workgroup K split / reduce launch
 bool adp_conv_tilek_eligible(const adp_conv_desc& d);
 int adp_conv_tilek(const adp_conv_desc& d, void* stream);
+int64_t adp_conv_tilek_gnb_entries(const adp_conv_desc& d);  // slices per row of gnb_ab
 int64_t adp_conv_tilek_gn_entries(const adp_conv_desc& d);  // one GroupNorm partial entry per row quad and 64-position tile
 
 // conv_direct.hip: VALU direct convolution for the narrow (2-8 channel) ends of the U-Net

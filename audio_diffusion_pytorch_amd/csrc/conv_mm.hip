@@ -130,9 +130,73 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_gn_kernel(adp_conv_des
   }
 }
 
+// The sum + epilogue for a data gradient that feeds the backward of SiLU(GroupNorm(gnb_x)) (adp_conv_desc.gnb_ab): one WAVE per
+// (row, slice of SPLITK_GN_SLICE positions), 16 bytes per lane and trip; the wave leaves the row's (sum ds * xhat, sum ds) over
+// the slice -- the first stage of that backward, which then needs no pass of its own (N % 4 == 0, 16-byte aligned tensors).
+__global__ __launch_bounds__(256) void conv_splitk_reduce_gnb_kernel(adp_conv_desc d, int KS, int E) {
+  const int64_t M = d.M, N = d.N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t id = (int64_t)blockIdx.x * 4 + wave;  // (b, m, e)
+  if (id >= d.B * M * E) return;
+  const int e = (int)(id % E);
+  id /= E;
+  const int64_t m = id % M, b = id / M;
+  const int64_t n0 = (int64_t)e * SPLITK_GN_SLICE;
+  const int cnt = (int)((N - n0) < SPLITK_GN_SLICE ? (N - n0) : SPLITK_GN_SLICE);
+  const int64_t total = d.B * M * N, row = (b * M + m) * N + n0;
+  const int64_t ebs = d.e_bstride ? d.e_bstride : M;
+  const float bias = d.bias ? d.bias[m] : 0.0f, sc = d.e_scale ? d.e_scale[b * ebs + m] : 1.0f;
+  const float* st = d.gnb_stats + (b * d.gnb_groups + m / (M / d.gnb_groups)) * 2;
+  const float mu = st[0], rs = st[1];
+  const float ga = d.gnb_gamma[m] * rs, be = d.gnb_beta[m] - mu * ga;
+  float sa = 0.0f, sb = 0.0f;
+  for (int p = 4 * lane; p < cnt; p += 256) {
+    const int64_t i = row + p;
+    f32x4 v = *reinterpret_cast<const f32x4*>(d.ws + i);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(d.gnb_x + i);
+    for (int k = 1; k < KS; ++k) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(d.ws + k * total + i);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] += t[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] += bias;
+    if (d.out_pre) *reinterpret_cast<f32x4*>(d.out_pre + i) = v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] *= sc;
+    if (d.res) {
+      const f32x4 r = *reinterpret_cast<const f32x4*>(d.res + i);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] += r[c];
+    }
+    *reinterpret_cast<f32x4*>(d.out + i) = v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float xh = (xv[c] - mu) * rs;
+      const float ds = v[c] * adp_dsilu_fast(fmaf(xv[c], ga, be));
+      sa = fmaf(ds, xh, sa);
+      sb += ds;
+    }
+  }
+  sa = adp_wave_sum(sa), sb = adp_wave_sum(sb);
+  if (lane == 0) *reinterpret_cast<f32x2*>(d.gnb_ab + ((b * M + m) * E + e) * 2) = f32x2{sa, sb};
+}
+
 }  // namespace
 
 int64_t adp_conv_splitk_gn_entries(const adp_conv_desc& d) { return adp_cdiv(d.N, SPLITK_GN_SLICE); }
+
+// slices per row of gnb_ab a conv_mm launch leaves: its 64-position tiles, or the split-K reduce kernel's slices
+int64_t adp_conv_mm_gnb_entries(const adp_conv_desc& d) {
+  if (d.store != 0) return 0;
+  if (d.ws && adp_conv_mm_ksplit(d) > 1) {
+    const bool vec = (d.N & 3) == 0 && ((reinterpret_cast<uintptr_t>(d.ws) | reinterpret_cast<uintptr_t>(d.out) |
+                                         reinterpret_cast<uintptr_t>(d.res) | reinterpret_cast<uintptr_t>(d.out_pre) |
+                                         reinterpret_cast<uintptr_t>(d.gnb_x)) & 15) == 0;
+    return vec ? adp_cdiv(d.N, SPLITK_GN_SLICE) : 0;
+  }
+  return adp_cdiv(d.N, 64);  // (conv_mm_impl.h: MM_BN)
+}
 
 // Cross-workgroup K split: when the output tiles alone leave most of the 256 CUs idle (batch-1 deep layers: depth 8
 // has 64 tiles of 32 x 64) the reduction over input channels is cut into 2 / 4 / 8 slices run by separate
@@ -230,6 +294,11 @@ int64_t adp_conv_mm_tile(const adp_conv_desc& d) {
 }
 
 int adp_conv_splitk_reduce(const adp_conv_desc& d, int64_t ks, void* stream) {
+  if (d.gnb_ab != nullptr) {  // (never together with gn_part: a data gradient feeds no GroupNorm forward)
+    const int64_t E = adp_cdiv(d.N, SPLITK_GN_SLICE);
+    ADP_LAUNCH(conv_splitk_reduce_gnb_kernel, dim3((unsigned)adp_cdiv(d.B * d.M * E, 4)), dim3(256), stream, d, (int)ks, (int)E);
+    return ADP_LAUNCH_OK();
+  }
   if (d.gn_part != nullptr && d.M % 4 == 0) {
     const int64_t E = adp_conv_splitk_gn_entries(d);
     ADP_LAUNCH(conv_splitk_reduce_gn_kernel, dim3((unsigned)(d.B * (d.M / 4) * E)), dim3(256), stream, d, (int)ks, (int)E);

@@ -628,7 +628,8 @@ int64_t adp_conv_mm4_gn_entries(const adp_conv_desc& d) {
 // Per-launch effect at batch 4 (eager event pairs, us): conv +0 .. +4, second stage +0.6 .. +2.3, first stage's 6.7 .. 8.5 gone;
 // 48 launches less per step, step time within +-0.04 ms (a small kernel costs ~3 us inside the replayed graph).
 int64_t adp_conv_mm4_gnb_entries(const adp_conv_desc& d) {
-  if (d.store != 0 || m4_ks_eff(d) > 1 || d.M < 128) return 0;
+  if (d.store != 0 || m4_ks_eff(d) > 1) return 0;
+  if (d.M < 128 && d.B * d.M * d.N > (4 << 20)) return 0;  // (the HBM-bound case above; at batch 1 the tensor is 4 MB and cached)
   return adp_cdiv(d.N, M4_BN);
 }
 

@@ -560,6 +560,36 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD, NSP)
     }
   }
   }
+  // ---- first stage of the backward of SiLU(GroupNorm(gnb_x)) whose output gradient this tile is (adp_conv_desc.gnb_ab; store 0,
+  // no K split): (sum ds * xhat, sum ds) per finished row over the tile's <= 64 positions, one entry per row and 64-position tile
+  if (d.gnb_ab != nullptr && KS == 1 && d.store == 0 && nw0 < N) {
+    const int cg = M / (int)d.gnb_groups;
+    const int n_a = WN ? nw0 + 2 * l31 : nw0 + l31, n_b = WN ? n_a + 1 : n_a + 32;  // positions of vfin[0] / vfin[1]
+    const int E = (N + MM_BN - 1) / MM_BN;
+    float xa[RPW], xb[RPW];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {  // (every row's operands requested before the first is used)
+      const int r = kg * RPW + rr;
+      const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const float* xr = d.gnb_x + ((int64_t)b * M + (m < M ? m : M - 1)) * N;
+      xa[rr] = xr[n_a < N ? n_a : N - 1];
+      xb[rr] = xr[n_b < N ? n_b : N - 1];
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int r = kg * RPW + rr;
+      const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int mc = m < M ? m : M - 1;
+      const float* st = d.gnb_stats + ((int64_t)b * d.gnb_groups + mc / cg) * 2;
+      const float mu = st[0], rs = st[1];
+      const float ga = d.gnb_gamma[mc] * rs, be = d.gnb_beta[mc] - mu * ga;
+      const float xh0 = (xa[rr] - mu) * rs, xh1 = (xb[rr] - mu) * rs;
+      const float ds0 = vfin[0][rr] * adp_dsilu_fast(fmaf(xa[rr], ga, be));  // (vfin = 0 outside the tensor)
+      const float ds1 = vfin[1][rr] * adp_dsilu_fast(fmaf(xb[rr], ga, be));
+      const float sa = adp_half_sum(fmaf(ds0, xh0, ds1 * xh1)), sb = adp_half_sum(ds0 + ds1);  // valid in lanes 16-31 / 48-63
+      if (l31 == 16 && m < M) *reinterpret_cast<f32x2*>(d.gnb_ab + (((int64_t)b * M + m) * E + nt * NSP + nq) * 2) = f32x2{sa, sb};
+    }
+  }
   // ---- GroupNorm partial statistics of the tile just stored (store 0, no K split): one (mean, M2, count) entry per
   // ROW QUAD (the 4 consecutive output channels a lane holds in accumulator registers 4q .. 4q+3) over the tile's
   // <= 64 positions: 8 values per lane, then the 32 lanes of the half-wave; two passes in registers.

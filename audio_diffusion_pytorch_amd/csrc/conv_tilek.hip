@@ -103,9 +103,20 @@ __global__ __launch_bounds__(64 * TK_NKW) void conv_tilek_kernel(adp_conv_desc d
   const int64_t foff = ((int64_t)b * M + fch) * L + n0 + 4 * j;
   f32x4 rv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   float bv = 0.0f;
+  // first stage of the backward of SiLU(GroupNorm(gnb_x)) whose output gradient this launch produces (adp_conv_desc.gnb_ab)
+  const bool GNB = d.gnb_ab != nullptr;  // (workgroup-uniform)
+  f32x4 gx = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  float gmu = 0.0f, grs = 0.0f, gga = 0.0f, gbe = 0.0f;
   if (fin) {
     if (RES) rv = *reinterpret_cast<const f32x4*>(d.res + foff);
     if (d.bias) bv = d.bias[fch];
+    if (GNB) {
+      gx = *reinterpret_cast<const f32x4*>(d.gnb_x + foff);
+      const float* st = d.gnb_stats + ((int64_t)b * d.gnb_groups + fch / (M / (int)d.gnb_groups)) * 2;
+      gmu = st[0], grs = st[1];
+      gga = d.gnb_gamma[fch] * grs;
+      gbe = d.gnb_beta[fch] - gmu * gga;
+    }
   }
 
   f32x4 Macc[RB][6];
@@ -229,6 +240,18 @@ __global__ __launch_bounds__(64 * TK_NKW) void conv_tilek_kernel(adp_conv_desc d
       for (int k = 0; k < 4; ++k) y[k] += rv[k];
     }
     *reinterpret_cast<f32x4*>(d.out + foff) = y;
+    if (GNB) {  // (sum ds * xhat, sum ds) of channel fch over the tile's 64 positions, ds = da * silu'(gamma * xhat + beta)
+      float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = (gx[k] - gmu) * grs;
+        const float ds = y[k] * adp_dsilu_fast(fmaf(gx[k], gga, gbe));
+        sa = fmaf(ds, xh, sa);
+        sb += ds;
+      }
+      sa = adp_row16_sum(sa), sb = adp_row16_sum(sb);
+      if (j == 0) *reinterpret_cast<f32x2*>(d.gnb_ab + (((int64_t)b * M + fch) * ntn + nt) * 2) = f32x2{sa, sb};
+    }
     if (GN) {
       // (mean, M2) of this wave's 64 positions of channel fch, shifted by the row's first value (|mean| >> sigma costs no digits)
       const float gk = __shfl(y[0], lane & 48, 64);
@@ -324,6 +347,7 @@ bool adp_conv_tilek_eligible(const adp_conv_desc& d) {
 }
 
 int64_t adp_conv_tilek_gn_entries(const adp_conv_desc& d) { return d.N / TK_TN; }
+int64_t adp_conv_tilek_gnb_entries(const adp_conv_desc& d) { return d.N / TK_TN; }  // one slice per row and 64-position tile
 
 int adp_conv_tilek(const adp_conv_desc& d, void* stream) {
   if (tilek_rb(d) == 2) return d.transposed ? launch_tilek<true, 2>(d, stream) : launch_tilek<false, 2>(d, stream);

@@ -618,13 +618,25 @@ def test_conv_mm4_winograd_f43(dev, B, R, M, L, tr, bkt, monkeypatch):
     assert rel_err(plain, ops.conv1d(xd, wd, None, pad=1, transposed=tr)) < 1e-5
 
 
-@pytest.mark.parametrize("B,C,L", [(2, 128, 256), (1, 160, 132), (2, 192, 1024), (1, 256, 260)])
-@pytest.mark.parametrize("bkt", ["64", "light"])
+@pytest.mark.parametrize("B,C,L", [(2, 128, 256), (1, 160, 132), (2, 192, 1024), (1, 256, 260), (2, 256, 128), (1, 512, 64)])
+@pytest.mark.parametrize("bkt", ["64", "light", "tilek1", "tilek2", "mm"])
 def test_conv_mm4_leaves_first_stage_of_groupnorm_backward(dev, B, C, L, bkt, monkeypatch):
     """The data gradient of a ConvBlock conv is the output gradient of SiLU(GroupNorm(x)) (components.py:89): conv_mm4's epilogue
-    leaves (sum ds * xhat, sum ds) per row and 128-position tile (adp_conv_desc.gnb_ab), adp_gn_silu_bwd_apply_ab finishes from
-    them -- against autograd through the fp64 composite, and against the two-launch GroupNorm backward on the same da."""
+    leaves (sum ds * xhat, sum ds) per row and 128-position tile (adp_conv_desc.gnb_ab; conv_tilek: per 64-position tile, 16- / 32-row
+    tiles), adp_gn_silu_bwd_apply_ab finishes from them -- against autograd through the fp64 composite, and against the two-launch
+    GroupNorm backward on the same da."""
     from ctypes import byref
+    tilek = bkt.startswith("tilek")
+    if tilek:
+        if C % 256 or L % 64:
+            pytest.skip("conv_tilek takes chunk pairs of 8 K slices and whole 64-position tiles")
+        monkeypatch.setenv("ADP_TILEK_MIN_R", "256")
+        monkeypatch.setenv("ADP_TILEK_MIN_TILES", "1")
+        monkeypatch.setenv("ADP_TILEK_RB", bkt[-1])
+    else:
+        monkeypatch.setenv("ADP_CONV_TILEK", "0")
+    if bkt == "mm":  # conv_mm's F(2,3) blocks; the small cases take its cross-workgroup K split (sums left by the reduce kernel)
+        monkeypatch.setenv("ADP_CONV_WINO4", "0")
     monkeypatch.setenv("ADP_MM4_MIN_BLOCKS", "1")
     monkeypatch.setenv("ADP_WINO4_MIN_R", "64")
     monkeypatch.setenv("ADP_MM4_LIGHT_MIN_BLOCKS", "1" if bkt == "light" else "1000000")
@@ -641,19 +653,22 @@ def test_conv_mm4_leaves_first_stage_of_groupnorm_backward(dev, B, C, L, bkt, mo
     st = ops.gn_stats(xd, G)
     d = _C.ConvDesc(_C.ptr(gyd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(gyd), None, B, C, C, L, C, L,
                     3, 1, 1, 1, 1, 1, 0, 1, 0, 1, 0)
-    assert _C.query("adp_conv1d_tile", byref(d)) == 64032128, "case must dispatch to the F(4,3) block"
+    tile = _C.query("adp_conv1d_tile", byref(d))
+    if bkt == "mm":
+        assert tile not in (48000064, 64032128) and tile >= 40000000, "case must dispatch to conv_mm's Winograd blocks"
+    else:
+        assert tile == (48000064 if tilek else 64032128), "case must dispatch to the named kernel"
     gb = ops.GnBwdPart(xd, st, gd, bd, G)
     dact = ops.conv1d(gyd, wd, None, pad=1, transposed=True, gnb=gb)
-    assert gb.ab is not None and tuple(gb.ab.shape) == (B, C, (L + 127) // 128, 2)
+    split = bkt == "mm" and _C.query("adp_conv1d_ws_bytes", byref(d)) > 0
+    if bkt == "mm" and (B, C, L) in ((2, 256, 128), (1, 512, 64)):
+        assert split, "the small cases are meant to cover the split-K reduce kernel"
+    want_e = (L + 1023) // 1024 if split else ((L + 63) // 64 if (tilek or bkt == "mm") else (L + 127) // 128)
+    assert gb.ab is not None and tuple(gb.ab.shape) == (B, C, want_e, 2)
     dx, dg, db = ops.gn_silu_bwd(xd, dact, st, gd, bd, G, dres=dres.to(dev), ab=gb.ab)
     assert rel_err(dx, dx_ref + dres.double()) < 2e-5 and rel_err(dg, dg_ref) < 2e-5 and rel_err(db, db_ref) < 2e-5
     dx2, dg2, db2 = ops.gn_silu_bwd(xd, dact, st, gd, bd, G, dres=dres.to(dev))  # the two-launch form on the same da
     assert rel_err(dx, dx2) < 2e-6 and rel_err(dg, dg2) < 2e-6 and rel_err(db, db2) < 2e-6
-    # a launch that cannot fill gnb_ab says so instead of leaving it unwritten (here: the K-split form)
-    monkeypatch.setenv("ADP_CONV_WINO4", "0")
-    gb0 = ops.GnBwdPart(xd, st, gd, bd, G)
-    ops.conv1d(gyd, wd, None, pad=1, transposed=True, gnb=gb0)
-    assert gb0.ab is None
 
 
 @pytest.mark.parametrize("B,R,M,L,tr,ksmax", [(1, 1024, 32, 128, False, 2), (2, 2048, 32, 132, True, 4), (1, 1024, 64, 8, False, 2)])
