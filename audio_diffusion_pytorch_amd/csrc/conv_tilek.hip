@@ -25,6 +25,16 @@
 #include "adp.h"
 #include "conv_internal.h"
 
+#ifdef ADP_KTRACE
+static __device__ unsigned long long* tk_kt_buf = nullptr;
+extern "C" int adp_ktrace_set_tilek(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(tk_kt_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define TK_KT_BUF tk_kt_buf
+#else
+#define TK_KT_BUF nullptr
+#endif
+
 namespace {
 
 constexpr int TK_KT = 3;
@@ -49,6 +59,11 @@ __global__ __launch_bounds__(64 * TK_NKW) void conv_tilek_kernel(adp_conv_desc d
   const int wave = adp_uniform(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;         // MFMA 16x16x4: lane = (row / quad column j, K index kq)
   const int M = (int)d.M, R = (int)d.R, L = (int)d.Lin;
+  ADP_KT_DECL(TK_KT_BUF)
+  ADP_KT(0);
+#ifdef ADP_KTRACE
+  int kt_chunk = 0;
+#endif
 
   // ---- XCD-aware decode of the 1-D grid: an XCD gets a contiguous range of row tiles (its L2 keeps their weight slabs)
   int id = blockIdx.x;
@@ -129,6 +144,11 @@ __global__ __launch_bounds__(64 * TK_NKW) void conv_tilek_kernel(adp_conv_desc d
 
   auto run_chunk = [&](ChunkRegs& cr, int next) {
     // ---- park the chunk: x tile (index i of a row <-> position n0 - 1 + i) and the raw weights
+#ifdef ADP_KTRACE
+    if (kt_chunk < 8) ADP_KT(1 + 6 * kt_chunk);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF == 2 ? 9 : 27) : "memory");  // (roughly: this set's loads have landed)
+    if (kt_chunk < 8) ADP_KT(2 + 6 * kt_chunk);
+#endif
     {
       float* o = X + (lane >> 4) * TK_RS + 4 * (lane & 15) + 1;
 #pragma unroll
@@ -156,10 +176,16 @@ __global__ __launch_bounds__(64 * TK_NKW) void conv_tilek_kernel(adp_conv_desc d
         uf[rb][ks][5] = g2;
       }
     adp_wave_sync();
+#ifdef ADP_KTRACE
+    if (kt_chunk < 8) ADP_KT(3 + 6 * kt_chunk);
+#endif
     // this set's next chunk, in flight under two chunks of MFMAs.  UNCONDITIONAL (past the end the last chunk is fetched again
     // and never used): a branch around the loads makes the compiler merge the two paths with register copies behind an
     // s_waitcnt vmcnt(0) -- every iteration then waits for the loads it has just requested
     load_chunk(cr, next < nchunks ? next : nchunks - 1);
+#ifdef ADP_KTRACE
+    if (kt_chunk < 8) ADP_KT(4 + 6 * kt_chunk);
+#endif
     // ---- four K steps: lane (j, kq) reads the six inputs around its quad and its rows' six planes of channel 4 ks + kq
     f32x2 dn[3];
     auto frags = [&](int ks) {
@@ -191,7 +217,14 @@ __global__ __launch_bounds__(64 * TK_NKW) void conv_tilek_kernel(adp_conv_desc d
         for (int rb = 0; rb < RB; ++rb) Macc[rb][p] = adp_mfma16(uf[rb][ks][p], v[p], Macc[rb][p]);
       adp_sched_fence();
     }
+#ifdef ADP_KTRACE
+    if (kt_chunk < 8) ADP_KT(5 + 6 * kt_chunk);
+#endif
     adp_wave_sync();  // the next chunk overwrites this wave's tiles
+#ifdef ADP_KTRACE
+    if (kt_chunk < 8) ADP_KT(6 + 6 * kt_chunk);
+    ++kt_chunk;
+#endif
   };
   // PF register sets = chunks in flight per wave (29 registers a set with 16-row tiles, 41 with 32-row tiles)
   ChunkRegs cs[PF];
@@ -209,6 +242,7 @@ __global__ __launch_bounds__(64 * TK_NKW) void conv_tilek_kernel(adp_conv_desc d
     }
   }
 
+  ADP_KT(60);
   // ---- y = A^T m per output row (A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]); the wave's partial tile goes
   // to the head of its own region: [rb][r][lane] float4
 #pragma unroll
@@ -222,6 +256,7 @@ __global__ __launch_bounds__(64 * TK_NKW) void conv_tilek_kernel(adp_conv_desc d
           f32x4{m0v + s12 + s34, fmaf(2.0f, d34, d12), fmaf(4.0f, s34, s12), fmaf(8.0f, d34, d12) + m5};
     }
   __syncthreads();
+  ADP_KT(61);
   float gmean = 0.0f, gm2 = 0.0f;
   if (fin) {
     // accumulator register r of row block rb <-> output channel 16 rb + 4 kq + r, column j = output quad: this wave sums row
@@ -290,6 +325,8 @@ __global__ __launch_bounds__(64 * TK_NKW) void conv_tilek_kernel(adp_conv_desc d
       e[2] = n;
     }
   }
+  ADP_KT(63);
+  ADP_KT_DUMP(blockIdx.x);
 }
 
 static int64_t tilek_tiles32(const adp_conv_desc& d) { return (d.M / 32) * d.B * (d.N / TK_TN); }
