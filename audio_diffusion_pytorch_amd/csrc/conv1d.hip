@@ -902,7 +902,7 @@ extern "C" int64_t adp_conv1d_gnb_entries(const adp_conv_desc* dp) {
   const adp_conv_desc& d = *dp;
   if (d.B <= 0 || d.R <= 0 || d.M <= 0 || d.N <= 0 || d.Lin <= 0) return ADP_ERR_SHAPE;
   if (d.store != 0) return 0;
-  if (adp_conv_tile_eligible(d)) return 0;
+  if (adp_conv_tile_eligible(d)) return adp_conv_tile_gnb_entries(d);
   if (adp_conv_tilek_eligible(d)) return adp_conv_tilek_gnb_entries(d);
   if (adp_conv_mm4_eligible(d)) return adp_conv_mm4_gnb_entries(d);
   if (adp_conv_mm_eligible(d)) return d.gn_part ? 0 : adp_conv_mm_gnb_entries(d);

@@ -40,6 +40,7 @@ int64_t adp_conv_mm4_ksplit(const adp_conv_desc& d);      // cross-workgroup K s
 // kernel-3 ConvBlock convs and their data gradients (depth 1)
 bool adp_conv_tile_eligible(const adp_conv_desc& d);
 int adp_conv_tile(const adp_conv_desc& d, void* stream);
+int64_t adp_conv_tile_gnb_entries(const adp_conv_desc& d);  // slices per row of gnb_ab (0: not a plain data gradient)
 int64_t adp_conv_tile_gn_entries(const adp_conv_desc& d);  // GroupNorm partial slices per output row quad (gn_part)
 
 // conv_tilek.hip: the same wave tile for the deep layers whose tiles alone cannot fill the chip (>= 512 channels, <= 320 tiles):

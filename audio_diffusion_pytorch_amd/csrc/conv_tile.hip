@@ -59,7 +59,9 @@ __device__ __forceinline__ f32x2 wt_silu2(f32x2 h) {
 
 constexpr int WT_US = WT_C * 2 * 16 * 6;  // floats of the transformed weights U[c][rb][m16][6]
 
-template <bool TR, int PRO, int NW, bool RES, bool GN>
+// GNB: this launch is a data gradient whose output feeds the backward of SiLU(GroupNorm(gnb_x)); the epilogue also leaves that
+//      backward's first stage (adp_conv_desc.gnb_ab): per channel and workgroup (NW tiles = 64 NW positions)
+template <bool TR, int PRO, int NW, bool RES, bool GN, bool GNB = false>
 __global__ __launch_bounds__(64 * NW) void conv_tile32_kernel(adp_conv_desc d, int tiles_per_b, int cfg) {
   // One LDS block, U first: its fragment reads (and the tile's) then take their K-step offsets as 16-bit immediates.
   //   U[c][rb][m][6] | (pa, pb) per input channel | statistics scratch [NW][8][2] | NW wave tiles [32][66]
@@ -264,6 +266,14 @@ __global__ __launch_bounds__(64 * NW) void conv_tile32_kernel(adp_conv_desc d, i
       for (int r = 0; r < 4; ++r) rv[r] = *reinterpret_cast<const f32x4*>(rt + (ob + (unsigned)(16 * rb + r) * Lb));
     }
     if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + 16 * rb + 4 * kq);
+    f32x4 gxq[4], gga = bv, gbe = bv;
+    if (GNB) {
+      const char* gxt = reinterpret_cast<const char*>(d.gnb_x + tbase);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gxq[r] = *reinterpret_cast<const f32x4*>(gxt + (ob + (unsigned)(16 * rb + r) * Lb));
+      gga = *reinterpret_cast<const f32x4*>(d.gnb_gamma + 16 * rb + 4 * kq);
+      gbe = *reinterpret_cast<const f32x4*>(d.gnb_beta + 16 * rb + 4 * kq);
+    }
     float gk = 0.0f;
     f32x2 gs = f32x2{0.0f, 0.0f}, gq = f32x2{0.0f, 0.0f};
 #pragma unroll
@@ -278,6 +288,23 @@ __global__ __launch_bounds__(64 * NW) void conv_tile32_kernel(adp_conv_desc d, i
       }
       if (!(elim & 2))
         *reinterpret_cast<f32x4*>(ot + (ob + (unsigned)(16 * rb + r) * Lb)) = f32x4{ya[0], ya[1], yb[0], yb[1]};
+      if (GNB) {  // (sum ds * xhat, sum ds) of channel 16 rb + 4 kq + r over the wave's 64 positions -> the wave's (dead) tile region
+        const int c = 16 * rb + 4 * kq + r;
+        const float* st = d.gnb_stats + ((int64_t)b * d.gnb_groups + c / (WT_C / (int)d.gnb_groups)) * 2;
+        const float mu = st[0], rs = st[1];
+        const float ga = gga[r] * rs, be = gbe[r] - mu * ga;
+        const float yv[4] = {ya[0], ya[1], yb[0], yb[1]};
+        float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xh = (gxq[r][k] - mu) * rs;
+          const float ds = yv[k] * adp_dsilu_fast(fmaf(gxq[r][k], ga, be));
+          sa = fmaf(ds, xh, sa);
+          sb += ds;
+        }
+        sa = adp_row16_sum(sa), sb = adp_row16_sum(sb);
+        if (j == 0) *reinterpret_cast<f32x2*>(xs + wave * WT_XT + 2 * c) = f32x2{sa, sb};
+      }
       if (want_gn) {
         if (r == 0) gk = __shfl(ya[0], lane & 48, 64);  // shift of this row quad: its first value, lane j = 0 of the kq row
         const f32x2 ea = ya - gk, eb = yb - gk;
@@ -298,6 +325,18 @@ __global__ __launch_bounds__(64 * NW) void conv_tile32_kernel(adp_conv_desc d, i
     }
   }
   WT_STAMP(5);
+  if (GNB) {  // the workgroup's NW waves in wave order -> one entry per channel and workgroup
+    __syncthreads();
+    if (tid < WT_C) {
+      float sa = 0.0f, sb = 0.0f;
+      for (int w = 0; w < NW; ++w) {
+        const f32x2 p = *reinterpret_cast<const f32x2*>(xs + w * WT_XT + 2 * tid);
+        sa += p[0], sb += p[1];
+      }
+      const int E = tiles_per_b / NW;
+      *reinterpret_cast<f32x2*>(d.gnb_ab + (((int64_t)b * WT_C + tid) * E + ((int)blockIdx.x - b * E)) * 2) = f32x2{sa, sb};
+    }
+  }
   if (want_gn) {
     // Chan-combined over the workgroup's NW waves -> one gn_part entry per row quad
     constexpr float cnt = 4.0f * WT_TN;
@@ -345,6 +384,24 @@ int launch_tile(const adp_conv_desc& d, void* stream) {
   return ADP_LAUNCH_OK();
 }
 
+static bool tile_gnb_ok(const adp_conv_desc& d) {
+  return d.transposed && d.prologue == 0 && !d.res && !d.gn_part && !d.bias && WT_C % (d.gnb_groups > 0 ? d.gnb_groups : 1) == 0 &&
+         ((reinterpret_cast<uintptr_t>(d.gnb_x) | reinterpret_cast<uintptr_t>(d.gnb_gamma) | reinterpret_cast<uintptr_t>(d.gnb_beta)) & 15) == 0;
+}
+
+int launch_tile_gnb(const adp_conv_desc& d, void* stream) {
+  const int tiles_per_b = (int)(d.N / WT_TN);
+  const int nw = tile_nw(d);
+  const unsigned grid = (unsigned)(d.B * tiles_per_b / nw);
+  const int cfg = 120;
+  switch (nw) {
+    case 16: ADP_LAUNCH((conv_tile32_kernel<true, 0, 16, false, false, true>), dim3(grid), dim3(1024), stream, d, tiles_per_b, cfg); break;
+    case 4: ADP_LAUNCH((conv_tile32_kernel<true, 0, 4, false, false, true>), dim3(grid), dim3(256), stream, d, tiles_per_b, cfg); break;
+    default: ADP_LAUNCH((conv_tile32_kernel<true, 0, 1, false, false, true>), dim3(grid), dim3(64), stream, d, tiles_per_b, cfg); break;
+  }
+  return ADP_LAUNCH_OK();
+}
+
 template <bool TR, int PRO>
 int launch_tile2(const adp_conv_desc& d, void* stream) {
   if (d.res) return d.gn_part ? launch_tile<TR, PRO, true, true>(d, stream) : launch_tile<TR, PRO, true, false>(d, stream);
@@ -369,8 +426,11 @@ bool adp_conv_tile_eligible(const adp_conv_desc& d) {
 }
 
 int64_t adp_conv_tile_gn_entries(const adp_conv_desc& d) { return d.N / WT_TN / tile_nw(d); }
+// slices per row of gnb_ab: one per workgroup (plain data gradients only; gnb_x / gamma / beta 16-byte aligned)
+int64_t adp_conv_tile_gnb_entries(const adp_conv_desc& d) { return tile_gnb_ok(d) ? d.N / WT_TN / tile_nw(d) : 0; }
 
 int adp_conv_tile(const adp_conv_desc& d, void* stream) {
+  if (d.gnb_ab) return launch_tile_gnb(d, stream);  // (adp_conv1d has checked adp_conv_tile_gnb_entries)
   if (d.transposed) return d.prologue == 1 ? launch_tile2<true, 1>(d, stream) : launch_tile2<true, 0>(d, stream);
   return d.prologue == 1 ? launch_tile2<false, 1>(d, stream) : launch_tile2<false, 0>(d, stream);
 }

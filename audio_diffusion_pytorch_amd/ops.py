@@ -76,11 +76,11 @@ def conv1d(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int =
             gn.of = out
             d.gn_part = ptr(gn.part)
     if gnb is not None and GNB_EPILOGUE:
-        d.gnb_groups = gnb.groups  # (the query checks nothing else of the gnb fields)
-        E = _C.query("adp_conv1d_gnb_entries", byref(d))
+        d.gnb_groups = gnb.groups
+        d.gnb_x, d.gnb_stats, d.gnb_gamma, d.gnb_beta = ptr(gnb.x), ptr(gnb.stats), ptr(gnb.gamma), ptr(gnb.beta)
+        E = _C.query("adp_conv1d_gnb_entries", byref(d))  # (some kernels look at the operands' alignment)
         if E > 0:
             gnb.ab = torch.empty((B, M, E, 2), dtype=torch.float32, device=x.device)
-            d.gnb_x, d.gnb_stats, d.gnb_gamma, d.gnb_beta = ptr(gnb.x), ptr(gnb.stats), ptr(gnb.gamma), ptr(gnb.beta)
             d.gnb_ab = ptr(gnb.ab)
     if _C.PROFILE is not None:  # algorithmic work of this launch: A_in + A_out (+A_res) + weights
         _C.tag(flops=2 * B * M * N * R * KT,

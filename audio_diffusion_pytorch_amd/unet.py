@@ -664,14 +664,16 @@ class _Run:
             def bwd(gy):
                 ops.conv1d_wgrad(h1, gy, 3, pad=1, park=self.wpark, prologue=1, pro_stats=st2, pro_gamma=p.gn2.weight,
                                  pro_beta=p.gn2.bias, groups=G, dw=self.g(p.conv2.weight), dbias=self.g(p.conv2.bias))
-                dact2 = ops.conv1d(gy, p.conv2.weight, None, pad=1, transposed=True)
+                gb2 = ops.GnBwdPart(h1, st2, p.gn2.weight, p.gn2.bias, G)
+                dact2 = ops.conv1d(gy, p.conv2.weight, None, pad=1, transposed=True, gnb=gb2)
                 dh1, _, _ = ops.gn_silu_bwd(h1, dact2, st2, p.gn2.weight, p.gn2.bias, G, dgamma=self.g(p.gn2.weight),
-                                            dbeta=self.g(p.gn2.bias))
+                                            dbeta=self.g(p.gn2.bias), ab=gb2.ab)
                 ops.conv1d_wgrad(x, dh1, 3, pad=1, park=self.wpark, prologue=1, pro_stats=st1, pro_gamma=p.gn1.weight,
                                  pro_beta=p.gn1.bias, groups=G, dw=self.g(p.conv1.weight), dbias=self.g(p.conv1.bias))
-                dact1 = ops.conv1d(dh1, p.conv1.weight, None, pad=1, transposed=True)
+                gb1 = ops.GnBwdPart(x, st1, p.gn1.weight, p.gn1.bias, G)
+                dact1 = ops.conv1d(dh1, p.conv1.weight, None, pad=1, transposed=True, gnb=gb1)
                 dx, _, _ = ops.gn_silu_bwd(x, dact1, st1, p.gn1.weight, p.gn1.bias, G, dres=gy,
-                                           dgamma=self.g(p.gn1.weight), dbeta=self.g(p.gn1.bias))
+                                           dgamma=self.g(p.gn1.weight), dbeta=self.g(p.gn1.bias), ab=gb1.ab)
                 return dx
             self.tape.append((bwd, None))
         return y

@@ -671,6 +671,36 @@ def test_conv_mm4_leaves_first_stage_of_groupnorm_backward(dev, B, C, L, bkt, mo
     assert rel_err(dx, dx2) < 2e-6 and rel_err(dg, dg2) < 2e-6 and rel_err(db, db2) < 2e-6
 
 
+@pytest.mark.parametrize("B,L,nw", [(2, 256, 1), (1, 1024, 4), (2, 2048, 16)])
+def test_conv_tile32_leaves_first_stage_of_groupnorm_backward(dev, B, L, nw, monkeypatch):
+    """The same contract for the 32-channel wave-tile kernel of depth 1 (conv_tile.hip): one entry per channel and workgroup
+    (1 / 4 / 16 waves = 64 / 256 / 1024 positions), summed over the workgroup's waves in wave order."""
+    from ctypes import byref
+    monkeypatch.setenv("ADP_TILE_NW", str(nw))
+    C, G = 32, 8
+    x = (rnd(B, C, L, seed=1) * 1.5 + 0.4).double().requires_grad_()
+    gamma = (rnd(C, seed=2) * 0.5 + 1).double().requires_grad_()
+    beta = (rnd(C, seed=3) * 0.2).double().requires_grad_()
+    w = rnd(C, C, 3, seed=4, scale=0.1)
+    gy, dres = rnd(B, C, L, seed=5), rnd(B, C, L, seed=6)
+    y = F.conv1d(ref_gn_silu(x, G, gamma, beta), w.double(), None, padding=1)
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(y, (x, gamma, beta), gy.double())
+    xd, wd, gyd = x.detach().float().to(dev), w.to(dev), gy.to(dev)
+    gd, bd = gamma.detach().float().to(dev), beta.detach().float().to(dev)
+    st = ops.gn_stats(xd, G)
+    d = _C.ConvDesc(_C.ptr(gyd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(gyd), None, B, C, C, L, C, L,
+                    3, 1, 1, 1, 1, 1, 0, 1, 0, 1, 0)
+    assert _C.query("adp_conv1d_tile", byref(d)) == 32064, "case must dispatch to the 32-channel wave-tile kernel"
+    gb = ops.GnBwdPart(xd, st, gd, bd, G)
+    dact = ops.conv1d(gyd, wd, None, pad=1, transposed=True, gnb=gb)
+    assert gb.ab is not None and tuple(gb.ab.shape) == (B, C, L // 64 // nw, 2)
+    assert rel_err(dact, F.conv_transpose1d(gy.double(), w.double(), None, padding=1)) < 1e-5
+    dx, dg, db = ops.gn_silu_bwd(xd, dact, st, gd, bd, G, dres=dres.to(dev), ab=gb.ab)
+    assert rel_err(dx, dx_ref + dres.double()) < 2e-5 and rel_err(dg, dg_ref) < 2e-5 and rel_err(db, db_ref) < 2e-5
+    dx2, dg2, db2 = ops.gn_silu_bwd(xd, dact, st, gd, bd, G, dres=dres.to(dev))
+    assert rel_err(dx, dx2) < 2e-6 and rel_err(dg, dg2) < 2e-6 and rel_err(db, db2) < 2e-6
+
+
 @pytest.mark.parametrize("B,R,M,L,tr,ksmax", [(1, 1024, 32, 128, False, 2), (2, 2048, 32, 132, True, 4), (1, 1024, 64, 8, False, 2)])
 def test_conv_mm4_cross_workgroup_split_k(dev, B, R, M, L, tr, ksmax, monkeypatch):
     """conv_mm4 with fewer tiles than the chip has CUs (depth 8 at batch 4: 128 tiles of 32 x 128): the channel reduction is cut
