@@ -88,7 +88,8 @@ def conv1d(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, stride: int =
                shape=f"B{B} R{R} M{M} N{N} KT{KT} s{stride} up{up} tr{int(transposed)} pro{prologue}")
     _C.call("adp_conv1d", byref(d), _C.stream())
     if _C.REPLAY is not None:
-        keep = (x, x2, w, bias, pro_stats, pro_gamma, pro_beta, e_scale, res, out, out_pre, gn.part if gn is not None else None)
+        keep = (x, x2, w, bias, pro_stats, pro_gamma, pro_beta, e_scale, res, out, out_pre, gn.part if gn is not None else None,
+                (gnb.x, gnb.stats, gnb.gamma, gnb.beta, gnb.ab) if gnb is not None else None, ws if need > 0 else None)
         _C.REPLAY.append((f"B{B} R{R} M{M} N{N} KT{KT} s{stride} up{up} tr{int(transposed)} pro{prologue}",
                           4 * (B * R * Lin + out.numel() + w.numel() + (res.numel() if res is not None else 0)),
                           lambda d=d, keep=keep: _C.call("adp_conv1d", byref(d), _C.stream())))
