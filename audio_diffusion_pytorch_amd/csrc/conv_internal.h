@@ -1,5 +1,6 @@
 // Private to libadp_hip.so: kernel families behind adp_conv1d / adp_conv1d_wgrad (not part of the C-ABI).
 #pragma once
+#include <stdlib.h>
 #include "adp.h"
 
 // conv_mm.hip (+ conv_mm_impl.h, conv_mm_m64/m32.hip): wave-specialised implicit-GEMM conv (stride 1 kernel 1/3,
@@ -32,6 +33,12 @@ int adp_wgrad_reduce(const float* ws, int64_t nsplit, int64_t cnt, int64_t M, fl
 // >= 200 blocks of 32 rows x 128 positions): MMA waves split the six Winograd planes and the chunk's channels
 bool adp_conv_mm4_eligible(const adp_conv_desc& d);
 int adp_conv_mm4(const adp_conv_desc& d, void* stream);
+// ADP_GNB_FAMILIES (A/B, bit mask; default all): which kernel families leave the GroupNorm-backward sums -- 1 conv_mm4 12-wave block,
+// 2 conv_mm4 light block, 4 conv_tilek, 8 conv_mm, 16 conv_tile32, 32 split-K reduce
+inline bool adp_gnb_family_on(int bit) {
+  const char* e = getenv("ADP_GNB_FAMILIES");
+  return e == nullptr || (atoi(e) & bit) != 0;
+}
 int64_t adp_conv_mm4_gnb_entries(const adp_conv_desc& d);  // slices per row of gnb_ab (0: K-split launch)
 int64_t adp_conv_mm4_gn_entries(const adp_conv_desc& d);  // two entries (row pairs) per row quad and 128-position tile
 int64_t adp_conv_mm4_ksplit(const adp_conv_desc& d);      // cross-workgroup K split (1 = none)

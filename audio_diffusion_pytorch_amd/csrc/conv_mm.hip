@@ -188,7 +188,9 @@ int64_t adp_conv_splitk_gn_entries(const adp_conv_desc& d) { return adp_cdiv(d.N
 
 // slices per row of gnb_ab a conv_mm launch leaves: its 64-position tiles, or the split-K reduce kernel's slices
 int64_t adp_conv_mm_gnb_entries(const adp_conv_desc& d) {
-  if (d.store != 0) return 0;
+  // (the instantiations that exist: plain Winograd data gradients)
+  if (d.store != 0 || !d.transposed || d.KT != 3 || d.prologue != 0 || d.up != 1 || d.stride != 1 || !adp_conv_mm_winograd(d)) return 0;
+  if (!adp_gnb_family_on(d.ws && adp_conv_mm_ksplit(d) > 1 ? 32 : 8)) return 0;
   if (d.ws && adp_conv_mm_ksplit(d) > 1) {
     const bool vec = (d.N & 3) == 0 && ((reinterpret_cast<uintptr_t>(d.ws) | reinterpret_cast<uintptr_t>(d.out) |
                                          reinterpret_cast<uintptr_t>(d.res) | reinterpret_cast<uintptr_t>(d.out_pre) |

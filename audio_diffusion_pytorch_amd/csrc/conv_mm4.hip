@@ -62,7 +62,9 @@ __device__ __forceinline__ f32x4 m4_load_xquad(const float* p) {
 //      under the other's MFMAs (a 4-chunk K loop is all ramp and drain otherwise)
 // UP: nearest-upsample factor folded into the X loader (the UpsampleItem convs); store mode 2 (runtime: the pooled store of
 //     their data gradients -- sums of sp = 2 / 4 adjacent outputs of the lane's quad, 8- / 4-byte stores, + residual)
-template <bool TR, int PD, int BKT, int M4_NKG, int UP = 1>
+// GNB: the launch also leaves the first stage of a GroupNorm backward (adp_conv_desc.gnb_ab) -- its own instantiations (plain
+//      transposed launches), so that every other launch keeps the registers and instruction stream it had without it
+template <bool TR, int PD, int BKT, int M4_NKG, int UP = 1, bool GNB = false>
 // (second launch bound = waves per SIMD the register allocation has to leave room for: the light 8-wave block lives on TWO
 //  blocks per CU = 4 waves per SIMD = at most 128 registers; the 12-wave block on one = 3 per SIMD)
 __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BKT == 32) ? 4 : 1) void conv_mm4_kernel(adp_conv_desc d) {
@@ -278,7 +280,7 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
 
   // (gnb_x, wanted after the K loop, is touched now -- one dword per lane and row, dropped: the rows' lines wait in L2 by then)
   float gnb_warm = 0.0f;
-  if (d.gnb_ab != nullptr && KS == 1 && d.store == 0 && nq < N) {
+  if (GNB && KS == 1 && d.store == 0 && nq < N) {
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int r = RPW * wave + rr;
@@ -390,23 +392,17 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
   ADP_KT(60);
   // first stage of the backward of SiLU(GroupNorm(gnb_x)) whose output gradient this tile is (adp_conv_desc.gnb_ab): the rows'
   // operands are requested here, AFTER the K loop (no registers held through it), under the plane exchange below
-  const bool gnb = d.gnb_ab != nullptr && KS == 1 && d.store == 0;
+  const bool gnb = GNB && KS == 1 && d.store == 0;
 #ifndef ADP_EMULATE
-  asm volatile("" ::"v"(gnb_warm));  // (keeps the touch above alive; the value is not used)
+  if (GNB) asm volatile("" ::"v"(gnb_warm));  // (keeps the touch above alive; the value is not used)
 #endif
   f32x4 gnb_xq[RPW];
-  float gnb_ga[RPW], gnb_be[RPW], gnb_mean[RPW], gnb_rstd[RPW];
-  if (gnb) {
-    const int cg = M / (int)d.gnb_groups;
+  if (gnb) {  // (the x quads only: the rows' statistics / affine parameters are fetched where they are used, after the stores --
+              //  the light block lives on 128 registers)
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int r = RPW * wave + rr;
       const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const int mc = m < M ? m : M - 1;
-      const float* st = d.gnb_stats + ((int64_t)b * d.gnb_groups + mc / cg) * 2;
-      gnb_mean[rr] = st[0], gnb_rstd[rr] = st[1];
-      gnb_ga[rr] = d.gnb_gamma[mc] * gnb_rstd[rr];
-      gnb_be[rr] = d.gnb_beta[mc] - gnb_mean[rr] * gnb_ga[rr];
       gnb_xq[rr] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       if (m < M && nq < N) gnb_xq[rr] = *reinterpret_cast<const f32x4*>(d.gnb_x + ((int64_t)b * M + m) * N + nq);
     }
@@ -526,15 +522,27 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
   // ---- (sum ds * xhat, sum ds) of each finished row over the tile's 128 positions, ds = da * silu'(gamma * xhat + beta): what
   // gn_bwd_reduce_vec_kernel (norm.hip) computes from a pass over x and da, taken from the registers that hold da
   if (gnb && n0 < N) {
+    const int cg = M / (int)d.gnb_groups;
+    float gnb_mean[RPW], gnb_rstd[RPW], gnb_gm[RPW], gnb_bt[RPW];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {  // (all requested before the first use)
+      const int r = RPW * wave + rr;
+      const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int mc = m < M ? m : M - 1;
+      const float* st = d.gnb_stats + ((int64_t)b * d.gnb_groups + mc / cg) * 2;
+      gnb_mean[rr] = st[0], gnb_rstd[rr] = st[1];
+      gnb_gm[rr] = d.gnb_gamma[mc], gnb_bt[rr] = d.gnb_beta[mc];
+    }
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int r = RPW * wave + rr;
       const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const float ga = gnb_gm[rr] * gnb_rstd[rr], be = gnb_bt[rr] - gnb_mean[rr] * ga;
       float sa = 0.0f, sb = 0.0f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float xh = (gnb_xq[rr][k] - gnb_mean[rr]) * gnb_rstd[rr];
-        const float ds = vfin[rr][k] * adp_dsilu_fast(fmaf(gnb_xq[rr][k], gnb_ga[rr], gnb_be[rr]));  // (vfin = 0 outside the tensor)
+        const float ds = vfin[rr][k] * adp_dsilu_fast(fmaf(gnb_xq[rr][k], ga, be));  // (vfin = 0 outside the tensor)
         sa = fmaf(ds, xh, sa);
         sb += ds;
       }
@@ -628,8 +636,9 @@ int64_t adp_conv_mm4_gn_entries(const adp_conv_desc& d) {
 // Per-launch effect at batch 4 (eager event pairs, us): conv +0 .. +4, second stage +0.6 .. +2.3, first stage's 6.7 .. 8.5 gone;
 // 48 launches less per step, step time within +-0.04 ms (a small kernel costs ~3 us inside the replayed graph).
 int64_t adp_conv_mm4_gnb_entries(const adp_conv_desc& d) {
-  if (d.store != 0 || m4_ks_eff(d) > 1) return 0;
-  if (d.M < 128 && d.B * d.M * d.N > (4 << 20)) return 0;  // (the HBM-bound case above; at batch 1 the tensor is 4 MB and cached)
+  if (d.store != 0 || m4_ks_eff(d) > 1 || !d.transposed || d.up != 1) return 0;  // (the instantiations that exist)
+  if (d.M < 128 && d.B * d.M * d.N > (4 << 20)) return 0;
+  if (!adp_gnb_family_on(m4_nkg(d) == 2 ? 2 : 1)) return 0;  // (the HBM-bound case above; at batch 1 the tensor is 4 MB and cached)
   return adp_cdiv(d.N, M4_BN);
 }
 
@@ -653,7 +662,8 @@ int adp_conv_mm4(const adp_conv_desc& d, void* stream) {
   }
   if (m4_nkg(d) == 2) {  // light block: 32-channel chunks (60 KB of LDS: two blocks per CU)
     const dim3 block((2 * M4_NPG + M4_NLD) * 64);
-    if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 32, 2>), grid, block, stream, d);
+    if (d.transposed && d.gnb_ab) ADP_LAUNCH((conv_mm4_kernel<true, 1, 32, 2, 1, true>), grid, block, stream, d);
+    else if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 32, 2>), grid, block, stream, d);
     else ADP_LAUNCH((conv_mm4_kernel<false, 1, 32, 2>), grid, block, stream, d);
     if (ADP_LAUNCH_OK() != ADP_OK) return ADP_ERR_LAUNCH;
     return ks > 1 ? adp_conv_splitk_reduce(d, ks, stream) : ADP_OK;
@@ -663,11 +673,15 @@ int adp_conv_mm4(const adp_conv_desc& d, void* stream) {
   const char* e = getenv("ADP_MM4_BKT");
   const int bkt = (e ? atoi(e) : 64) == 64 && d.R % 64 == 0 ? 64 : 32;
   if (bkt == 64) {  // (one register stage: a second one with 64-channel chunks spills)
-    if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64, 4>), grid, block, stream, d);
+    if (d.transposed && d.gnb_ab) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64, 4, 1, true>), grid, block, stream, d);
+    else if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64, 4>), grid, block, stream, d);
     else ADP_LAUNCH((conv_mm4_kernel<false, 1, 64, 4>), grid, block, stream, d);
   } else {
     const bool pd2 = d.R / 32 / ks >= 4;
-    if (d.transposed) {
+    if (d.transposed && d.gnb_ab) {
+      if (pd2) ADP_LAUNCH((conv_mm4_kernel<true, 2, 32, 4, 1, true>), grid, block, stream, d);
+      else ADP_LAUNCH((conv_mm4_kernel<true, 1, 32, 4, 1, true>), grid, block, stream, d);
+    } else if (d.transposed) {
       if (pd2) ADP_LAUNCH((conv_mm4_kernel<true, 2, 32, 4>), grid, block, stream, d);
       else ADP_LAUNCH((conv_mm4_kernel<true, 1, 32, 4>), grid, block, stream, d);
     } else {

@@ -98,7 +98,10 @@ struct cmax {
 // NSP > 1 (2 / 4; short K, long N: the mid-depth layers): the block covers NSP adjacent 64-position tiles and the MMA
 // waves trade K groups for positions (NKG = 4 / NSP), so a block stages the same weight chunk once for NSP times the
 // outputs, half / none of the K-group exchange remains, and a wave issues NSP times the MFMAs per barrier.
-template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD, bool WN = false, int NSP = 1, bool PF = false>
+// GNB: the launch also leaves the first stage of a GroupNorm backward (adp_conv_desc.gnb_ab): its own instantiations (plain
+//      Winograd data gradients without the K split); every other launch compiles as it did without it
+template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD, bool WN = false, int NSP = 1, bool PF = false,
+          bool GNB = false>
 __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD, NSP)) * 64) void conv_mm_kernel(
     adp_conv_desc d, int KS) {
   static_assert(!WN || (KT == 3 && S == 1), "Winograd F(2,3): kernel 3, stride 1 (any upsample factor: the LDS tile "
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD, NSP)
   }
   // ---- first stage of the backward of SiLU(GroupNorm(gnb_x)) whose output gradient this tile is (adp_conv_desc.gnb_ab; store 0,
   // no K split): (sum ds * xhat, sum ds) per finished row over the tile's <= 64 positions, one entry per row and 64-position tile
-  if (d.gnb_ab != nullptr && KS == 1 && d.store == 0 && nw0 < N) {
+  if (GNB && KS == 1 && d.store == 0 && nw0 < N) {
     const int cg = M / (int)d.gnb_groups;
     const int n_a = WN ? nw0 + 2 * l31 : nw0 + l31, n_b = WN ? n_a + 1 : n_a + 32;  // positions of vfin[0] / vfin[1]
     const int E = (N + MM_BN - 1) / MM_BN;
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD, NSP)
   }
 }
 
-template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD, bool WN = false, int NSP = 1>
+template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, int PD, bool WN = false, int NSP = 1, bool GNB = false>
 int launch_mm(const adp_conv_desc& d, void* stream) {
   const int64_t blocks = (d.M / BM) * adp_cdiv(d.N, MM_BN * NSP) * d.B;
   const int KS = d.ws ? (int)adp_conv_mm_ksplit(d) : 1;
@@ -635,32 +638,32 @@ int launch_mm(const adp_conv_desc& d, void* stream) {
   if constexpr (WN && BM == 32 && NSP == 1 && BKT == 32 && UP == 1 && mm_nld(PRO, BM, PD, NSP) == 4) {
     const char* e = getenv("ADP_MM_PF");
     if (!e || e[0] != '0') {
-      ADP_LAUNCH((conv_mm_kernel<BM, KT, S, UP, TR, PRO, BKT, PD, WN, NSP, true>), dim3((unsigned)blocks, (unsigned)KS),
+      ADP_LAUNCH((conv_mm_kernel<BM, KT, S, UP, TR, PRO, BKT, PD, WN, NSP, true, GNB>), dim3((unsigned)blocks, (unsigned)KS),
                  dim3(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD, NSP)) * 64), stream, d, KS);
       return ADP_LAUNCH_OK();
     }
   }
-  ADP_LAUNCH((conv_mm_kernel<BM, KT, S, UP, TR, PRO, BKT, PD, WN, NSP>), dim3((unsigned)blocks, (unsigned)KS),
+  ADP_LAUNCH((conv_mm_kernel<BM, KT, S, UP, TR, PRO, BKT, PD, WN, NSP, false, GNB>), dim3((unsigned)blocks, (unsigned)KS),
              dim3(((BM / 32) * mm_nkg(BKT) + mm_nld(PRO, BM, PD, NSP)) * 64), stream, d, KS);
   return ADP_LAUNCH_OK();
 }
 
 // short K (one or two chunks: the HBM-bound shallow layers) runs without ghost iterations
-template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, bool WN = false>
+template <int BM, int KT, int S, int UP, bool TR, int PRO, int BKT, bool WN = false, bool GNB = false>
 int launch_pd(const adp_conv_desc& d, void* stream) {
   const int64_t KS = d.ws ? adp_conv_mm_ksplit(d) : 1;
   if constexpr (BM == 64 && S == 1 && (WN || KT == 1)) {  // wide-N blocks (one register stage: their chunks are long)
     const int nsp = adp_conv_mm_nsp(d);
     if constexpr (WN) {  // (the 1x1 convs stop at 128 positions: adp_conv_mm_nsp)
-      if (nsp == 4) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1, WN, 4>(d, stream);
+      if (nsp == 4) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1, WN, 4, GNB>(d, stream);
     }
-    if (nsp == 2) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1, WN, 2>(d, stream);
+    if (nsp == 2) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1, WN, 2, GNB>(d, stream);
   }
   // (a 64-channel chunk already is two 32-channel register stages; a second one does not fit the register file)
   // (a third register stage for the short Winograd chunks was measured: 14.37 -> 15.17 ms per step, rejected)
   // (four register stages for the batch-1 deep layers, 16 chunks per block: batch-1 step 7.97 -> 8.10 ms, sampler 2.75 -> 2.80)
-  if (BKT < 64 && d.R / BKT / KS >= 4) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 2, WN>(d, stream);
-  return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1, WN>(d, stream);
+  if (BKT < 64 && d.R / BKT / KS >= 4) return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 2, WN, 1, GNB>(d, stream);
+  return launch_mm<BM, KT, S, UP, TR, PRO, BKT, 1, WN, 1, GNB>(d, stream);
 }
 
 // every (kernel, stride, upsample, direction, prologue) variant of one block tile
@@ -680,6 +683,8 @@ int run_tile(const adp_conv_desc& d, void* stream) {
       if (d.prologue == 1)
         return tr ? launch_pd<BM, 3, 1, 1, true, 1, 32, true>(d, stream)
                   : launch_pd<BM, 3, 1, 1, false, 1, 32, true>(d, stream);
+      // (data gradient that also leaves a GroupNorm backward's first stage: unsplit launches -- with the K split the reduce kernel does)
+      if (tr && d.gnb_ab && !(d.ws && adp_conv_mm_ksplit(d) > 1)) return launch_pd<BM, 3, 1, 1, true, 0, 32, true, true>(d, stream);
       return tr ? launch_pd<BM, 3, 1, 1, true, 0, 32, true>(d, stream)
                 : launch_pd<BM, 3, 1, 1, false, 0, 32, true>(d, stream);
     }

@@ -427,7 +427,7 @@ bool adp_conv_tile_eligible(const adp_conv_desc& d) {
 
 int64_t adp_conv_tile_gn_entries(const adp_conv_desc& d) { return d.N / WT_TN / tile_nw(d); }
 // slices per row of gnb_ab: one per workgroup (plain data gradients only; gnb_x / gamma / beta 16-byte aligned)
-int64_t adp_conv_tile_gnb_entries(const adp_conv_desc& d) { return tile_gnb_ok(d) ? d.N / WT_TN / tile_nw(d) : 0; }
+int64_t adp_conv_tile_gnb_entries(const adp_conv_desc& d) { return tile_gnb_ok(d) && adp_gnb_family_on(16) ? d.N / WT_TN / tile_nw(d) : 0; }
 
 int adp_conv_tile(const adp_conv_desc& d, void* stream) {
   if (d.gnb_ab) return launch_tile_gnb(d, stream);  // (adp_conv1d has checked adp_conv_tile_gnb_entries)

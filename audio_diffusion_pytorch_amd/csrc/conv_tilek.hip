@@ -47,7 +47,9 @@ constexpr int TK_XF = TK_CH * TK_RS;
 // NCH: 16-channel chunks per wave, unrolled (4: 512 input channels, 8: 1024) -- in a rolled loop the chunk-ahead registers are
 // loop-carried values and the compiler parks them through register copies behind s_waitcnt vmcnt(0) at the back edge, which
 // turns the prefetch into a wait for what was just requested; 0 = rolled loop (any other channel count)
-template <bool TR, int RB, int NCH, int PF = 2>
+// GNB: the launch also leaves the first stage of a GroupNorm backward (adp_conv_desc.gnb_ab): separate instantiations (data
+//      gradients, PF = 2), every other launch compiles as it did without it
+template <bool TR, int RB, int NCH, int PF = 2, bool GNB = false>
 __global__ __launch_bounds__(64 * TK_NKW) void conv_tilek_kernel(adp_conv_desc d, int ntn) {
   const bool RES = d.res != nullptr, GN = d.gn_part != nullptr;  // (workgroup-uniform)
   constexpr int ROWS = 16 * RB;
@@ -119,7 +121,6 @@ __global__ __launch_bounds__(64 * TK_NKW) void conv_tilek_kernel(adp_conv_desc d
   f32x4 rv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   float bv = 0.0f;
   // first stage of the backward of SiLU(GroupNorm(gnb_x)) whose output gradient this launch produces (adp_conv_desc.gnb_ab)
-  const bool GNB = d.gnb_ab != nullptr;  // (workgroup-uniform)
   f32x4 gx = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   float gmu = 0.0f, grs = 0.0f, gga = 0.0f, gbe = 0.0f;
   if (fin) {
@@ -347,6 +348,14 @@ int launch_tilek(const adp_conv_desc& d, void* stream) {
   // chunks in flight per wave: 2.  In-step A/B (hipGraph replay, same box), 2 -> 4: batch-1 step 6.22 -> 6.28 ms, config-4 layout
   // 10.12 -> 10.19 ms -- the CUs are short of L1 fill rate, not of requests in flight (ADP_TILEK_PF=4: the deeper variant, 16-row tiles)
   const bool pf4 = RB == 1 && pf && atoi(pf) == 4;
+  if constexpr (TR) {
+    if (d.gnb_ab) {
+      if (nch == 4) ADP_LAUNCH((conv_tilek_kernel<TR, RB, 4, 2, true>), dim3(grid), dim3(64 * TK_NKW), stream, d, ntn);
+      else if (nch == 8) ADP_LAUNCH((conv_tilek_kernel<TR, RB, 8, 2, true>), dim3(grid), dim3(64 * TK_NKW), stream, d, ntn);
+      else ADP_LAUNCH((conv_tilek_kernel<TR, RB, 0, 2, true>), dim3(grid), dim3(64 * TK_NKW), stream, d, ntn);
+      return ADP_LAUNCH_OK();
+    }
+  }
   if (nch == 4 && pf4) ADP_LAUNCH((conv_tilek_kernel<TR, RB, 4, (RB == 1 ? 4 : 2)>), dim3(grid), dim3(64 * TK_NKW), stream, d, ntn);
   else if (nch == 8 && pf4) ADP_LAUNCH((conv_tilek_kernel<TR, RB, 8, (RB == 1 ? 4 : 2)>), dim3(grid), dim3(64 * TK_NKW), stream, d, ntn);
   else if (nch == 4) ADP_LAUNCH((conv_tilek_kernel<TR, RB, 4>), dim3(grid), dim3(64 * TK_NKW), stream, d, ntn);
@@ -384,7 +393,8 @@ bool adp_conv_tilek_eligible(const adp_conv_desc& d) {
 }
 
 int64_t adp_conv_tilek_gn_entries(const adp_conv_desc& d) { return d.N / TK_TN; }
-int64_t adp_conv_tilek_gnb_entries(const adp_conv_desc& d) { return d.N / TK_TN; }  // one slice per row and 64-position tile
+// one slice per row and 64-position tile (data gradients: the instantiations that exist)
+int64_t adp_conv_tilek_gnb_entries(const adp_conv_desc& d) { return d.transposed && adp_gnb_family_on(4) ? d.N / TK_TN : 0; }
 
 int adp_conv_tilek(const adp_conv_desc& d, void* stream) {
   if (tilek_rb(d) == 2) return d.transposed ? launch_tilek<true, 2>(d, stream) : launch_tilek<false, 2>(d, stream);
