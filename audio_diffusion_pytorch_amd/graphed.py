@@ -26,6 +26,7 @@ from collections import OrderedDict
 from typing import Any, Callable, Dict, List, Optional
 
 import torch
+import torch.distributed
 import torch.nn as nn
 from torch import Tensor
 
@@ -201,10 +202,17 @@ class TrainStepGraphs:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         torch.cuda.set_rng_state(rng, dev)
+        # inside a process group (e.g. under torch's DistributedDataParallel): its watchdog thread queries the events of earlier
+        # collectives -- let it retire them first, and do not let a query from that thread abort the capture
+        mode = "global"
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            from .parallel import quiesce_watchdog
+            quiesce_watchdog()
+            mode = "thread_local"
         e.g_f, e.g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(e.g_f):
+        with torch.cuda.graph(e.g_f, capture_error_mode=mode):
             e.sloss = eager(e.sx, e.snoise, **skw)
-        with torch.cuda.graph(e.g_b, pool=e.g_f.pool()):
+        with torch.cuda.graph(e.g_b, pool=e.g_f.pool(), capture_error_mode=mode):
             e.grads = torch.autograd.grad(e.sloss, params, grad_outputs=e.sgloss, allow_unused=True)
         # Drop the captured step's autograd graph: it keeps the parameters' AccumulateGrad nodes alive, and those were created
         # on the CAPTURE stream -- every later backward would then run its 600 gradient accumulations on that stream behind an

@@ -32,6 +32,19 @@ def graph_safe_rccl_env() -> None:
     os.environ.setdefault("TORCH_NCCL_DUMP_ON_TIMEOUT", "0")
 
 
+def quiesce_watchdog(seconds: float = 0.3) -> None:
+    """Called between the eager warm-up collectives and a stream capture: ProcessGroupNCCL's watchdog thread retires finished
+    work objects on its next pass (every ~100 ms) by QUERYING their events, and an event query that lands inside an open capture
+    can still abort the process on this stack even in thread_local mode (one `dp1` run in about ten died that way, with a c10::Error
+    out of a libtorch_hip thread).  After a device synchronisation every pending work is complete; one pause later the watchdog's
+    list is empty, and works issued under capture are never handed to it."""
+    import time
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    if dist.is_available() and dist.is_initialized():
+        time.sleep(seconds)
+
+
 def capture_step(step, warmup: int = 2):
     """Captures `step()` -- a whole training step through a DataParallel wrapper, collectives included -- in a hipGraph and
     returns (graph, replay).  `warmup` eager steps run first on a side stream (RCCL communicators, allocator pools and lazily
@@ -46,7 +59,7 @@ def capture_step(step, warmup: int = 2):
         for _ in range(warmup):
             step()
     torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
+    quiesce_watchdog()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, capture_error_mode="thread_local"):
         step()
@@ -67,7 +80,7 @@ def capture_step_deferred(step, dp: "DataParallel", warmup: int = 2):
                 step()
                 dp.flush_deferred()
         torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        quiesce_watchdog()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             step()

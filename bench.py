@@ -765,6 +765,9 @@ def _graphed(step, zero, mode="global"):
             step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    if mode == "thread_local":
+        from audio_diffusion_pytorch_amd import parallel
+        parallel.quiesce_watchdog()  # (the watchdog retires the warm-up collectives before the capture opens)
     zero()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, capture_error_mode=mode):
@@ -1011,6 +1014,8 @@ def main():
                     eager_step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            if world > 1:
+                parallel.quiesce_watchdog()  # (the watchdog retires the warm-up collectives before the capture opens)
             zero()
             graph = torch.cuda.CUDAGraph()
             # (with RCCL: thread_local -- the watchdog thread may still poll the warm-up collectives' events: parallel.capture_step)
