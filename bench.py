@@ -176,6 +176,18 @@ def roofline_leg(model, x, top: int = 14):
     except (OSError, ValueError, ImportError):
         pass
 
+    def pmc_of(name):
+        """Counters of a kernel named by its launcher's template arguments: rocprofv3 prints trailing DEFAULTED template
+        parameters too (`conv_tile32_kernel<false, 1, 16, false, true>` is `<..., true, false>` there)."""
+        if name in pmc:
+            return pmc[name]
+        if name.endswith(">"):
+            stem = name[:-1] + ", "
+            for k, v in pmc.items():
+                if k.startswith(stem) and all(t.strip() in ("false", "0") for t in k[len(stem):-1].split(",")):
+                    return v
+        return None
+
     def entry(name, a):
         sec = a["ms"] * 1e-3
         tf, gb = a["flops"] / sec / 1e12, a["bytes"] / sec / 1e9
@@ -197,7 +209,7 @@ def roofline_leg(model, x, top: int = 14):
             e["achieved"] = round(tf * wf, 2)
             e["frac"] = round(e["achieved"] / e["peak"], 4)
             e["frac_executed"] = e["frac"]
-        t = pmc.get(name.split(" | ")[0])
+        t = pmc_of(name.split(" | ")[0])
         e["traffic"] = t.get("hbm_bytes_per_launch") if t else None
         e["traffic_source"] = ("stored rocprofv3 PMC pass of this command (profiles/pmc_traffic.json: separate FETCH_SIZE / "
                                "WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction)"
@@ -242,7 +254,7 @@ def roofline_leg(model, x, top: int = 14):
         hbm = entry(" | ".join(sorted(names)), hb)
         # HBM-side bytes per launch of each kernel in the group, from the stored PMC passes (the depth-0 and depth-1
         # launches move the same algorithmic bytes; NB the counters include Infinity-Cache hits)
-        per = {n: pmc[n]["hbm_bytes_per_launch"] for n in sorted(names) if n in pmc}
+        per = {n: pmc_of(n)["hbm_bytes_per_launch"] for n in sorted(names) if pmc_of(n) is not None}
         hbm["traffic"] = per or None
         hbm["traffic_source"] = "stored rocprofv3 PMC pass (profiles/pmc_traffic.json), per kernel instantiation" if per else None
         hbm["what"] = "forward ConvBlock convs (GroupNorm+SiLU prologue, k=3) of depths 0-1: A_in + A_out (+A_res) bytes"
