@@ -11,7 +11,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libadp_hip.so")
-SOURCES = ["conv1d.hip", "conv_mm.hip", "conv_mm_m64.hip", "conv_mm_m32.hip", "conv_tile.hip", "conv_tilek.hip", "conv_mm4.hip", "wgrad_mm.hip", "conv_direct.hip", "wgrad_direct.hip", "norm.hip", "elementwise.hip", "resample.hip", "linear.hip", "attention.hip", "ctx_bank.hip", "probe.hip"]
+SOURCES = ["conv1d.hip", "conv_mm.hip", "conv_mm_m64.hip", "conv_mm_m32.hip", "conv_tile.hip", "conv_tilek.hip", "conv_tilek1.hip", "conv_mm4.hip", "wgrad_mm.hip", "conv_direct.hip", "wgrad_direct.hip", "norm.hip", "elementwise.hip", "resample.hip", "linear.hip", "attention.hip", "ctx_bank.hip", "probe.hip"]
 
 
 def _newest_mtime(paths):

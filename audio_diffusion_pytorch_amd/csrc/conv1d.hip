@@ -861,6 +861,7 @@ extern "C" int adp_conv1d(const adp_conv_desc* dp, void* stream) {
   if (adp_conv_tile_eligible(d)) return adp_conv_tile(d, stream);
   if (adp_conv_tilek_eligible(d)) return adp_conv_tilek(d, stream);
   if (adp_conv_mm4_eligible(d)) return adp_conv_mm4(d, stream);
+  if (adp_conv_tilek1_eligible(d)) return adp_conv_tilek1(d, stream);
   if (adp_conv_mm_eligible(d)) return adp_conv_mm(d, stream);
   if (adp_conv_direct_eligible(d)) return adp_conv_direct(d, stream);
   if (d.KT == 1) return dispatch_conv<1, 1>(d, stream);
@@ -878,6 +879,7 @@ extern "C" int64_t adp_conv1d_ws_bytes(const adp_conv_desc* dp) {
     const int64_t ks4 = adp_conv_mm4_ksplit(d);
     return ks4 > 1 ? ks4 * d.B * d.M * d.N * (int64_t)sizeof(float) : 0;
   }
+  if (adp_conv_tilek1_eligible(d)) return 0;  // (its K split stays inside the workgroup)
   if (!adp_conv_mm_eligible(d)) return 0;
   const int64_t ks = adp_conv_mm_ksplit(d);
   return ks > 1 ? ks * d.B * d.M * d.N * (int64_t)sizeof(float) : 0;
@@ -891,6 +893,7 @@ extern "C" int64_t adp_conv1d_gn_entries(const adp_conv_desc* dp) {
   if (adp_conv_tile_eligible(d)) return adp_conv_tile_gn_entries(d);
   if (adp_conv_tilek_eligible(d)) return adp_conv_tilek_gn_entries(d);
   if (adp_conv_mm4_eligible(d)) return adp_conv_mm4_gn_entries(d);
+  if (adp_conv_tilek1_eligible(d)) return adp_conv_tilek1_gn_entries(d);
   // (the K split only happens when the caller passed its scratch: set d.ws before asking)
   if (adp_conv_mm_eligible(d))  // one slice per 64-position tile, or the K-split reduce kernel's slices
     return d.ws && adp_conv_mm_ksplit(d) > 1 ? adp_conv_splitk_gn_entries(d) : adp_cdiv(d.N, 64);
@@ -905,6 +908,7 @@ extern "C" int64_t adp_conv1d_gnb_entries(const adp_conv_desc* dp) {
   if (adp_conv_tile_eligible(d)) return adp_conv_tile_gnb_entries(d);
   if (adp_conv_tilek_eligible(d)) return adp_conv_tilek_gnb_entries(d);
   if (adp_conv_mm4_eligible(d)) return adp_conv_mm4_gnb_entries(d);
+  if (adp_conv_tilek1_eligible(d)) return 0;
   if (adp_conv_mm_eligible(d)) return d.gn_part ? 0 : adp_conv_mm_gnb_entries(d);
   return 0;
 }
@@ -914,7 +918,8 @@ extern "C" int64_t adp_conv1d_tile(const adp_conv_desc* dp) {
   if (!dp) return ADP_ERR_NULL;
   if (adp_conv_tile_eligible(*dp)) return 32 * 1000 + 64;   // wave-tile 32-channel kernel: 32 outputs x 64 positions per wave
   if (adp_conv_tilek_eligible(*dp)) return 48000000 + 64;   // deep-layer wave tiles: 16 / 32 rows x 64 positions, 8 K slices per workgroup
-  if (adp_conv_mm4_eligible(*dp)) return 64000000 + 32 * 1000 + 128;  // F(4,3) block: 6 planes x 4 K groups, 32 rows x 128 positions
+  if (adp_conv_mm4_eligible(*dp)) return 64000000 + 32 * 1000 + 128;
+  if (adp_conv_tilek1_eligible(*dp)) return 47000000 + 64;  // 1x1 wave tiles: 16 rows x 64 positions, 8 K slices per workgroup  // F(4,3) block: 6 planes x 4 K groups, 32 rows x 128 positions
   if (adp_conv_mm_eligible(*dp)) return adp_conv_mm_tile(*dp);
   if (adp_conv_direct_eligible(*dp)) return 8 * 1000 + 999;  // direct VALU kernel: 8 output channels x 1024 positions
   return pick_tile(*dp);

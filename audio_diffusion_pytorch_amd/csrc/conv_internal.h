@@ -54,6 +54,10 @@ int64_t adp_conv_tile_gn_entries(const adp_conv_desc& d);  // GroupNorm partial 
 // eight waves of a workgroup split the input channels, 16- or 32-row tiles, no cross-workgroup K split / reduce launch
 bool adp_conv_tilek_eligible(const adp_conv_desc& d);
 int adp_conv_tilek(const adp_conv_desc& d, void* stream);
+// conv_tilek1.hip: the 1x1 sibling (attention projections at batch 1: K split inside the workgroup instead of across workgroups)
+bool adp_conv_tilek1_eligible(const adp_conv_desc& d);
+int adp_conv_tilek1(const adp_conv_desc& d, void* stream);
+int64_t adp_conv_tilek1_gn_entries(const adp_conv_desc& d);  // one GroupNorm partial entry per row quad and 64-position tile
 int64_t adp_conv_tilek_gnb_entries(const adp_conv_desc& d);  // slices per row of gnb_ab
 int64_t adp_conv_tilek_gn_entries(const adp_conv_desc& d);  // one GroupNorm partial entry per row quad and 64-position tile
 

@@ -618,6 +618,45 @@ def test_conv_mm4_winograd_f43(dev, B, R, M, L, tr, bkt, monkeypatch):
     assert rel_err(plain, ops.conv1d(xd, wd, None, pad=1, transposed=tr)) < 1e-5
 
 
+@pytest.mark.parametrize("B,R,M,L", [(1, 512, 512, 128), (1, 1024, 512, 256), (2, 256, 48, 64), (1, 512, 1024, 192)])
+@pytest.mark.parametrize("tr", [False, True])
+def test_conv_tilek1_projection(dev, B, R, M, L, tr, monkeypatch):
+    """conv_tilek1.hip: the attention items' 1x1 projections at batch 1 (components.py:92-93) -- eight waves of a workgroup split
+    the input channels of one 16 x 64 output tile, no cross-workgroup K split and no reduce launch: forward with bias / residual
+    and the GroupNorm partial statistics of the output, data gradient through the transposed weight view; against fp64, and
+    against conv_mm's split-K path on the same operands."""
+    from ctypes import byref
+    monkeypatch.setenv("ADP_TILEK1_MIN_TILES", "1")
+    G = 4
+    x = rnd(B, R, L, seed=1) * 1.3 + 0.2
+    w = rnd(R, M, 1, seed=2, scale=0.05) if tr else rnd(M, R, 1, seed=2, scale=0.05)
+    b, r = rnd(M, seed=3), rnd(B, M, L, seed=4)
+    xd, wd = x.to(dev), w.to(dev)
+    d = _C.ConvDesc(_C.ptr(xd), None, _C.ptr(wd), None, None, None, None, None, None, _C.ptr(xd), None, B, R, R, L, M, L,
+                    1, 1, 1, 0, 1, int(tr), 0, 1, 0, 1, 0)
+    assert _C.query("adp_conv1d_tile", byref(d)) == 47000064, "case must dispatch to the 1x1 wave-tile kernel"
+    assert _C.query("adp_conv1d_ws_bytes", byref(d)) == 0
+    if tr:
+        ref = F.conv_transpose1d(x.double(), w.double(), None)
+        out = ops.conv1d(xd, wd, None, transposed=True)
+        assert rel_err(out, ref) < 1e-5
+    else:
+        ref = F.conv1d(x.double(), w.double(), b.double()) + r.double()
+        gn = ops.GnPart()
+        out = ops.conv1d(xd, wd, b.to(dev), res=r.to(dev), gn=gn)
+        assert rel_err(out, ref) < 1e-5
+        assert gn.part is not None and gn.part.shape == (B, M // 4, L // 64, 3) and gn.part[..., 2].eq(256).all()
+        if M % (4 * G) == 0:
+            st = ops.gn_finalize(gn.part, G)
+            g64 = ref.view(B, G, -1)
+            assert rel_err(st[..., 0], g64.mean(-1)) < 2e-5
+            assert rel_err(st[..., 1], (g64.var(-1, unbiased=False) + 1e-5).rsqrt()) < 2e-5
+    monkeypatch.setenv("ADP_CONV_TILEK1", "0")
+    assert _C.query("adp_conv1d_tile", byref(d)) != 47000064
+    other = ops.conv1d(xd, wd, None, transposed=True) if tr else ops.conv1d(xd, wd, b.to(dev), res=r.to(dev))
+    assert rel_err(out, other) < 1e-5
+
+
 @pytest.mark.parametrize("B,C,L", [(2, 128, 256), (1, 160, 132), (2, 192, 1024), (1, 256, 260), (2, 256, 128), (1, 512, 64)])
 @pytest.mark.parametrize("bkt", ["64", "light", "tilek1", "tilek2", "mm"])
 def test_conv_mm4_leaves_first_stage_of_groupnorm_backward(dev, B, C, L, bkt, monkeypatch):
