@@ -26,11 +26,11 @@ constexpr int T1_CH = 16;          // channels per chunk (four K steps of v_mfma
 constexpr int T1_NKW = 8;          // waves per workgroup = K slices
 constexpr int T1_XF = T1_CH * T1_TN;  // floats of a wave's region: the x tile, later its partial tile [4][64] float4
 
-template <bool TR>
-__global__ __launch_bounds__(64 * T1_NKW) void conv_tilek1_kernel(adp_conv_desc d, int ntn) {
+template <bool TR, int NKW = T1_NKW>
+__global__ __launch_bounds__(64 * NKW) void conv_tilek1_kernel(adp_conv_desc d, int ntn) {
   const bool RES = d.res != nullptr, GN = d.gn_part != nullptr;  // (workgroup-uniform)
-  __shared__ __attribute__((aligned(16))) float lds[T1_NKW * T1_XF + T1_NKW * 8];
-  float* const gsh = lds + T1_NKW * T1_XF;  // statistics scratch [wave][kq][2]
+  __shared__ __attribute__((aligned(16))) float lds[NKW * T1_XF + 64];
+  float* const gsh = lds + NKW * T1_XF;  // statistics scratch [wave < 4][kq][2]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = adp_uniform(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;  // MFMA 16x16x4: lane = (row / column j, K index kq)
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64 * T1_NKW) void conv_tilek1_kernel(adp_conv_desc 
   const int b = rem / ntn, nt = rem - b * ntn;
   const int m0 = mt * 16, n0 = nt * T1_TN;
 
-  const int kc = R / T1_NKW;  // this wave's channels [c_lo, c_lo + kc)
+  const int kc = R / NKW;  // this wave's channels [c_lo, c_lo + kc)
   const int c_lo = wave * kc, nchunks = kc / T1_CH;
   float* const X = lds + wave * T1_XF;
 
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64 * T1_NKW) void conv_tilek1_kernel(adp_conv_desc 
   if (fin) {
     f32x4 y = *reinterpret_cast<const f32x4*>(lds + (fr * 64 + lane) * 4);
 #pragma unroll
-    for (int w = 1; w < T1_NKW; ++w) {  // wave order: deterministic
+    for (int w = 1; w < NKW; ++w) {  // wave order: deterministic
       const f32x4 t = *reinterpret_cast<const f32x4*>(lds + w * T1_XF + (fr * 64 + lane) * 4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) y[k] += t[k];
@@ -215,6 +215,15 @@ int64_t adp_conv_tilek1_gn_entries(const adp_conv_desc& d) { return d.N / T1_TN;
 int adp_conv_tilek1(const adp_conv_desc& d, void* stream) {
   const int ntn = (int)(d.N / T1_TN);
   const unsigned grid = (unsigned)((d.M / 16) * d.B * ntn);
+  // ADP_TILEK1_NKW=16 (A/B, tests): sixteen K slices, four waves per SIMD.  Measured 0.5-0.8 us SLOWER per launch on every shape
+  // ([1,1024->512,128] 8.8 -> 9.6 us, [1,512->512,512] 6.3 -> 6.8): the K loop is not what these launches wait for.  Default: eight.
+  const char* e = getenv("ADP_TILEK1_NKW");
+  const bool w16 = e && atoi(e) == 16 && d.R % (2 * 16 * T1_CH) == 0;
+  if (w16) {
+    if (d.transposed) ADP_LAUNCH((conv_tilek1_kernel<true, 16>), dim3(grid), dim3(64 * 16), stream, d, ntn);
+    else ADP_LAUNCH((conv_tilek1_kernel<false, 16>), dim3(grid), dim3(64 * 16), stream, d, ntn);
+    return ADP_LAUNCH_OK();
+  }
   if (d.transposed) ADP_LAUNCH((conv_tilek1_kernel<true>), dim3(grid), dim3(64 * T1_NKW), stream, d, ntn);
   else ADP_LAUNCH((conv_tilek1_kernel<false>), dim3(grid), dim3(64 * T1_NKW), stream, d, ntn);
   return ADP_LAUNCH_OK();

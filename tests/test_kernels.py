@@ -620,13 +620,17 @@ def test_conv_mm4_winograd_f43(dev, B, R, M, L, tr, bkt, monkeypatch):
 
 @pytest.mark.parametrize("B,R,M,L", [(1, 512, 512, 128), (1, 1024, 512, 256), (2, 256, 48, 64), (1, 512, 1024, 192)])
 @pytest.mark.parametrize("tr", [False, True])
-def test_conv_tilek1_projection(dev, B, R, M, L, tr, monkeypatch):
+@pytest.mark.parametrize("nkw", ["8", "16"])  # K slices = waves per workgroup
+def test_conv_tilek1_projection(dev, B, R, M, L, tr, nkw, monkeypatch):
     """conv_tilek1.hip: the attention items' 1x1 projections at batch 1 (components.py:92-93) -- eight waves of a workgroup split
     the input channels of one 16 x 64 output tile, no cross-workgroup K split and no reduce launch: forward with bias / residual
     and the GroupNorm partial statistics of the output, data gradient through the transposed weight view; against fp64, and
     against conv_mm's split-K path on the same operands."""
     from ctypes import byref
+    if nkw == "16" and R % 512:
+        pytest.skip("sixteen slices take chunk pairs of 512 channels")
     monkeypatch.setenv("ADP_TILEK1_MIN_TILES", "1")
+    monkeypatch.setenv("ADP_TILEK1_NKW", nkw)
     G = 4
     x = rnd(B, R, L, seed=1) * 1.3 + 0.2
     w = rnd(R, M, 1, seed=2, scale=0.05) if tr else rnd(M, R, 1, seed=2, scale=0.05)

@@ -27,8 +27,9 @@ def main():
         ws = [torch.randn(M, R, 1, device=dev) * 0.02 for _ in range(nw)]
         b = torch.randn(M, device=dev)
         row = []
-        for name, env in (("mm", "0"), ("tilek1", "1")):
+        for name, env, nkw in (("mm", "0", "8"), ("tilek1 x8", "1", "8"), ("tilek1 x16", "1", "16")):
             os.environ["ADP_CONV_TILEK1"] = env
+            os.environ["ADP_TILEK1_NKW"] = nkw
             n = max(20, nw)
             t1 = graph_time([(lambda i: (lambda: ops.conv1d(xs[i & 1], ws[i % nw], b, res=rs[i & 1])))(i) for i in range(n)])
             t2 = graph_time([(lambda i: (lambda: ops.conv1d(gs[i & 1], ws[i % nw], None, transposed=True)))(i) for i in range(n)])
