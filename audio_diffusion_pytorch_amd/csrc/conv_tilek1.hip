@@ -26,7 +26,9 @@ constexpr int T1_CH = 16;          // channels per chunk (four K steps of v_mfma
 constexpr int T1_NKW = 8;          // waves per workgroup = K slices
 constexpr int T1_XF = T1_CH * T1_TN;  // floats of a wave's region: the x tile, later its partial tile [4][64] float4
 
-template <bool TR, int NKW = T1_NKW>
+// SH: pixel-shuffle store (store mode 1: the DownsampleItem data gradient as a 1x1 conv over the space-to-depth view) --
+//     out[b][m / sp][n * sp + m % sp] (+ residual there); its own instantiation
+template <bool TR, int NKW = T1_NKW, bool SH = false>
 __global__ __launch_bounds__(64 * NKW) void conv_tilek1_kernel(adp_conv_desc d, int ntn) {
   const bool RES = d.res != nullptr, GN = d.gn_part != nullptr;  // (workgroup-uniform)
   __shared__ __attribute__((aligned(16))) float lds[NKW * T1_XF + 64];
@@ -75,11 +77,21 @@ __global__ __launch_bounds__(64 * NKW) void conv_tilek1_kernel(adp_conv_desc d, 
   const bool fin = wave < 4;
   const int fr = wave & 3;
   const int fch = m0 + 4 * kq + fr;  // this lane's output channel when its wave finishes
-  const int64_t foff = ((int64_t)b * M + fch) * L + n0 + 4 * j;
+  const int sp = SH ? (int)d.sp : 1;
+  // SH: element k of the lane's quad goes to foff + k * sp (row fch / sp of a [B, M / sp, L * sp] tensor, phase fch % sp)
+  const int64_t foff = SH ? ((int64_t)b * (M / sp) + fch / sp) * ((int64_t)L * sp) + (int64_t)(n0 + 4 * j) * sp + fch % sp
+                          : ((int64_t)b * M + fch) * L + n0 + 4 * j;
   f32x4 rv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   float bv = 0.0f;
   if (fin) {
-    if (RES) rv = *reinterpret_cast<const f32x4*>(d.res + foff);
+    if (RES) {
+      if (SH) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rv[k] = d.res[foff + k * sp];
+      } else {
+        rv = *reinterpret_cast<const f32x4*>(d.res + foff);
+      }
+    }
     if (d.bias) bv = d.bias[fch];
   }
 
@@ -136,8 +148,13 @@ __global__ __launch_bounds__(64 * NKW) void conv_tilek1_kernel(adp_conv_desc d, 
 #pragma unroll
       for (int k = 0; k < 4; ++k) y[k] += rv[k];
     }
-    *reinterpret_cast<f32x4*>(d.out + foff) = y;
-    if (GN) {
+    if (SH) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d.out[foff + k * sp] = y[k];
+    } else {
+      *reinterpret_cast<f32x4*>(d.out + foff) = y;
+    }
+    if (GN && !SH) {
       // (mean, M2) of this wave's 64 positions of channel fch, shifted by the row's first value
       const float gk = __shfl(y[0], lane & 48, 64);
       float s = 0.0f, q = 0.0f;
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(64 * NKW) void conv_tilek1_kernel(adp_conv_desc d, 
       }
     }
   }
-  if (GN) {
+  if (GN && !SH) {
     __syncthreads();
     if (tid < 4) {
       // row quad tid = kq: its four channels were finished by waves r = 0..3 (Chan's pairwise update)
@@ -185,7 +202,8 @@ int64_t tilek1_tiles(const adp_conv_desc& d) { return (d.M / 16) * d.B * (d.N / 
 bool adp_conv_tilek1_eligible(const adp_conv_desc& d) {
   const char* e = getenv("ADP_CONV_TILEK1");
   if (e && e[0] == '0') return false;
-  if (d.KT != 1 || d.stride != 1 || d.dil != 1 || d.pad != 0 || d.up != 1 || d.store != 0) return false;
+  if (d.KT != 1 || d.stride != 1 || d.dil != 1 || d.pad != 0 || d.up != 1) return false;
+  if (d.store != 0 && !(d.store == 1 && d.transposed && !d.gn_part && d.sp >= 1 && d.M % d.sp == 0)) return false;  // (SH instantiation)
   if (d.prologue != 0 || d.x2 || d.R1 != d.R || d.out_pre || d.e_scale || d.gnb_ab) return false;
   const char* mr = getenv("ADP_TILEK1_MIN_R");
   const char* xr = getenv("ADP_TILEK1_MAX_R");  // (2048 channels = 16 serial chunks per wave: conv_mm's split wins, 15.2 vs 18.3 us)
@@ -218,13 +236,14 @@ int adp_conv_tilek1(const adp_conv_desc& d, void* stream) {
   // ADP_TILEK1_NKW=16 (A/B, tests): sixteen K slices, four waves per SIMD.  Measured 0.5-0.8 us SLOWER per launch on every shape
   // ([1,1024->512,128] 8.8 -> 9.6 us, [1,512->512,512] 6.3 -> 6.8): the K loop is not what these launches wait for.  Default: eight.
   const char* e = getenv("ADP_TILEK1_NKW");
-  const bool w16 = e && atoi(e) == 16 && d.R % (2 * 16 * T1_CH) == 0;
+  const bool w16 = e && atoi(e) == 16 && d.R % (2 * 16 * T1_CH) == 0 && d.store == 0;
   if (w16) {
     if (d.transposed) ADP_LAUNCH((conv_tilek1_kernel<true, 16>), dim3(grid), dim3(64 * 16), stream, d, ntn);
     else ADP_LAUNCH((conv_tilek1_kernel<false, 16>), dim3(grid), dim3(64 * 16), stream, d, ntn);
     return ADP_LAUNCH_OK();
   }
-  if (d.transposed) ADP_LAUNCH((conv_tilek1_kernel<true>), dim3(grid), dim3(64 * T1_NKW), stream, d, ntn);
+  if (d.store == 1) ADP_LAUNCH((conv_tilek1_kernel<true, T1_NKW, true>), dim3(grid), dim3(64 * T1_NKW), stream, d, ntn);
+  else if (d.transposed) ADP_LAUNCH((conv_tilek1_kernel<true>), dim3(grid), dim3(64 * T1_NKW), stream, d, ntn);
   else ADP_LAUNCH((conv_tilek1_kernel<false>), dim3(grid), dim3(64 * T1_NKW), stream, d, ntn);
   return ADP_LAUNCH_OK();
 }

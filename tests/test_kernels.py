@@ -655,10 +655,19 @@ def test_conv_tilek1_projection(dev, B, R, M, L, tr, nkw, monkeypatch):
             g64 = ref.view(B, G, -1)
             assert rel_err(st[..., 0], g64.mean(-1)) < 2e-5
             assert rel_err(st[..., 1], (g64.var(-1, unbiased=False) + 1e-5).rsqrt()) < 2e-5
+    sh = None
+    if tr and nkw == "8":  # pixel-shuffle store (the DownsampleItem data gradient: out[b][m / sp][n * sp + m % sp] + residual)
+        for sp in (2, 4):
+            rs = rnd(B, M // sp, L * sp, seed=7)
+            sh = ops.conv1d(xd, wd, None, transposed=True, store=1, sp=sp, res=rs.to(dev))
+            want = ref.view(B, M // sp, sp, L).permute(0, 1, 3, 2).reshape(B, M // sp, L * sp) + rs.double()
+            assert rel_err(sh, want) < 1e-5
     monkeypatch.setenv("ADP_CONV_TILEK1", "0")
     assert _C.query("adp_conv1d_tile", byref(d)) != 47000064
     other = ops.conv1d(xd, wd, None, transposed=True) if tr else ops.conv1d(xd, wd, b.to(dev), res=r.to(dev))
     assert rel_err(out, other) < 1e-5
+    if sh is not None:
+        assert rel_err(sh, ops.conv1d(xd, wd, None, transposed=True, store=1, sp=4, res=rs.to(dev))) < 1e-5
 
 
 @pytest.mark.parametrize("B,C,L", [(2, 128, 256), (1, 160, 132), (2, 192, 1024), (1, 256, 260), (2, 256, 128), (1, 512, 64)])
