@@ -64,11 +64,16 @@ __device__ __forceinline__ f32x4 m4_load_xquad(const float* p) {
 //     their data gradients -- sums of sp = 2 / 4 adjacent outputs of the lane's quad, 8- / 4-byte stores, + residual)
 // GNB: the launch also leaves the first stage of a GroupNorm backward (adp_conv_desc.gnb_ab) -- its own instantiations (plain
 //      transposed launches), so that every other launch keeps the registers and instruction stream it had without it
-template <bool TR, int PD, int BKT, int M4_NKG, int UP = 1, bool GNB = false>
+// NPG: plane groups = MMA waves per K group.  2: three planes per wave (the blocks above).  3 (round 6, 16-wave block: 12 MMA + 4
+//      loader waves, THREE MMA waves per SIMD, two planes each -- (0,1) with the left halo, (2,3) with none, (4,5) with the right one):
+//      a wave's stream is a third shorter, three of them interleave on the SIMD; the first eight MMA waves run the epilogue
+template <bool TR, int PD, int BKT, int M4_NKG, int UP = 1, bool GNB = false, int NPG = M4_NPG>
 // (second launch bound = waves per SIMD the register allocation has to leave room for: the light 8-wave block lives on TWO
 //  blocks per CU = 4 waves per SIMD = at most 128 registers; the 12-wave block on one = 3 per SIMD)
-__global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BKT == 32) ? 4 : 1) void conv_mm4_kernel(adp_conv_desc d) {
-  constexpr int M4_NMMA = M4_NKG * M4_NPG, RPW = 16 / M4_NMMA;  // accumulator rows finished per wave (2 or 4)
+__global__ __launch_bounds__((M4_NKG * NPG + M4_NLD) * 64, (M4_NKG == 2 && BKT == 32) ? 4 : 1) void conv_mm4_kernel(adp_conv_desc d) {
+  static_assert(NPG == 2 || (NPG == 3 && M4_NKG == 4), "three plane groups: the 16-wave form of the 4-K-group block");
+  constexpr int M4_NMMA = M4_NKG * NPG, PPW = 6 / NPG;          // MMA waves; planes per wave
+  constexpr int NEPI = NPG == 3 ? 8 : M4_NMMA, RPW = 16 / NEPI;  // waves that run the epilogue; accumulator rows each finishes (2 or 4)
   constexpr int M4_RED = M4_NKG * 6 * 1024;                     // parked partial tiles
   constexpr int M4_QK = BKT * M4_KT;                            // floats of a forward weight row per chunk
   constexpr int M4_AROWS = TR ? BKT : M4_BM;
@@ -256,10 +261,11 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
   }
 
   // =========================== MMA waves ===========================
-  const int pg = wave & 1, kg = wave >> 1;
-  f32x16 acc[3];
+  const int pg = NPG == 3 ? wave % 3 : (wave & 1), kg = NPG == 3 ? wave / 3 : (wave >> 1);
+  const int ewave = wave < NEPI ? wave : 0;  // (NPG = 3: waves 8-11 leave after the exchange; their epilogue operands shadow wave 0's)
+  f32x16 acc[PPW];
 #pragma unroll
-  for (int p = 0; p < 3; ++p)
+  for (int p = 0; p < PPW; ++p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
 
@@ -269,7 +275,7 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
   float pre_bias[RPW], pre_scale[RPW];
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr) {
-    const int r = RPW * wave + rr;
+    const int r = RPW * ewave + rr;
     const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
     const int mc = m < M ? m : M - 1;
     pre_bias[rr] = d.bias ? d.bias[mc] : 0.0f;
@@ -283,7 +289,7 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
   if (GNB && KS == 1 && d.store == 0 && nq < N) {
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
-      const int r = RPW * wave + rr;
+      const int r = RPW * ewave + rr;
       const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       if (m < M) gnb_warm += d.gnb_x[((int64_t)b * M + m) * N + nq];
     }
@@ -292,7 +298,7 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
   const int xfrag = 4 * hi * XSP + 4 * l31 + 4;                         // + (ci + cc) * XSP: the lane's input quad d1..d4
   const int hfrag = 4 * hi * XSP + (pg == 0 ? 3 : 4 + M4_BN);           // tile-edge halo (d0 of quad 0 / d5 of quad 31)
   const int afrag = TR ? 4 * hi * AS + l31 * KT : l31 * AS + 4 * hi * KT;
-  const bool edge = pg == 0 ? (l31 == 0) : (l31 == 31);
+  const bool edge = pg == 0 ? (l31 == 0) : (l31 == 31);                 // (NPG = 3: plane group 1 needs no halo)
 
   for (int c = 0; c < nrounds; ++c) {
 #ifdef ADP_KTRACE
@@ -356,7 +362,37 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
         } else {
           load_frag(av, qx, hx, sub);
         }
-        if (pg == 0) {
+        if constexpr (NPG == 3) {
+          if (pg == 0) {         // planes 0, 1
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              const float d1 = qx[cc][0], d2 = qx[cc][1], d3 = qx[cc][2], d4 = qx[cc][3];
+              const float nb = adp_lane_prev(0.0f, d4);
+              const float d0 = edge ? hx[cc] : nb;
+              const float g0 = av[cc * KT], g1 = av[cc * KT + 1], g2 = av[cc * KT + 2];
+              acc[0] = adp_mfma32(g0, fmaf(4.0f, d0, fmaf(-5.0f, d2, d4)), acc[0]);
+              acc[1] = adp_mfma32(g0 + g2 + g1, fmaf(-4.0f, d2, d4) + fmaf(-4.0f, d1, d3), acc[1]);
+            }
+          } else if (pg == 1) {  // planes 2, 3: no halo
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              const float d1 = qx[cc][0], d2 = qx[cc][1], d3 = qx[cc][2], d4 = qx[cc][3];
+              const float g0 = av[cc * KT], g1 = av[cc * KT + 1], g2 = av[cc * KT + 2];
+              acc[0] = adp_mfma32(g0 + g2 - g1, fmaf(-4.0f, d2, d4) - fmaf(-4.0f, d1, d3), acc[0]);
+              acc[1] = adp_mfma32(fmaf(2.0f, g1, fmaf(4.0f, g2, g0)), fmaf(2.0f, d3 - d1, d4 - d2), acc[1]);
+            }
+          } else {               // planes 4, 5
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              const float d1 = qx[cc][0], d2 = qx[cc][1], d3 = qx[cc][2], d4 = qx[cc][3];
+              const float nb = adp_lane_next(0.0f, d1);
+              const float d5 = edge ? hx[cc] : nb;
+              const float g0 = av[cc * KT], g1 = av[cc * KT + 1], g2 = av[cc * KT + 2];
+              acc[0] = adp_mfma32(fmaf(-2.0f, g1, fmaf(4.0f, g2, g0)), fmaf(-2.0f, d3 - d1, d4 - d2), acc[0]);
+              acc[1] = adp_mfma32(g2, fmaf(4.0f, d1, fmaf(-5.0f, d3, d5)), acc[1]);
+            }
+          }
+        } else if (pg == 0) {
 #pragma unroll
           for (int cc = 0; cc < 4; ++cc) {
             const float d1 = qx[cc][0], d2 = qx[cc][1], d3 = qx[cc][2], d4 = qx[cc][3];
@@ -367,7 +403,7 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
             const float gs = g0 + g2;
             acc[0] = adp_mfma32(g0, fmaf(4.0f, d0, fmaf(-5.0f, d2, d4)), acc[0]);
             acc[1] = adp_mfma32(gs + g1, t1 + t2, acc[1]);
-            acc[2] = adp_mfma32(gs - g1, t1 - t2, acc[2]);
+            acc[PPW - 1] = adp_mfma32(gs - g1, t1 - t2, acc[PPW - 1]);
           }
         } else {
 #pragma unroll
@@ -380,7 +416,7 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
             const float gq = fmaf(4.0f, g2, g0);
             acc[0] = adp_mfma32(fmaf(2.0f, g1, gq), fmaf(2.0f, t4, t3), acc[0]);
             acc[1] = adp_mfma32(fmaf(-2.0f, g1, gq), fmaf(-2.0f, t4, t3), acc[1]);
-            acc[2] = adp_mfma32(g2, fmaf(4.0f, d1, fmaf(-5.0f, d3, d5)), acc[2]);
+            acc[PPW - 1] = adp_mfma32(g2, fmaf(4.0f, d1, fmaf(-5.0f, d3, d5)), acc[PPW - 1]);
           }
         }
       }
@@ -401,7 +437,7 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
               //  the light block lives on 128 registers)
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
-      const int r = RPW * wave + rr;
+      const int r = RPW * ewave + rr;
       const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       gnb_xq[rr] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       if (m < M && nq < N) gnb_xq[rr] = *reinterpret_cast<const f32x4*>(d.gnb_x + ((int64_t)b * M + m) * N + nq);
@@ -412,12 +448,16 @@ __global__ __launch_bounds__((M4_NKG * M4_NPG + M4_NLD) * 64, (M4_NKG == 2 && BK
 
   // ---- plane / K-group exchange through LDS: tile (kg, plane P) at smem[(kg * 6 + P) * 1024 + r * 64 + lane]
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    float* rp = smem + (kg * 6 + pg * 3 + p) * 1024 + lane;
+  for (int p = 0; p < PPW; ++p) {
+    float* rp = smem + (kg * 6 + pg * PPW + p) * 1024 + lane;
 #pragma unroll
     for (int r = 0; r < 16; ++r) rp[r * 64] = acc[p][r];
   }
   __syncthreads();
+  if (NPG == 3 && wave >= NEPI) {  // (the last four MMA waves have no rows to finish)
+    ADP_KT_DUMP(blockIdx.x);
+    return;
+  }
 
   // ---- output transform: this wave finishes accumulator rows RPW * wave .. (for both halves of the wave)
   const bool nok = nq < N;  // N % 4 == 0: a quad is inside or outside
@@ -672,7 +712,13 @@ int adp_conv_mm4(const adp_conv_desc& d, void* stream) {
   // 64-channel chunks (24 MFMAs per wave and barrier instead of 12) unless ADP_MM4_BKT=32: step 12.15 -> 12.09 ms
   const char* e = getenv("ADP_MM4_BKT");
   const int bkt = (e ? atoi(e) : 64) == 64 && d.R % 64 == 0 ? 64 : 32;
-  if (bkt == 64) {  // (one register stage: a second one with 64-channel chunks spills)
+  const char* e3 = getenv("ADP_MM4_NPG");
+  if (bkt == 64 && e3 && atoi(e3) == 3) {  // 16-wave block: three plane groups (see NPG)
+    const dim3 block16((4 * 3 + M4_NLD) * 64);
+    if (d.transposed && d.gnb_ab) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64, 4, 1, true, 3>), grid, block16, stream, d);
+    else if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64, 4, 1, false, 3>), grid, block16, stream, d);
+    else ADP_LAUNCH((conv_mm4_kernel<false, 1, 64, 4, 1, false, 3>), grid, block16, stream, d);
+  } else if (bkt == 64) {  // (one register stage: a second one with 64-channel chunks spills)
     if (d.transposed && d.gnb_ab) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64, 4, 1, true>), grid, block, stream, d);
     else if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64, 4>), grid, block, stream, d);
     else ADP_LAUNCH((conv_mm4_kernel<false, 1, 64, 4>), grid, block, stream, d);

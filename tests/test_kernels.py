@@ -572,7 +572,7 @@ def test_wgrad_f43_trained_gradient_dynamic_range(dev, monkeypatch):
 
 @pytest.mark.parametrize("B,R,M,L,tr", [(2, 128, 64, 256, False), (1, 160, 160, 132, False), (2, 128, 128, 128, True),
                                         (1, 256, 32, 260, True), (3, 128, 96, 4, False), (1, 128, 64, 1024, False)])
-@pytest.mark.parametrize("bkt", ["32", "64", "light"])
+@pytest.mark.parametrize("bkt", ["32", "64", "light", "npg3"])
 def test_conv_mm4_winograd_f43(dev, B, R, M, L, tr, bkt, monkeypatch):
     """conv_mm4.hip: the Winograd F(4,3) block of the wide kernel-3 convs (MMA waves split the six planes and the chunk's
     channels; 32 rows x 128 positions per block): forward with bias / e_scale / residual / out_pre and the GroupNorm partial
@@ -583,6 +583,11 @@ def test_conv_mm4_winograd_f43(dev, B, R, M, L, tr, bkt, monkeypatch):
     monkeypatch.setenv("ADP_WINO4_MIN_R", "128")
     if bkt == "light":  # the 8-wave block with two K groups (short-K layers, two blocks per CU): one GroupNorm entry per tile
         monkeypatch.setenv("ADP_MM4_LIGHT_MIN_BLOCKS", "1")
+    elif bkt == "npg3":  # the 16-wave block: three plane groups of two planes (ADP_MM4_NPG=3, 64-channel chunks)
+        if R % 64:
+            pytest.skip("64-channel chunks")
+        monkeypatch.setenv("ADP_MM4_LIGHT_MIN_BLOCKS", "1000000")
+        monkeypatch.setenv("ADP_MM4_NPG", "3")
     else:
         monkeypatch.setenv("ADP_MM4_LIGHT_MIN_BLOCKS", "1000000")
         monkeypatch.setenv("ADP_MM4_BKT", bkt)
