@@ -183,9 +183,12 @@ def roofline_leg(model, x, top: int = 14):
             return pmc[name]
         if name.endswith(">"):
             stem = name[:-1] + ", "
-            for k, v in pmc.items():
-                if k.startswith(stem) and all(t.strip() in ("false", "0") for t in k[len(stem):-1].split(",")):
-                    return v
+            cand = [k for k in pmc if k.startswith(stem)]
+            if len(cand) == 1:
+                return pmc[cand[0]]
+            for k in cand:  # several instantiations share the stem: the one whose extra parameters are all defaults of the "off" kind
+                if all(t.strip() in ("false", "0") for t in k[len(stem):-1].split(",")):
+                    return pmc[k]
         return None
 
     def entry(name, a):
