@@ -40,6 +40,7 @@ namespace {
 
 constexpr int M4_BM = 32, M4_BN = 128, M4_KT = 3;
 constexpr int M4_NPG = 2, M4_NLD = 4;
+constexpr bool M4_VPRE_DEFAULT = false;
 constexpr int M4_NLT = M4_NLD * 64;
 constexpr int M4_XSP = M4_BN + 8, M4_XQ = M4_XSP / 4;         // X row: positions n0-4 .. n0+131
 
@@ -67,11 +68,17 @@ __device__ __forceinline__ f32x4 m4_load_xquad(const float* p) {
 // NPG: plane groups = MMA waves per K group.  2: three planes per wave (the blocks above).  3 (round 6, 16-wave block: 12 MMA + 4
 //      loader waves, THREE MMA waves per SIMD, two planes each -- (0,1) with the left halo, (2,3) with none, (4,5) with the right one):
 //      a wave's stream is a third shorter, three of them interleave on the SIMD; the first eight MMA waves run the epilogue
-template <bool TR, int PD, int BKT, int M4_NKG, int UP = 1, bool GNB = false, int NPG = M4_NPG>
+// VPRE (round 6, full 128-position tiles, UP = 1): the LOADER waves stage the TRANSFORMED inputs -- V[quad][plane][channel], the six
+//      planes of a quad for four channels per 16-byte store -- instead of raw x rows: the MMA waves then read one float4 per plane
+//      and four channels and spend no VALU / DPP on B^T d at all (their stream was ~45 VALU + 20 LDS instructions per 12 MFMAs and
+//      closed the barrier; the loaders had the slack).
+template <bool TR, int PD, int BKT, int M4_NKG, int UP = 1, bool GNB = false, int NPG = M4_NPG, bool VPRE = false>
 // (second launch bound = waves per SIMD the register allocation has to leave room for: the light 8-wave block lives on TWO
 //  blocks per CU = 4 waves per SIMD = at most 128 registers; the 12-wave block on one = 3 per SIMD)
 __global__ __launch_bounds__((M4_NKG * NPG + M4_NLD) * 64, (M4_NKG == 2 && BKT == 32) ? 4 : 1) void conv_mm4_kernel(adp_conv_desc d) {
   static_assert(NPG == 2 || (NPG == 3 && M4_NKG == 4), "three plane groups: the 16-wave form of the 4-K-group block");
+  static_assert(!VPRE || (UP == 1 && NPG == 2), "pre-transformed inputs: plain convs, two plane groups");
+  constexpr int M4_QS = 6 * BKT + 4;                            // VPRE: floats per quad row of V (4 mod 64: conflict-free b128 columns)
   constexpr int M4_NMMA = M4_NKG * NPG, PPW = 6 / NPG;          // MMA waves; planes per wave
   constexpr int NEPI = NPG == 3 ? 8 : M4_NMMA, RPW = 16 / NEPI;  // waves that run the epilogue; accumulator rows each finishes (2 or 4)
   constexpr int M4_RED = M4_NKG * 6 * 1024;                     // parked partial tiles
@@ -79,7 +86,7 @@ __global__ __launch_bounds__((M4_NKG * NPG + M4_NLD) * 64, (M4_NKG == 2 && BKT =
   constexpr int M4_AROWS = TR ? BKT : M4_BM;
   constexpr int M4_AS = (TR ? M4_BM * M4_KT : M4_QK) + 4;       // A row stride (4 mod 8 dwords)
   constexpr int M4_AQ = (TR ? M4_BM * M4_KT : M4_QK) / 4;       // float4 per A row
-  constexpr int M4_A_ELEMS = M4_AROWS * M4_AS, M4_X_ELEMS = BKT * M4_XSP;
+  constexpr int M4_A_ELEMS = M4_AROWS * M4_AS, M4_X_ELEMS = VPRE ? 32 * M4_QS : BKT * M4_XSP;
   constexpr int M4_NA4 = (M4_AROWS * M4_AQ + M4_NLT - 1) / M4_NLT, M4_NX4 = (BKT * M4_XQ + M4_NLT - 1) / M4_NLT;
   constexpr int M4_STAGE = 2 * (M4_A_ELEMS + M4_X_ELEMS);
   constexpr int M4_SM = M4_RED > M4_STAGE ? M4_RED : M4_STAGE;
@@ -127,40 +134,86 @@ __global__ __launch_bounds__((M4_NKG * NPG + M4_NLD) * 64, (M4_NKG == 2 && BKT =
         // the 32 interior quads of an X row; the first 2 * BKT lanes stage the halo quads and are the only ones to test the row's ends.
         constexpr int LPR = M4_NLT / M4_AROWS;        // lanes per A row (8, or 4 for the 64-row transposed view)
         constexpr int NA = M4_AQ / LPR;               // A slots per lane (quad columns qq0 + LPR * i)
-        constexpr int NX = BKT / 8;                   // X slots per lane (rows row0 + 8 i of one interior quad column)
+        constexpr int NX = VPRE ? BKT / 32 * 4 : BKT / 8;  // X slots per lane (rows row0 + 8 i of one interior quad column;
+                                                      // VPRE: BKT / 32 groups of four consecutive channels of ONE quad)
         static_assert(M4_AQ % LPR == 0 && M4_NLT % M4_AROWS == 0, "A tile: whole quad columns per lane");
         const int arow = lt / LPR, aq0 = lt % LPR;
         const unsigned a_off = (unsigned)((TR ? arow * M * KT : arow * R * KT) + 4 * aq0);
         const int a_lds = arow * AS + 4 * aq0;
         const int xrow0 = lt >> 5, xpq = 1 + (lt & 31);
-        const unsigned x_off = (unsigned)(xrow0 * L + (n0 - 4 + 4 * xpq));
-        const int x_lds = xrow0 * XSP + 4 * xpq;
-        const bool halo_lane = lt < 2 * BKT;          // (wave-uniform: 2 * BKT is a multiple of 64)
+        const unsigned x_off = VPRE ? (unsigned)(4 * xrow0 * L + (n0 + 4 * (lt & 31))) : (unsigned)(xrow0 * L + (n0 - 4 + 4 * xpq));
+        const int x_lds = VPRE ? (lt & 31) * M4_QS + 4 * xrow0 : xrow0 * XSP + 4 * xpq;
+        // VPRE: quad q = lt & 31 of channels 4 (xrow0 + 8 g) .. + 3, g < BKT / 32; the tile-edge lanes (q = 0 / 31) fetch the one input
+        // beyond the tile themselves, the others take d0 / d5 from their neighbour lanes
+        const int vq = lt & 31;
+        const bool v_edge = vq == 0 || vq == 31;
+        const int v_hu = vq == 0 ? n0 - 1 : n0 + M4_BN;
+        const bool v_hok = v_hu >= 0 && v_hu < L;
+        const unsigned v_hoff = (unsigned)(4 * xrow0 * L + (v_hok ? v_hu : 0));
+        const bool halo_lane = !VPRE && lt < 2 * BKT;  // (wave-uniform: 2 * BKT is a multiple of 64)
         const int hrow = lt % BKT, hside = lt / BKT;  // side 0: positions n0-4 .. n0-1, side 1: n0+128 .. n0+131
         const int hu = hside ? n0 + M4_BN : n0 - 4;
         const bool h_ok = hu >= 0 && hu < L;          // (a property of the tile, not of the chunk)
         const unsigned h_off = (unsigned)(hrow * L + (h_ok ? hu : 0));
         const int h_lds = hrow * XSP + (hside ? M4_BN + 4 : 0);
-        f32x4 ra[PD][NA], rx[PD][NX], rh[PD];
-        auto load_chunk = [&](f32x4 (&a)[NA], f32x4 (&x)[NX], f32x4& h, int chunk) {
+        f32x4 ra[PD][NA], rx[PD][NX], rh[PD][2];  // (rh: the halo quad of a row; VPRE: d0 / d5 of the edge lanes, one float4 per group)
+        auto load_chunk = [&](f32x4 (&a)[NA], f32x4 (&x)[NX], f32x4 (&h)[2], int chunk) {
           const int rn = (c_lo + (chunk < nchunks ? chunk : nchunks - 1)) * BKT;  // (the tail re-reads the last chunk: never consumed)
           const float* wp = TR ? wbase + (int64_t)rn * M * KT : wbase + rn * KT;  // wave-uniform
           const float* xp = xb + (int64_t)rn * L;
 #pragma unroll
           for (int i = 0; i < NA; ++i) a[i] = *reinterpret_cast<const f32x4*>(wp + (a_off + (unsigned)(4 * LPR * i)));
+          if constexpr (VPRE) {
 #pragma unroll
-          for (int i = 0; i < NX; ++i) x[i] = *reinterpret_cast<const f32x4*>(xp + (x_off + (unsigned)(8 * i * L)));
-          if (halo_lane) h = *reinterpret_cast<const f32x4*>(xp + h_off);
+            for (int i = 0; i < NX; ++i)  // slot i = 4 g + k: channel 4 (xrow0 + 8 g) + k
+              x[i] = *reinterpret_cast<const f32x4*>(xp + (x_off + (unsigned)((32 * (i >> 2) + (i & 3)) * L)));
+            if (v_edge) {
+#pragma unroll
+              for (int g = 0; g < BKT / 32; ++g)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) h[g][k] = xp[v_hoff + (unsigned)((32 * g + k) * L)];
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = *reinterpret_cast<const f32x4*>(xp + (x_off + (unsigned)(8 * i * L)));
+            if (halo_lane) h[0] = *reinterpret_cast<const f32x4*>(xp + h_off);
+          }
         };
-        auto store_chunk = [&](const f32x4 (&a)[NA], const f32x4 (&x)[NX], const f32x4& h, int chunk) {
+        auto store_chunk = [&](const f32x4 (&a)[NA], const f32x4 (&x)[NX], const f32x4 (&h)[2], int chunk) {
           float* Ab = smem + (chunk & 1) * (M4_A_ELEMS + M4_X_ELEMS);
           float* Xb = Ab + M4_A_ELEMS;
 #pragma unroll
           for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(Ab + a_lds + 4 * LPR * i) = a[i];
+          if constexpr (VPRE) {
+            // V = B^T d per quad: (4 d0 - 5 d2 + d4, t1 + t2, t1 - t2 | t3 + 2 t4, t3 - 2 t4, 4 d1 - 5 d3 + d5), t1 = d4 - 4 d2, t2 = d3 - 4 d1,
+            // t3 = d4 - d2, t4 = d3 - d1; plane p of the group's four channels = one 16-byte store at V[q][p][4 (xrow0 + 8 g)]
+#pragma unroll
+            for (int g = 0; g < BKT / 32; ++g) {
+              f32x4 vp[6];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const f32x4 dq = x[4 * g + k];
+                const float d1 = dq[0], d2 = dq[1], d3 = dq[2], d4 = dq[3];
+                const float pv = adp_lane_prev(0.0f, d4), nx = adp_lane_next(0.0f, d1);
+                const float hv = v_hok ? h[g][k] : 0.0f;  // zero padding beyond the row's ends
+                const float d0 = vq == 0 ? hv : pv, d5 = vq == 31 ? hv : nx;
+                const float t1 = fmaf(-4.0f, d2, d4), t2 = fmaf(-4.0f, d1, d3), t3 = d4 - d2, t4 = d3 - d1;
+                vp[0][k] = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));
+                vp[1][k] = t1 + t2;
+                vp[2][k] = t1 - t2;
+                vp[3][k] = fmaf(2.0f, t4, t3);
+                vp[4][k] = fmaf(-2.0f, t4, t3);
+                vp[5][k] = fmaf(4.0f, d1, fmaf(-5.0f, d3, d5));
+              }
+#pragma unroll
+              for (int pl = 0; pl < 6; ++pl) *reinterpret_cast<f32x4*>(Xb + x_lds + 32 * g + pl * BKT) = vp[pl];
+            }
+            return;
+          }
 #pragma unroll
           for (int i = 0; i < NX; ++i) *reinterpret_cast<f32x4*>(Xb + x_lds + 8 * i * XSP) = x[i];
           if (halo_lane) {
-            f32x4 v = h;
+            f32x4 v = h[0];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = h_ok ? v[j] : 0.0f;  // zero padding
             *reinterpret_cast<f32x4*>(Xb + h_lds) = v;
@@ -316,6 +369,13 @@ __global__ __launch_bounds__((M4_NKG * NPG + M4_NLD) * 64, (M4_NKG == 2 && BKT =
       // group exposed an LDS round trip to the matrix pipe (tools/ktrace.py: ~4600 cycles per chunk and SIMD for 3072 of MFMAs).
       auto load_frag = [&](float (&av)[4 * KT], f32x4 (&qx)[4], float (&hx)[4], int sub) {
         const int ci = kg * CPK + sub * 8;
+        if constexpr (VPRE) {  // qx[p] = plane 3 pg + p of this lane's quad for channels ci + 4 hi .. + 3 (one float4); hx unused
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) qx[pl] = *reinterpret_cast<const f32x4*>(Xb + l31 * M4_QS + (3 * pg + pl) * BKT + ci + 4 * hi);
+          qx[3] = qx[0];
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) hx[cc] = 0.0f;
+        }
         // av[cc * 3 + t] = tap t of channel ci + cc + 4 * hi for this lane's output row
         if (!TR) {
           const float* ap = Ab + afrag + ci * KT;
@@ -331,10 +391,12 @@ __global__ __launch_bounds__((M4_NKG * NPG + M4_NLD) * 64, (M4_NKG == 2 && BKT =
 #pragma unroll
             for (int t = 0; t < KT; ++t) av[cc * KT + t] = Ab[afrag + (ci + cc) * AS + (KT - 1 - t)];
         }
+        if constexpr (!VPRE) {
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          qx[cc] = *reinterpret_cast<const f32x4*>(Xb + xfrag + (ci + cc) * XSP);
-          hx[cc] = Xb[hfrag + (ci + cc) * XSP];  // one address per half-wave: a broadcast read
+          for (int cc = 0; cc < 4; ++cc) {
+            qx[cc] = *reinterpret_cast<const f32x4*>(Xb + xfrag + (ci + cc) * XSP);
+            hx[cc] = Xb[hfrag + (ci + cc) * XSP];  // one address per half-wave: a broadcast read
+          }
         }
       };
       // (measured round 6 on the 12-wave block: no gain -- the pipe's idle time is the lock step of the two MMA waves of a SIMD
@@ -362,7 +424,27 @@ __global__ __launch_bounds__((M4_NKG * NPG + M4_NLD) * 64, (M4_NKG == 2 && BKT =
         } else {
           load_frag(av, qx, hx, sub);
         }
-        if constexpr (NPG == 3) {
+        if constexpr (VPRE) {
+          if (pg == 0) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              const float g0 = av[cc * KT], g1 = av[cc * KT + 1], g2 = av[cc * KT + 2];
+              const float gs = g0 + g2;
+              acc[0] = adp_mfma32(g0, qx[0][cc], acc[0]);
+              acc[1] = adp_mfma32(gs + g1, qx[1][cc], acc[1]);
+              acc[2] = adp_mfma32(gs - g1, qx[2][cc], acc[2]);
+            }
+          } else {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              const float g0 = av[cc * KT], g1 = av[cc * KT + 1], g2 = av[cc * KT + 2];
+              const float gq = fmaf(4.0f, g2, g0);
+              acc[0] = adp_mfma32(fmaf(2.0f, g1, gq), qx[0][cc], acc[0]);
+              acc[1] = adp_mfma32(fmaf(-2.0f, g1, gq), qx[1][cc], acc[1]);
+              acc[2] = adp_mfma32(g2, qx[2][cc], acc[2]);
+            }
+          }
+        } else if constexpr (NPG == 3) {
           if (pg == 0) {         // planes 0, 1
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
@@ -700,6 +782,17 @@ int adp_conv_mm4(const adp_conv_desc& d, void* stream) {
     }
     return ADP_LAUNCH_OK();
   }
+  // loaders stage the transformed inputs (VPRE) for full 128-position tiles: ADP_MM4_VPRE=0 / 1 (A/B)
+  const char* ev = getenv("ADP_MM4_VPRE");
+  const bool vpre = d.N % M4_BN == 0 && (ev ? ev[0] != '0' : M4_VPRE_DEFAULT);
+  if (m4_nkg(d) == 2 && vpre) {
+    const dim3 block((2 * M4_NPG + M4_NLD) * 64);
+    if (d.transposed && d.gnb_ab) ADP_LAUNCH((conv_mm4_kernel<true, 1, 32, 2, 1, true, 2, true>), grid, block, stream, d);
+    else if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 32, 2, 1, false, 2, true>), grid, block, stream, d);
+    else ADP_LAUNCH((conv_mm4_kernel<false, 1, 32, 2, 1, false, 2, true>), grid, block, stream, d);
+    if (ADP_LAUNCH_OK() != ADP_OK) return ADP_ERR_LAUNCH;
+    return ks > 1 ? adp_conv_splitk_reduce(d, ks, stream) : ADP_OK;
+  }
   if (m4_nkg(d) == 2) {  // light block: 32-channel chunks (60 KB of LDS: two blocks per CU)
     const dim3 block((2 * M4_NPG + M4_NLD) * 64);
     if (d.transposed && d.gnb_ab) ADP_LAUNCH((conv_mm4_kernel<true, 1, 32, 2, 1, true>), grid, block, stream, d);
@@ -718,6 +811,10 @@ int adp_conv_mm4(const adp_conv_desc& d, void* stream) {
     if (d.transposed && d.gnb_ab) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64, 4, 1, true, 3>), grid, block16, stream, d);
     else if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64, 4, 1, false, 3>), grid, block16, stream, d);
     else ADP_LAUNCH((conv_mm4_kernel<false, 1, 64, 4, 1, false, 3>), grid, block16, stream, d);
+  } else if (bkt == 64 && vpre) {
+    if (d.transposed && d.gnb_ab) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64, 4, 1, true, 2, true>), grid, block, stream, d);
+    else if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64, 4, 1, false, 2, true>), grid, block, stream, d);
+    else ADP_LAUNCH((conv_mm4_kernel<false, 1, 64, 4, 1, false, 2, true>), grid, block, stream, d);
   } else if (bkt == 64) {  // (one register stage: a second one with 64-channel chunks spills)
     if (d.transposed && d.gnb_ab) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64, 4, 1, true>), grid, block, stream, d);
     else if (d.transposed) ADP_LAUNCH((conv_mm4_kernel<true, 1, 64, 4>), grid, block, stream, d);

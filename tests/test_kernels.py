@@ -571,8 +571,9 @@ def test_wgrad_f43_trained_gradient_dynamic_range(dev, monkeypatch):
 
 
 @pytest.mark.parametrize("B,R,M,L,tr", [(2, 128, 64, 256, False), (1, 160, 160, 132, False), (2, 128, 128, 128, True),
-                                        (1, 256, 32, 260, True), (3, 128, 96, 4, False), (1, 128, 64, 1024, False)])
-@pytest.mark.parametrize("bkt", ["32", "64", "light", "npg3"])
+                                        (1, 256, 32, 260, True), (3, 128, 96, 4, False), (1, 128, 64, 1024, False),
+                                        (1, 192, 64, 384, True)])
+@pytest.mark.parametrize("bkt", ["32", "64", "light", "npg3", "vpre64", "vprelight"])
 def test_conv_mm4_winograd_f43(dev, B, R, M, L, tr, bkt, monkeypatch):
     """conv_mm4.hip: the Winograd F(4,3) block of the wide kernel-3 convs (MMA waves split the six planes and the chunk's
     channels; 32 rows x 128 positions per block): forward with bias / e_scale / residual / out_pre and the GroupNorm partial
@@ -581,6 +582,13 @@ def test_conv_mm4_winograd_f43(dev, B, R, M, L, tr, bkt, monkeypatch):
     from ctypes import byref
     monkeypatch.setenv("ADP_MM4_MIN_BLOCKS", "1")
     monkeypatch.setenv("ADP_WINO4_MIN_R", "128")
+    if bkt.startswith("vpre"):  # the loader waves stage the transformed inputs (full 128-position tiles only)
+        if L % 128 or (bkt == "vpre64" and R % 64):
+            pytest.skip("pre-transformed inputs: whole 128-position tiles")
+        monkeypatch.setenv("ADP_MM4_VPRE", "1")
+        bkt = "light" if bkt == "vprelight" else "64"
+    else:
+        monkeypatch.setenv("ADP_MM4_VPRE", "0")
     if bkt == "light":  # the 8-wave block with two K groups (short-K layers, two blocks per CU): one GroupNorm entry per tile
         monkeypatch.setenv("ADP_MM4_LIGHT_MIN_BLOCKS", "1")
     elif bkt == "npg3":  # the 16-wave block: three plane groups of two planes (ADP_MM4_NPG=3, 64-channel chunks)
